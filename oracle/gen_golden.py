@@ -1,0 +1,233 @@
+#!/usr/bin/env python3
+"""Generate tests/golden/*.npz by running the REFERENCE's own Drone.step / Racer.step.
+
+TEST INFRASTRUCTURE - runs only in the build container, where /root/reference is mounted:
+
+    PYTHONDONTWRITEBYTECODE=1 MPLBACKEND=Agg python3 -W ignore oracle/gen_golden.py
+
+The reference is imported (never copied): src/utils/components.py:73-248 (Drone) and
+tests/racer_drone_test.py:68-103 (Racer), with import-time stubs for modules that are not
+installed / not usable on Linux (cv2, drawnow, icosphere, the winmm joystick).  Outputs are plain
+data: seeded inputs (rounded through float32 so fp32 and fp64 consumers see identical sticks) and
+the float64 states the reference produced.  The GPU box never sees the reference, only these files.
+"""
+import contextlib
+import copy
+import io
+import os
+import sys
+import types
+
+import numpy as np
+
+sys.dont_write_bytecode = True
+REPO = os.path.abspath(os.path.join(os.path.dirname(os.path.abspath(__file__)), ".."))
+REF = "/root/reference"
+OUT = os.path.join(REPO, "tests", "golden")
+sys.path.insert(0, REPO)
+
+from fpyv_amd import sticks  # noqa: E402  (input profiles only; no physics)
+
+
+def import_reference():
+    sys.path[:0] = [os.path.join(REF, "src"), REF]
+    for n in ("cv2", "drawnow"):
+        sys.modules[n] = types.ModuleType(n)
+    sys.modules["drawnow"].drawnow = lambda *a, **k: None
+    ico = types.ModuleType("icosphere")
+    ico.icosphere = lambda nu=1: (np.zeros((1, 3)), np.zeros((1, 3), int))
+    sys.modules["icosphere"] = ico
+    gs = types.ModuleType("utils.get_sticks")
+
+    class Joystick:
+        status = False
+
+        def calibrate(self, *a, **k):
+            pass
+
+    gs.Joystick = Joystick
+    sys.modules["utils.get_sticks"] = gs
+    from utils import yaml_helper
+    from utils.components import Drone
+    from utils.flight_time_calculator import read_motor_test_report
+    import tests.racer_drone_test as racer_mod
+    return yaml_helper, Drone, read_motor_test_report, racer_mod
+
+
+def ref_params(yaml_helper, fps):
+    p = yaml_helper.yaml_reader(os.path.join(REF, "config", "params.yaml"))
+    p["drone"]["motor_test_report_path"] = os.path.join(REF, "config", "t_motos_f80_motor_test.csv")
+    p["simulator"]["fps"] = fps
+    return p
+
+
+def run_drone(Drone, params, actions, position, velocity, ypr, wind=(0, 0, 0), stride=10):
+    """actions [T,4] float32.  Snapshots after steps stride, 2*stride, ..., and always after T."""
+    T = actions.shape[0]
+    a64 = actions.astype(np.float64)
+    wind = np.asarray(wind, dtype=np.float64)
+    snaps = sorted(set(list(range(stride, T + 1, stride)) + [T]))
+    rec = {k: [] for k in ("state", "R", "prev_rates", "prev_thrust", "accel")}
+    done = np.zeros(T, dtype=np.uint8)
+    with contextlib.redirect_stdout(io.StringIO()):
+        d = Drone(copy.deepcopy(params))
+        d.reset(position=np.asarray(position, float), velocity=np.asarray(velocity, float),
+                ypr=np.asarray(ypr, float))
+        for t in range(T):
+            ret = d.step(action=a64[t].copy(), wind_velocity_vector=wind, object_list=[])
+            done[t] = bool(d.done)
+            if t + 1 in snaps:
+                rec["state"].append(d.state.copy())
+                rec["R"].append(d.rotation_matrix.copy())
+                rec["prev_rates"].append(np.asarray(d.prev_rates, float).copy())
+                rec["prev_thrust"].append(float(d.prev_thrust))
+                rec["accel"].append(np.asarray(ret[2], float).copy())
+    out = {k: np.asarray(v) for k, v in rec.items()}
+    out["done"] = done
+    out["snap_steps"] = np.asarray(snaps)
+    out["ret_RT"] = np.asarray(ret[0], float)
+    out["ret_gyro"] = np.asarray(ret[1], float)
+    return out, d
+
+
+def stack(cases):
+    """list of per-drone dicts -> dict of arrays with a leading drone axis"""
+    return {k: np.stack([c[k] for c in cases]) for k in cases[0]}
+
+
+def save(name, **arrs):
+    path = os.path.join(OUT, name + ".npz")
+    np.savez_compressed(path, **arrs)
+    print(f"{name:28s} {os.path.getsize(path) / 1024:8.1f} KiB")
+
+
+def main():
+    os.makedirs(OUT, exist_ok=True)
+    yaml_helper, Drone, read_report, racer_mod = import_reference()
+    P1k = ref_params(yaml_helper, 1000)
+    P60 = ref_params(yaml_helper, 60)
+    p0, v0, o0 = [0, 0, 10.0], [1.0, 0, 0], [0, 0, 0]
+
+    # ---- constants the reference derives at construction (components.py:96-142) ----
+    with contextlib.redirect_stdout(io.StringIO()):
+        d = Drone(copy.deepcopy(P1k))
+        blocks = read_report(P1k["drone"]["motor_test_report_path"])
+    thr = d.motor_test_report["Throttle"].values.astype(float)
+    thrust_n = d.n_motors * d.motor_test_report["Thrust"].values.astype(float) / 1000 * d.gravity
+    from utils.flight_time_calculator import model_xy
+    xs = np.array([-1.0, -0.9, -0.5, 0.0, 0.37, 1.0, 1.2])
+    save("params_golden",
+         thrust_poly=np.asarray(model_xy(thr, thrust_n).coeffs, float),
+         inverse_thrust_poly=np.asarray(model_xy(thrust_n, thr).coeffs, float),
+         min_throttle_in_force=float(d.min_throttle_in_force),
+         max_throttle_in_force=float(d.max_throttle_in_force),
+         stick_samples=xs, thrust_samples=np.array([float(d.throttle2thrust(x)) for x in xs]),
+         thrust2throttle_samples=np.array([float(d.thrust2throttle(y)) for y in (0.0, 5.0, 31.5, 60.0, 90.0)]),
+         motors_relative_position=d.motors_relative_position, cross_section_areas=d.cross_section_areas,
+         dt=float(d.dt), mass=float(d.mass), gravity=float(d.gravity), max_rates=float(d.max_rates),
+         drag_coef=d.drag_coef, rates_transition_rate=float(d.rates_transition_rate),
+         thrust_transition_rate=float(d.thrust_transition_rate),
+         n_blocks=len(blocks),
+         block_throttle=np.stack([b["Throttle"].values.astype(float) for b in blocks]),
+         block_thrust_g=np.stack([b["Thrust"].values.astype(float) for b in blocks]))
+
+    # ---- G1: config 1 - one drone, zero sticks, 10 000 steps at dt = 1 ms ----
+    c, _ = run_drone(Drone, P1k, sticks.zeros(10000, 1)[:, 0], p0, v0, o0, stride=100)
+    save("g1_zero_10k", dt=1e-3, actions=sticks.zeros(10000, 1), init_position=[p0], init_velocity=[v0],
+         init_ypr=[o0], wind=np.zeros(3), **stack([c]))
+
+    # ---- G1b: default fps = 60 (large per-step angles), sin/cos sticks, 600 steps ----
+    ids = [0, 1024, 2048, 3072]
+    a = sticks.sinusoid(600, 4096, 1 / 60, amplitude=0.8, drone_ids=ids)
+    cs = [run_drone(Drone, P60, a[:, k], p0, v0, o0, stride=10)[0] for k in range(len(ids))]
+    save("g1b_fps60_sin", dt=1 / 60, actions=a, drone_ids=ids, init_position=[p0] * 4, init_velocity=[v0] * 4,
+         init_ypr=[o0] * 4, wind=np.zeros(3), **stack(cs))
+
+    # ---- G2: config 2 sample - 16 of 4096 drones, constant throttle + sin/cos roll/pitch ----
+    ids = list(range(0, 4096, 256))
+    a = sticks.sinusoid(1000, 4096, 1e-3, drone_ids=ids)
+    cs = [run_drone(Drone, P1k, a[:, k], p0, v0, o0)[0] for k in range(len(ids))]
+    save("g2_sin_4096", dt=1e-3, actions=a, drone_ids=ids, init_position=[p0] * 16, init_velocity=[v0] * 16,
+         init_ypr=[o0] * 16, wind=np.zeros(3), **stack(cs))
+
+    # ---- G3: EMA-smoothed Gaussian sticks (noise_smooth_test.py:6-12), seeds 0..7 ----
+    ids = list(range(8))
+    a = sticks.ema_noise(1000, ids, seed=0)
+    cs = [run_drone(Drone, P1k, a[:, k], p0, v0, o0)[0] for k in range(8)]
+    save("g3_ema_noise", dt=1e-3, actions=a, drone_ids=ids, init_position=[p0] * 8, init_velocity=[v0] * 8,
+         init_ypr=[o0] * 8, wind=np.zeros(3), **stack(cs))
+
+    # ---- G4: saturated / out-of-range sticks (clip path, negative thrust, cubic extrapolation) ----
+    acts = np.array([[1.0, -1.0, 1.0, -1.0], [1.5, -2.0, 0.3, 1.0], [-3.0, 0.2, -1.0, 1.2], [0.5, 0, 0, 0],
+                     [0.0, 0.0, 2.0, -1.3], [-1, -1, -1, 0.25]])
+    a = np.stack([sticks.constant(1000, 1, x)[:, 0] for x in acts], axis=1)
+    cs = [run_drone(Drone, P1k, a[:, k], p0, v0, o0)[0] for k in range(len(acts))]
+    save("g4_saturated", dt=1e-3, actions=a, init_position=[p0] * 6, init_velocity=[v0] * 6,
+         init_ypr=[o0] * 6, wind=np.zeros(3), **stack(cs))
+
+    # ---- G5: non-identity initial attitude, wind != 0, per-drone initial conditions ----
+    rng = np.random.default_rng(5)
+    n5 = 6
+    ip = np.round(rng.uniform([-5, -5, 5], [5, 5, 30], (n5, 3)), 3)
+    iv = np.round(rng.uniform(-4, 4, (n5, 3)), 3)
+    io_ = np.round(rng.uniform([-180, -80, -180], [180, 80, 180], (n5, 3)), 2)
+    wind = np.array([2.0, -1.0, 0.5])
+    a = sticks.ema_noise(1000, list(range(100, 100 + n5)), seed=0)
+    a[..., 3] += np.float32(-0.3)
+    cs = [run_drone(Drone, P1k, a[:, k], ip[k], iv[k], io_[k], wind=wind)[0] for k in range(n5)]
+    save("g5_attitude_wind", dt=1e-3, actions=a, init_position=ip, init_velocity=iv, init_ypr=io_, wind=wind,
+         **stack(cs))
+
+    # ---- G6: ground contact - throttle -1 from low altitude, done flips and is NOT latched ----
+    ip = np.array([[0, 0, 0.15], [0, 0, 0.12], [0, 0, 0.11]])
+    iv = np.array([[1.0, 0, 0], [0, 0, -1.0], [0, 0, -2.0]])
+    io_ = np.array([[0, 0, 0], [25.0, -10, 0], [0, 60, 30]])
+    acts = np.array([[0, 0, 0, -1.0], [0.2, 0.1, 0, -1.0], [0, 0, 0, 1.0]])   # last one recovers above z=0
+    a = np.stack([sticks.constant(400, 1, x)[:, 0] for x in acts], axis=1)
+    cs = [run_drone(Drone, P1k, a[:, k], ip[k], iv[k], io_[k], stride=1)[0] for k in range(3)]
+    save("g6_ground", dt=1e-3, actions=a, init_position=ip, init_velocity=iv, init_ypr=io_, wind=np.zeros(3),
+         **stack(cs))
+
+    # ---- G7/G8: Racer (rate PID -> torque) ----
+    def run_racer(actions, pid_values, stride=10):
+        T = actions.shape[0]
+        env = racer_mod.Racer(prop_size_inch=5, pid_values=pid_values)
+        env.reset()
+        rec = {k: [] for k in ("omega", "quat_xyzw", "matrix", "position", "velocity", "i_error")}
+        snaps = sorted(set(list(range(stride, T + 1, stride)) + [T]))
+        with contextlib.redirect_stdout(io.StringIO()):
+            for t in range(T):
+                env.step(action=[float(x) for x in actions[t]])
+                if t + 1 in snaps:
+                    rec["omega"].append(np.array(env.angular_velocity, float))
+                    rec["quat_xyzw"].append(env.orientation.as_quat())
+                    rec["matrix"].append(env.orientation.as_matrix())
+                    rec["position"].append(env.position.copy())
+                    rec["velocity"].append(env.linear_velocity.copy())
+                    rec["i_error"].append(np.array([v.i_error for v in env.pid.values()], float))
+        out = {k: np.asarray(v) for k, v in rec.items()}
+        out["snap_steps"] = np.asarray(snaps)
+        out["inertia"] = np.asarray(env.I, float)
+        return out
+
+    pid_main = {"roll": [2, 0, 0], "pitch": [2, 0, 0], "yaw": [0.1, 0, 0]}
+    a = np.zeros((1000, 4), dtype=np.float32)        # racer_drone_test.py:113-122
+    a[:21] = [80, 10, 0, 0]
+    a[21:] = [-30, -50, 0, 0]
+    save("g7_racer_main", dt=1e-3, actions=a[:, None, :], pid=np.array([pid_main[k] for k in ("roll", "pitch", "yaw")], float),
+         **stack([run_racer(a, pid_main)]))
+
+    pid_full = {"roll": [0.004, 0.02, 1e-6], "pitch": [0.003, 0.01, 2e-6], "yaw": [0.002, 0.005, 0.0]}
+    t = np.arange(1000) * 1e-3
+    a = np.stack([3 * np.sin(2 * np.pi * t), 2 * np.cos(2 * np.pi * 0.5 * t), 0.5 * np.ones_like(t),
+                  4 + np.sin(2 * np.pi * 2 * t)], axis=1).astype(np.float32)
+    save("g8_racer_pid_thrust", dt=1e-3, actions=a[:, None, :],
+         pid=np.array([pid_full[k] for k in ("roll", "pitch", "yaw")], float),
+         **stack([run_racer(a, pid_full)]))
+
+    leftovers = [r for r, ds, _ in os.walk(REF) if "__pycache__" in ds]
+    assert not leftovers, f"bytecode written into the reference mount: {leftovers}"
+
+
+if __name__ == "__main__":
+    main()

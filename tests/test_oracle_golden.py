@@ -1,0 +1,111 @@
+"""The float64 CPU restatement (oracle/) against golden vectors captured from the reference itself
+(oracle/gen_golden.py: Drone.step /root/reference/src/utils/components.py:220-248 and Racer.step
+/root/reference/tests/racer_drone_test.py:95-103).  This pins the oracle; every GPU parity test
+then compares the HIP path with the oracle."""
+import numpy as np
+import pytest
+
+from conftest import load_golden
+from oracle import oracle
+
+TOL = 1e-12   # float64 restatement vs float64 reference, <= 10 000 steps
+
+
+def _replay_drone(p, g, dt_fps=None):
+    """Step the oracle through the golden's actions, comparing at every snapshot."""
+    acts = g["actions"].astype(np.float64)            # [T, n, 4]
+    T, n = acts.shape[:2]
+    s = oracle.drone_initial_state(n, g["init_position"], g["init_velocity"], g["init_ypr"])
+    snaps = [int(x) for x in np.atleast_2d(g["snap_steps"])[0]]   # same for every drone of a file
+    done_all = np.zeros((n, T), dtype=np.uint8)
+    t0, worst = 0, 0.0
+    for k, t1 in enumerate(snaps):
+        _, accel, done = oracle.drone_run(p, s, acts[t0:t1], wind=g["wind"])
+        done_all[:, t1 - 1] = done          # dense only when the golden snapshots every step (g6)
+        t0 = t1
+        ref_state, ref_R = g["state"][:, k], g["R"][:, k].reshape(n, 9)
+        err = max(np.abs(s[:, 0:6] - ref_state).max(), np.abs(s[:, 6:15] - ref_R).max(),
+                  np.abs(s[:, 15:18] - g["prev_rates"][:, k]).max(),
+                  np.abs(s[:, 18] - g["prev_thrust"][:, k]).max())
+        scale = max(1.0, np.abs(ref_state).max())
+        worst = max(worst, err / scale)
+        assert err / scale < TOL, f"snapshot {k} (step {t1}): err {err:.3e}"
+        assert np.abs(accel - g["accel"][:, k]).max() < 1e-9 * max(1.0, np.abs(g["accel"][:, k]).max())
+        assert np.array_equal(done, g["done"][:, t1 - 1])
+    return s, done_all, worst
+
+
+@pytest.mark.parametrize("name", ["g2_sin_4096", "g3_ema_noise", "g4_saturated", "g5_attitude_wind"])
+def test_drone_step_matches_reference_1ms(params_1k, name):
+    _replay_drone(params_1k, load_golden(name))
+
+
+def test_config1_zero_sticks_10k(params_1k):
+    g = load_golden("g1_zero_10k")
+    s, _, _ = _replay_drone(params_1k, g)
+    # end state quoted in BASELINE.md / SURVEY.md App. B
+    np.testing.assert_allclose(s[0, 0:3], [2.5945630299793589, 0, 206.31842397173011], rtol=1e-12, atol=1e-12)
+    np.testing.assert_allclose(s[0, 3:6], [0.013260768981383429, 0, 20.545675068066696], rtol=1e-11, atol=1e-12)
+    np.testing.assert_allclose(s[0, 6:15].reshape(3, 3), np.eye(3), atol=1e-15)
+    assert abs(s[0, 18] - 31.508531191978875) < 1e-12
+
+
+def test_default_fps60(params_60):
+    _replay_drone(params_60, load_golden("g1b_fps60_sin"))
+
+
+def test_ground_contact_done_sequence(params_1k):
+    g = load_golden("g6_ground")
+    _, done_all, _ = _replay_drone(params_1k, g)
+    assert np.array_equal(done_all, g["done"])
+    assert g["done"][0].any() and not g["done"][0][0]          # falls through the ground
+    d2 = g["done"][2]
+    assert d2.any() and not d2[-1], "case 2 must recover: done is recomputed, not latched"
+
+
+def test_return_triple_last_step(params_1k):
+    """Drone.step returns (R.T, E(rates used as radians), R_new @ acc) - components.py:247-248."""
+    g = load_golden("g3_ema_noise")
+    n = g["actions"].shape[1]
+    s = oracle.drone_initial_state(n, g["init_position"], g["init_velocity"], g["init_ypr"])
+    oracle.drone_run(params_1k, s, g["actions"].astype(np.float64), wind=g["wind"])
+    for i in range(n):
+        np.testing.assert_allclose(s[i, 6:15].reshape(3, 3).T, g["ret_RT"][i], atol=1e-12)
+        r = s[i, 15:18]
+        np.testing.assert_allclose(oracle.euler_zyx_matrix(r[0], r[1], r[2]), g["ret_gyro"][i], atol=1e-9)
+
+
+def test_spot_value_constant_roll(params_1k):
+    """SURVEY App. A anchor: roll stick +0.5 for 1 000 steps at 1 ms -> q = [0.17291149, -0.98493737, 0, 0]."""
+    s = oracle.drone_initial_state(1, [0, 0, 10.0], [1.0, 0, 0], [0, 0, 0])
+    oracle.drone_run(params_1k, s, np.array([[0.5, 0, 0, 0]]), steps=1000)
+    np.testing.assert_allclose(s[0, 0:3], [0.9085033271961015, -10.52662258755109, 11.806584453407886], rtol=1e-12)
+    q = oracle.matrix_to_quat(s[0, 6:15])[0]
+    np.testing.assert_allclose(q, [0.17291149468075978, -0.9849373660325151, 0, 0], atol=1e-12)
+
+
+@pytest.mark.parametrize("name", ["g7_racer_main", "g8_racer_pid_thrust"])
+def test_racer_step_matches_reference(params_1k, name):
+    g = load_golden(name)
+    p = params_1k.replace(racer_pid=g["pid"], dt=float(g["dt"]))
+    np.testing.assert_allclose(p.racer_inertia, g["inertia"][0], rtol=1e-15)
+    acts = g["actions"].astype(np.float64)
+    s = oracle.racer_initial_state(1)
+    t0 = 0
+    for k, t1 in enumerate(int(x) for x in g["snap_steps"][0]):
+        oracle.racer_run(p, s, acts[t0:t1])
+        t0 = t1
+        np.testing.assert_allclose(s[0, 10:13], g["omega"][0, k], rtol=1e-11, atol=1e-11)
+        np.testing.assert_allclose(s[0, 0:3], g["position"][0, k], rtol=1e-10, atol=1e-12)
+        np.testing.assert_allclose(s[0, 3:6], g["velocity"][0, k], rtol=1e-10, atol=1e-12)
+        np.testing.assert_allclose(s[0, 13:16], g["i_error"][0, k], rtol=1e-11, atol=1e-12)
+        # quaternion sign is free; compare the rotation it encodes
+        qx, qy, qz, qw = s[0, 6:10]
+        M = oracle.quat_to_matrix(np.array([qw, qx, qy, qz]))[0]
+        np.testing.assert_allclose(M, g["matrix"][0, k], atol=2e-10)
+
+
+def test_racer_spot_value(params_1k):
+    g = load_golden("g7_racer_main")
+    np.testing.assert_allclose(g["omega"][0, -1], [-30, -50, 0], atol=1e-9)
+    np.testing.assert_allclose(g["inertia"][0], 0.002016125, rtol=1e-12)
