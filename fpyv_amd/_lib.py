@@ -1,0 +1,147 @@
+"""ctypes binding of libfpv_hip.so (include/fpv_abi.h).
+
+There is exactly one compute path: the HIP library.  If it is missing or does not load, importing
+this module's `lib()` raises - there is no CPU fallback.
+"""
+from __future__ import annotations
+
+import ctypes as C
+import os
+from typing import Optional
+
+import numpy as np
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "libfpv_hip.so")
+
+FPV_ABI_VERSION = 1
+FPV_OK = 0
+FPV_MODE_DRONE, FPV_MODE_RACER = 0, 1
+FPV_DRONE_ROWS, FPV_RACER_ROWS = 14, 20
+FPV_FLAG_AUTO_RESET = 1
+
+# state rows (fpv_abi.h)
+PX, PY, PZ, VX, VY, VZ, QW, QX, QY, QZ, RX, RY, RZ, THRUST = range(14)
+R_OMEGA, R_IERR, R_LERR, R_FIRST = 10, 13, 16, 19
+
+# every symbol include/fpv_abi.h declares
+EXPORTS = ("fpv_abi_version", "fpv_state_rows", "fpv_algorithmic_bytes", "fpv_create", "fpv_destroy",
+           "fpv_reset", "fpv_step", "fpv_rollout", "fpv_set_params", "fpv_set_tuning", "fpv_last_error",
+           "fpv_error_name")
+
+
+class FpvParams(C.Structure):
+    _fields_ = [
+        ("struct_size", C.c_uint32), ("mode", C.c_uint32), ("flags", C.c_uint32), ("racer_omega_dt", C.c_uint32),
+        ("dt", C.c_double), ("gravity", C.c_double), ("mass", C.c_double), ("max_rates", C.c_double),
+        ("rates_transition_rate", C.c_double), ("thrust_transition_rate", C.c_double),
+        ("thrust_poly", C.c_double * 4),
+        ("drag_coefficients", C.c_double * 3), ("cross_section_areas", C.c_double * 3),
+        ("air_density", C.c_double),
+        ("motor_xy", (C.c_double * 2) * 4),
+        ("init_position", C.c_double * 3), ("init_velocity", C.c_double * 3), ("init_quat", C.c_double * 4),
+        ("ceiling", C.c_double), ("goal", C.c_double * 3),
+        ("racer_mass", C.c_double), ("racer_inertia", C.c_double * 3), ("racer_pid", (C.c_double * 3) * 3),
+        ("racer_velocity_damping", C.c_double),
+    ]
+
+
+class FpvBuffers(C.Structure):
+    _fields_ = [
+        ("state", C.c_void_p), ("ld", C.c_int64), ("action", C.c_void_p), ("reward", C.c_void_p),
+        ("done", C.c_void_p), ("done_bits", C.c_void_p), ("accel", C.c_void_p), ("ep_return", C.c_void_p),
+        ("ep_length", C.c_void_p), ("last_return", C.c_void_p), ("last_length", C.c_void_p),
+        ("wind", C.c_float * 3), ("_pad", C.c_uint32),
+    ]
+
+
+def pack_params(p, auto_reset: bool = False) -> FpvParams:
+    """DroneParams -> fpv_params_t."""
+    s = FpvParams()
+    s.struct_size = C.sizeof(FpvParams)
+    s.mode = int(p.mode)
+    s.flags = FPV_FLAG_AUTO_RESET if auto_reset else 0
+    s.racer_omega_dt = int(bool(p.racer_omega_dt))
+    s.dt, s.gravity, s.mass, s.max_rates = float(p.dt), float(p.gravity), float(p.mass), float(p.max_rates)
+    s.rates_transition_rate = float(p.rates_transition_rate)
+    s.thrust_transition_rate = float(p.thrust_transition_rate)
+    s.thrust_poly[:] = [float(x) for x in p.thrust_poly]
+    s.drag_coefficients[:] = [float(x) for x in p.drag_coefficients]
+    s.cross_section_areas[:] = [float(x) for x in p.cross_section_areas]
+    s.air_density = float(p.air_density)
+    for m in range(4):
+        s.motor_xy[m][0], s.motor_xy[m][1] = float(p.motor_xy[m][0]), float(p.motor_xy[m][1])
+    s.init_position[:] = [float(x) for x in p.init_position]
+    s.init_velocity[:] = [float(x) for x in p.init_velocity]
+    s.init_quat[:] = [float(x) for x in p.init_quat]
+    s.ceiling = float(p.ceiling)
+    s.goal[:] = [float(x) for x in p.goal]
+    s.racer_mass = float(p.racer_mass)
+    s.racer_inertia[:] = [float(x) for x in p.racer_inertia]
+    for i in range(3):
+        for j in range(3):
+            s.racer_pid[i][j] = float(p.racer_pid[i][j])
+    s.racer_velocity_damping = float(p.racer_velocity_damping)
+    return s
+
+
+class FpvError(RuntimeError):
+    def __init__(self, code: int, name: str, msg: str):
+        super().__init__(f"{name} ({code}): {msg}")
+        self.code, self.name = code, name
+
+
+_lib: Optional[C.CDLL] = None
+
+
+def lib() -> C.CDLL:
+    """Load libfpv_hip.so (once).  torch is imported first so that the HIP runtime torch ships
+    (same SONAME, libamdhip64.so.7) is the one both sides use - one runtime, shared streams and
+    device pointers."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not os.path.isfile(LIB_PATH):
+        raise ImportError(f"{LIB_PATH} is missing - build it with `python -c 'import __graft_entry__ as g; g.build()'` "
+                          "(hipcc --offload-arch=gfx950).  fpyv_amd has no CPU fallback.")
+    import torch  # noqa: F401  (loads libamdhip64 / libhsa-runtime64 from torch/lib)
+    L = C.CDLL(LIB_PATH, mode=C.RTLD_LOCAL)
+    vp, i64, pp, pb = C.c_void_p, C.c_int64, C.POINTER(FpvParams), C.POINTER(FpvBuffers)
+    L.fpv_abi_version.restype = C.c_int
+    L.fpv_state_rows.argtypes = [C.c_int]
+    L.fpv_algorithmic_bytes.argtypes = [C.c_int]
+    L.fpv_create.argtypes = [pp, i64, C.c_int, C.POINTER(vp)]
+    L.fpv_destroy.argtypes = [vp]
+    L.fpv_destroy.restype = None
+    L.fpv_reset.argtypes = [vp, pb, vp, vp, vp, vp, vp]
+    L.fpv_step.argtypes = [vp, pb, vp]
+    L.fpv_rollout.argtypes = [vp, pb, C.c_int, i64, i64, vp]
+    L.fpv_set_params.argtypes = [vp, pp]
+    L.fpv_set_tuning.argtypes = [vp, C.c_int]
+    L.fpv_last_error.restype = C.c_char_p
+    L.fpv_error_name.argtypes = [C.c_int]
+    L.fpv_error_name.restype = C.c_char_p
+    if L.fpv_abi_version() != FPV_ABI_VERSION:
+        raise ImportError(f"libfpv_hip.so ABI {L.fpv_abi_version()} != binding {FPV_ABI_VERSION}")
+    _lib = L
+    return L
+
+
+def check(rc: int) -> int:
+    if rc < 0:
+        L = lib()
+        raise FpvError(rc, L.fpv_error_name(rc).decode(), L.fpv_last_error().decode())
+    return rc
+
+
+def state_rows(mode: int) -> int:
+    return FPV_DRONE_ROWS if mode == FPV_MODE_DRONE else FPV_RACER_ROWS
+
+
+def algorithmic_bytes(mode: int) -> int:
+    """state read + write, action read, reward + done write (fpv_algorithmic_bytes)."""
+    return state_rows(mode) * 8 + 16 + 4 + 1
+
+
+def as_float32_soa(a: np.ndarray) -> np.ndarray:
+    return np.ascontiguousarray(a, dtype=np.float32)

@@ -1,0 +1,73 @@
+// fpv_derive.h - host-side narrowing of fpv_params_t (double) to the kernel constants FpvK (fp32).
+//
+// Everything that can be folded on the host in double precision is folded here, once per
+// fpv_create/fpv_set_params, so the per-lane fp32 arithmetic starts from correctly rounded
+// constants:
+//   * the thrust cubic over throttle PERCENT (components.py:136, x = 100(a+1)/2) is re-expanded
+//     around the stick value a (x = 50a + 50): same polynomial, but |a| <= 1 keeps the fp32 Horner
+//     terms the size of the result instead of cancelling ~90 N against ~-36 N;
+//   * 0.5*rho*Cd*A/m per body axis (kinematics.py:36 followed by components.py:243);
+//   * deg/s -> half-angle per step, 0.5 * pi/180 * dt (kinematics.py:29).
+#pragma once
+
+#include <math.h>
+#include <string.h>
+
+#include "../../include/fpv_abi.h"
+#include "fpv_math.h"
+
+// Returns 0 or an FPV_E* code; *why receives a static message on failure.
+static inline int fpv_derive_constants(const fpv_params_t* P, FpvK* K, bool* big_angle, const char** why)
+{
+    *why = "";
+    if (P->struct_size != sizeof(fpv_params_t)) { *why = "fpv_params_t.struct_size does not match this library"; return FPV_EINVAL; }
+    if (P->mode != FPV_MODE_DRONE && P->mode != FPV_MODE_RACER) { *why = "unknown mode"; return FPV_EINVAL; }
+    if (!(P->dt > 0) || !isfinite(P->dt)) { *why = "dt must be positive and finite"; return FPV_EPARAM; }
+    if (!(P->mass > 0)) { *why = "mass must be positive"; return FPV_EPARAM; }
+    if (!(P->max_rates >= 0) || !isfinite(P->max_rates)) { *why = "max_rates must be finite and >= 0"; return FPV_EPARAM; }
+    if (P->mode == FPV_MODE_RACER) {
+        if (!(P->racer_mass > 0)) { *why = "racer_mass must be positive"; return FPV_EPARAM; }
+        for (int i = 0; i < 3; ++i)
+            if (!(P->racer_inertia[i] > 0)) { *why = "racer_inertia must be positive"; return FPV_EPARAM; }
+    }
+    const double qn = sqrt(P->init_quat[0] * P->init_quat[0] + P->init_quat[1] * P->init_quat[1] +
+                           P->init_quat[2] * P->init_quat[2] + P->init_quat[3] * P->init_quat[3]);
+    if (!(fabs(qn - 1.0) < 1e-6)) { *why = "init_quat must be a unit quaternion"; return FPV_EPARAM; }
+
+    memset(K, 0, sizeof(*K));
+    K->dt = (float)P->dt;
+    K->max_rates = (float)P->max_rates;
+    K->kr = (float)P->rates_transition_rate;
+    K->omkr = (float)(1.0 - P->rates_transition_rate);
+    K->kt = (float)P->thrust_transition_rate;
+    K->omkt = (float)(1.0 - P->thrust_transition_rate);
+    const double c3 = P->thrust_poly[0], c2 = P->thrust_poly[1], c1 = P->thrust_poly[2], c0 = P->thrust_poly[3];
+    const double h = 50.0;   // x = h*a + h
+    K->d3 = (float)(c3 * h * h * h);
+    K->d2 = (float)(3 * c3 * h * h * h + c2 * h * h);
+    K->d1 = (float)(3 * c3 * h * h * h + 2 * c2 * h * h + c1 * h);
+    K->d0 = (float)(c3 * h * h * h + c2 * h * h + c1 * h + c0);
+    K->inv_mass = (float)(1.0 / P->mass);
+    K->g = (float)P->gravity;
+    for (int i = 0; i < 3; ++i)
+        K->kdrag_m[i] = (float)(0.5 * P->drag_coefficients[i] * P->air_density * P->cross_section_areas[i] / P->mass);
+    K->half_k = (float)(0.5 * (M_PI / 180.0) * P->dt);
+    for (int m = 0; m < 4; ++m) { K->motor_x[m] = (float)P->motor_xy[m][0]; K->motor_y[m] = (float)P->motor_xy[m][1]; }
+    for (int i = 0; i < 3; ++i) { K->p0[i] = (float)P->init_position[i]; K->v0[i] = (float)P->init_velocity[i]; K->goal[i] = (float)P->goal[i]; }
+    for (int i = 0; i < 4; ++i) K->q0[i] = (float)(P->init_quat[i] / qn);
+    K->ceiling = (float)P->ceiling;        // +inf stays +inf
+    K->r_dt = (float)P->dt;
+    K->r_inv_dt = (float)(1.0 / P->dt);
+    K->r_inv_mass = (float)(1.0 / (P->racer_mass > 0 ? P->racer_mass : 1.0));
+    K->r_damp = (float)P->racer_velocity_damping;
+    K->r_ang_k = P->racer_omega_dt ? (float)P->dt : 1.0f;
+    for (int i = 0; i < 3; ++i) {
+        K->r_dt_over_I[i] = (float)(P->dt / (P->racer_inertia[i] > 0 ? P->racer_inertia[i] : 1.0));
+        for (int j = 0; j < 3; ++j) K->r_pid[i][j] = (float)P->racer_pid[i][j];
+    }
+    K->flags = P->flags;
+    // |rates| <= max_rates always (clip + convex low-pass from 0), so the largest half-angle of one
+    // step is known here; beyond pi/4 the short polynomial is no longer exact to fp32.
+    *big_angle = (0.5 * (M_PI / 180.0) * P->dt * P->max_rates) > 0.78;
+    return FPV_OK;
+}

@@ -1,0 +1,426 @@
+// fpv_hip.hip - gfx950 kernels + the C ABI of include/fpv_abi.h.
+//
+// One lane = one drone (or DPL drones, strided by the block width so every wave instruction still
+// touches 256 contiguous bytes of each SoA row).  A step is: 14 row loads + one 16-byte action
+// load per drone -> ~250 flop in registers (fpv_math.h) -> 14 row stores + reward + done.  There is
+// no reuse, no cross-lane data flow and no dense contraction, so the kernel is bound by HBM / the
+// Infinity Cache; the only wave-level primitive on the data path is the ballot that bit-packs the
+// done mask.  Uniform constants ride in the kernel argument (SGPRs).
+//
+// Replaces, per drone: Drone.step /root/reference/src/utils/components.py:220-248,
+// Drone.reset :150-169, Racer.step /root/reference/tests/racer_drone_test.py:95-103.
+#include <hip/hip_runtime.h>
+
+#include <math.h>
+#include <stdint.h>
+#include <stdio.h>
+#include <string.h>
+
+#include <new>
+#include <string>
+
+#include "../../include/fpv_abi.h"
+#include "fpv_derive.h"
+#include "fpv_math.h"
+
+namespace {
+
+constexpr int kBlock = 256;   // 4 wave64 per workgroup
+
+struct FpvBufD {
+    float* state;
+    int64_t ld;
+    const float4* action;
+    float* reward;
+    uint8_t* done;
+    unsigned long long* done_bits;
+    float* accel;
+    float* ep_return;
+    int32_t* ep_length;
+    float* last_return;
+    int32_t* last_length;
+    float wx, wy, wz;
+};
+
+__device__ __forceinline__ void ld_drone(const float* __restrict__ st, int64_t ld, int64_t i, FpvDroneState& s)
+{
+    s.px = st[FPV_PX * ld + i]; s.py = st[FPV_PY * ld + i]; s.pz = st[FPV_PZ * ld + i];
+    s.vx = st[FPV_VX * ld + i]; s.vy = st[FPV_VY * ld + i]; s.vz = st[FPV_VZ * ld + i];
+    s.q.w = st[FPV_QW * ld + i]; s.q.x = st[FPV_QX * ld + i]; s.q.y = st[FPV_QY * ld + i]; s.q.z = st[FPV_QZ * ld + i];
+    s.rx = st[FPV_RX * ld + i]; s.ry = st[FPV_RY * ld + i]; s.rz = st[FPV_RZ * ld + i];
+    s.thrust = st[FPV_THRUST * ld + i];
+}
+
+__device__ __forceinline__ void st_drone(float* __restrict__ st, int64_t ld, int64_t i, const FpvDroneState& s)
+{
+    st[FPV_PX * ld + i] = s.px; st[FPV_PY * ld + i] = s.py; st[FPV_PZ * ld + i] = s.pz;
+    st[FPV_VX * ld + i] = s.vx; st[FPV_VY * ld + i] = s.vy; st[FPV_VZ * ld + i] = s.vz;
+    st[FPV_QW * ld + i] = s.q.w; st[FPV_QX * ld + i] = s.q.x; st[FPV_QY * ld + i] = s.q.y; st[FPV_QZ * ld + i] = s.q.z;
+    st[FPV_RX * ld + i] = s.rx; st[FPV_RY * ld + i] = s.ry; st[FPV_RZ * ld + i] = s.rz;
+    st[FPV_THRUST * ld + i] = s.thrust;
+}
+
+// Episode bookkeeping + done outputs shared by both modes.  `done` is wave-divergent data;
+// all pointer tests are wave-uniform scalar branches.
+__device__ __forceinline__ void emit_outputs(const FpvBufD& B, int64_t i, bool live, float reward, bool done)
+{
+    // done_bits: one ballot per 64 consecutive drones; i - lane is a multiple of 64 by construction
+    const unsigned long long mask = __ballot(live && done);
+    if (B.done_bits && (threadIdx.x & 63) == 0 && live) B.done_bits[i >> 6] = mask;
+    if (!live) return;
+    if (B.reward) B.reward[i] = reward;
+    if (B.done) B.done[i] = done ? 1 : 0;
+    if (B.ep_return) {
+        const float r = B.ep_return[i] + reward;
+        const int32_t l = B.ep_length[i] + 1;
+        if (done) {
+            if (B.last_return) B.last_return[i] = r;
+            if (B.last_length) B.last_length[i] = l;
+        }
+        B.ep_return[i] = done ? 0.0f : r;
+        B.ep_length[i] = done ? 0 : l;
+    }
+}
+
+template <int DPL, bool BIG>
+__global__ __launch_bounds__(kBlock) void fpv_drone_step_kernel(const FpvK K, const FpvBufD B, const int64_t n)
+{
+    const int64_t base = (int64_t)blockIdx.x * (kBlock * DPL) + threadIdx.x;
+    FpvDroneState s[DPL];
+    float4 a[DPL];
+    bool live[DPL];
+    // issue every load of every drone of this lane before the first use
+#pragma unroll
+    for (int j = 0; j < DPL; ++j) {
+        const int64_t i = base + (int64_t)j * kBlock;
+        live[j] = i < n;
+        if (live[j]) {
+            a[j] = B.action[i];
+            ld_drone(B.state, B.ld, i, s[j]);
+        }
+    }
+#pragma unroll
+    for (int j = 0; j < DPL; ++j) {
+        const int64_t i = base + (int64_t)j * kBlock;
+        FpvStepOut o;
+        o.done = false; o.reward = 0.0f; o.ax = o.ay = o.az = 0.0f;
+        if (live[j]) {
+            o = fpv_drone_step_lane<BIG>(K, s[j], a[j].x, a[j].y, a[j].z, a[j].w, B.wx, B.wy, B.wz);
+            if (B.accel) {
+                B.accel[0 * B.ld + i] = o.ax; B.accel[1 * B.ld + i] = o.ay; B.accel[2 * B.ld + i] = o.az;
+            }
+            if ((K.flags & FPV_FLAG_AUTO_RESET) && o.done) fpv_drone_reset_lane(K, s[j]);
+            st_drone(B.state, B.ld, i, s[j]);
+        }
+        emit_outputs(B, i, live[j], o.reward, o.done);
+    }
+}
+
+__device__ __forceinline__ void ld_racer(const float* __restrict__ st, int64_t ld, int64_t i, FpvRacerState& s)
+{
+    s.px = st[FPV_PX * ld + i]; s.py = st[FPV_PY * ld + i]; s.pz = st[FPV_PZ * ld + i];
+    s.vx = st[FPV_VX * ld + i]; s.vy = st[FPV_VY * ld + i]; s.vz = st[FPV_VZ * ld + i];
+    s.q.w = st[FPV_QW * ld + i]; s.q.x = st[FPV_QX * ld + i]; s.q.y = st[FPV_QY * ld + i]; s.q.z = st[FPV_QZ * ld + i];
+#pragma unroll
+    for (int k = 0; k < 3; ++k) {
+        s.w[k] = st[(FPV_R_OMEGA + k) * ld + i];
+        s.ierr[k] = st[(FPV_R_IERR + k) * ld + i];
+        s.lerr[k] = st[(FPV_R_LERR + k) * ld + i];
+    }
+    s.first = st[FPV_R_FIRST * ld + i];
+}
+
+__device__ __forceinline__ void st_racer(float* __restrict__ st, int64_t ld, int64_t i, const FpvRacerState& s)
+{
+    st[FPV_PX * ld + i] = s.px; st[FPV_PY * ld + i] = s.py; st[FPV_PZ * ld + i] = s.pz;
+    st[FPV_VX * ld + i] = s.vx; st[FPV_VY * ld + i] = s.vy; st[FPV_VZ * ld + i] = s.vz;
+    st[FPV_QW * ld + i] = s.q.w; st[FPV_QX * ld + i] = s.q.x; st[FPV_QY * ld + i] = s.q.y; st[FPV_QZ * ld + i] = s.q.z;
+#pragma unroll
+    for (int k = 0; k < 3; ++k) {
+        st[(FPV_R_OMEGA + k) * ld + i] = s.w[k];
+        st[(FPV_R_IERR + k) * ld + i] = s.ierr[k];
+        st[(FPV_R_LERR + k) * ld + i] = s.lerr[k];
+    }
+    st[FPV_R_FIRST * ld + i] = s.first;
+}
+
+__global__ __launch_bounds__(kBlock) void fpv_racer_step_kernel(const FpvK K, const FpvBufD B, const int64_t n)
+{
+    const int64_t i = (int64_t)blockIdx.x * kBlock + threadIdx.x;
+    const bool live = i < n;
+    float reward = 0.0f;
+    bool done = false;
+    if (live) {
+        FpvRacerState s;
+        const float4 a = B.action[i];
+        ld_racer(B.state, B.ld, i, s);
+        reward = fpv_racer_step_lane(K, s, a.x, a.y, a.z, a.w);
+        done = !(fabsf(s.pz) <= K.ceiling);            // the Racer has no ground; build-defined ceiling only
+        if ((K.flags & FPV_FLAG_AUTO_RESET) && done) fpv_racer_reset_lane(s);
+        st_racer(B.state, B.ld, i, s);
+    }
+    emit_outputs(B, i, live, reward, done);
+}
+
+// Drone.reset (components.py:150-169): p, v, R = E(deg2rad(ypr)) with the triple consumed as
+// (roll, pitch, yaw); prev_rates = 0, prev_thrust = 0, done = False.  Racer.reset: zeros + identity.
+__global__ __launch_bounds__(kBlock) void fpv_reset_kernel(const FpvK K, const FpvBufD B, const int mode,
+                                                           const uint8_t* __restrict__ mask,
+                                                           const float* __restrict__ pos,
+                                                           const float* __restrict__ vel,
+                                                           const float* __restrict__ ypr, const int64_t n)
+{
+    const int64_t i = (int64_t)blockIdx.x * kBlock + threadIdx.x;
+    if (i >= n) return;
+    if (mask && !mask[i]) return;
+    if (mode == FPV_MODE_DRONE) {
+        FpvDroneState s;
+        fpv_drone_reset_lane(K, s);
+        if (pos) { s.px = pos[3 * i]; s.py = pos[3 * i + 1]; s.pz = pos[3 * i + 2]; }
+        if (vel) { s.vx = vel[3 * i]; s.vy = vel[3 * i + 1]; s.vz = vel[3 * i + 2]; }
+        if (ypr) {
+            const float d2r_half = 0.5f * 0.017453292519943295f;
+            float sr, cr, sp, cp, sy, cy;
+            fpv_sincos_full(ypr[3 * i] * d2r_half, &sr, &cr);
+            fpv_sincos_full(ypr[3 * i + 1] * d2r_half, &sp, &cp);
+            fpv_sincos_full(ypr[3 * i + 2] * d2r_half, &sy, &cy);
+            s.q.w = fmaf(cy * cp, cr, sy * sp * sr);
+            s.q.x = fmaf(cy * cp, sr, -(sy * sp * cr));
+            s.q.y = fmaf(cy * sp, cr, sy * cp * sr);
+            s.q.z = fmaf(sy * cp, cr, -(cy * sp * sr));
+        }
+        st_drone(B.state, B.ld, i, s);
+    } else {
+        FpvRacerState s;
+        fpv_racer_reset_lane(s);
+        st_racer(B.state, B.ld, i, s);
+    }
+    if (B.done) B.done[i] = 0;
+    if (B.ep_return) { B.ep_return[i] = 0.0f; B.ep_length[i] = 0; }
+}
+
+thread_local std::string g_err;
+
+int fail(int code, const std::string& msg)
+{
+    g_err = msg;
+    return code;
+}
+
+int hip_fail(hipError_t e, const char* what)
+{
+    return fail(e == hipErrorNoDevice || e == hipErrorInvalidDevice ? FPV_ENODEV : FPV_EHIP,
+                std::string(what) + ": " + hipGetErrorString(e));
+}
+
+}  // namespace
+
+struct fpv_env {
+    FpvK K;
+    fpv_params_t P;
+    int64_t n;
+    int device;
+    int mode;
+    int dpl;        // drones per lane (1, 2 or 4)
+    bool big_angle;
+};
+
+namespace {
+
+int check_buffers(const fpv_env* h, const fpv_buffers_t* b, bool need_action)
+{
+    if (!h) return fail(FPV_EINVAL, "null handle");
+    if (!b) return fail(FPV_EINVAL, "null fpv_buffers_t");
+    if (!b->state) return fail(FPV_EINVAL, "fpv_buffers_t.state is null");
+    if (need_action && !b->action) return fail(FPV_EINVAL, "fpv_buffers_t.action is null");
+    if (b->ld < h->n) return fail(FPV_EALIGN, "fpv_buffers_t.ld is smaller than the number of drones");
+    if (b->ld % 4) return fail(FPV_EALIGN, "fpv_buffers_t.ld must be a multiple of 4 floats");
+    if (((uintptr_t)b->state & 15) || ((uintptr_t)b->action & 15))
+        return fail(FPV_EALIGN, "state and action must be 16-byte aligned");
+    if ((uintptr_t)b->done_bits & 7) return fail(FPV_EALIGN, "done_bits must be 8-byte aligned");
+    if ((b->ep_return == nullptr) != (b->ep_length == nullptr))
+        return fail(FPV_EINVAL, "ep_return and ep_length must be given together");
+    if ((b->last_return || b->last_length) && !b->ep_return)
+        return fail(FPV_EINVAL, "last_return/last_length need ep_return/ep_length");
+    return FPV_OK;
+}
+
+FpvBufD to_device_view(const fpv_buffers_t* b)
+{
+    FpvBufD d;
+    d.state = b->state; d.ld = b->ld; d.action = reinterpret_cast<const float4*>(b->action);
+    d.reward = b->reward; d.done = b->done; d.done_bits = reinterpret_cast<unsigned long long*>(b->done_bits);
+    d.accel = b->accel; d.ep_return = b->ep_return; d.ep_length = b->ep_length;
+    d.last_return = b->last_return; d.last_length = b->last_length;
+    d.wx = b->wind[0]; d.wy = b->wind[1]; d.wz = b->wind[2];
+    return d;
+}
+
+int bind_device(const fpv_env* h)
+{
+    int cur = -1;
+    hipError_t e = hipGetDevice(&cur);
+    if (e != hipSuccess) return hip_fail(e, "hipGetDevice");
+    if (cur != h->device) {
+        e = hipSetDevice(h->device);
+        if (e != hipSuccess) return hip_fail(e, "hipSetDevice");
+    }
+    return FPV_OK;
+}
+
+template <int DPL>
+void launch_drone(const fpv_env* h, const FpvBufD& d, hipStream_t s)
+{
+    const int64_t per_block = (int64_t)kBlock * DPL;
+    const dim3 grid((unsigned)((h->n + per_block - 1) / per_block));
+    if (h->big_angle)
+        hipLaunchKernelGGL((fpv_drone_step_kernel<DPL, true>), grid, dim3(kBlock), 0, s, h->K, d, h->n);
+    else
+        hipLaunchKernelGGL((fpv_drone_step_kernel<DPL, false>), grid, dim3(kBlock), 0, s, h->K, d, h->n);
+}
+
+int launch_step(const fpv_env* h, const FpvBufD& d, hipStream_t s)
+{
+    if (h->mode == FPV_MODE_DRONE) {
+        switch (h->dpl) {
+            case 4: launch_drone<4>(h, d, s); break;
+            case 2: launch_drone<2>(h, d, s); break;
+            default: launch_drone<1>(h, d, s); break;
+        }
+    } else {
+        const dim3 grid((unsigned)((h->n + kBlock - 1) / kBlock));
+        hipLaunchKernelGGL(fpv_racer_step_kernel, grid, dim3(kBlock), 0, s, h->K, d, h->n);
+    }
+    const hipError_t e = hipGetLastError();
+    if (e != hipSuccess) return hip_fail(e, "step kernel launch");
+    return FPV_OK;
+}
+
+}  // namespace
+
+extern "C" {
+
+int fpv_abi_version(void) { return FPV_ABI_VERSION; }
+
+int fpv_state_rows(int mode)
+{
+    if (mode == FPV_MODE_DRONE) return FPV_DRONE_ROWS;
+    if (mode == FPV_MODE_RACER) return FPV_RACER_ROWS;
+    return fail(FPV_EINVAL, "unknown mode");
+}
+
+int fpv_algorithmic_bytes(int mode)
+{
+    const int rows = fpv_state_rows(mode);
+    if (rows < 0) return rows;
+    return rows * 4 * 2 + 16 + 4 + 1;   // state read + write, action read, reward + done write
+}
+
+int fpv_create(const fpv_params_t* params, int64_t n, int device, fpv_handle_t* out)
+{
+    if (!params || !out) return fail(FPV_EINVAL, "null argument");
+    *out = nullptr;
+    if (n <= 0) return fail(FPV_EINVAL, "n must be positive");
+    if (n > ((int64_t)1 << 31) * kBlock) return fail(FPV_EINVAL, "n exceeds the launch grid");
+    int count = 0;
+    hipError_t e = hipGetDeviceCount(&count);
+    if (e != hipSuccess || count <= 0)
+        return fail(FPV_ENODEV, std::string("no HIP device available: ") + (e != hipSuccess ? hipGetErrorString(e) : "device count is 0"));
+    if (device < 0 || device >= count) return fail(FPV_ENODEV, "device index out of range");
+    FpvK K;
+    bool big = false;
+    const char* why = "";
+    const int rc = fpv_derive_constants(params, &K, &big, &why);
+    if (rc != FPV_OK) return fail(rc, why);
+    fpv_env* h = new (std::nothrow) fpv_env;
+    if (!h) return fail(FPV_EINVAL, "out of host memory");
+    h->K = K; h->P = *params; h->n = n; h->device = device; h->mode = (int)params->mode;
+    h->dpl = 1; h->big_angle = big;
+    *out = h;
+    return FPV_OK;
+}
+
+void fpv_destroy(fpv_handle_t h) { delete h; }
+
+int fpv_set_params(fpv_handle_t h, const fpv_params_t* params)
+{
+    if (!h || !params) return fail(FPV_EINVAL, "null argument");
+    if ((int)params->mode != h->mode) return fail(FPV_EINVAL, "mode cannot change on a live handle (state layout differs)");
+    FpvK K;
+    bool big = false;
+    const char* why = "";
+    const int rc = fpv_derive_constants(params, &K, &big, &why);
+    if (rc != FPV_OK) return fail(rc, why);
+    h->K = K; h->P = *params; h->big_angle = big;
+    return FPV_OK;
+}
+
+int fpv_set_tuning(fpv_handle_t h, int drones_per_lane)
+{
+    if (!h) return fail(FPV_EINVAL, "null handle");
+    if (drones_per_lane == 0) drones_per_lane = 1;
+    if (drones_per_lane != 1 && drones_per_lane != 2 && drones_per_lane != 4)
+        return fail(FPV_EINVAL, "drones_per_lane must be 0, 1, 2 or 4");
+    h->dpl = drones_per_lane;
+    return FPV_OK;
+}
+
+int fpv_reset(fpv_handle_t h, const fpv_buffers_t* b, const uint8_t* mask, const float* position,
+              const float* velocity, const float* ypr_deg, void* stream)
+{
+    int rc = check_buffers(h, b, false);
+    if (rc != FPV_OK) return rc;
+    if ((rc = bind_device(h)) != FPV_OK) return rc;
+    const dim3 grid((unsigned)((h->n + kBlock - 1) / kBlock));
+    hipLaunchKernelGGL(fpv_reset_kernel, grid, dim3(kBlock), 0, (hipStream_t)stream, h->K, to_device_view(b),
+                       h->mode, mask, position, velocity, ypr_deg, h->n);
+    const hipError_t e = hipGetLastError();
+    if (e != hipSuccess) return hip_fail(e, "reset kernel launch");
+    return FPV_OK;
+}
+
+int fpv_step(fpv_handle_t h, const fpv_buffers_t* b, void* stream)
+{
+    int rc = check_buffers(h, b, true);
+    if (rc != FPV_OK) return rc;
+    if ((rc = bind_device(h)) != FPV_OK) return rc;
+    return launch_step(h, to_device_view(b), (hipStream_t)stream);
+}
+
+int fpv_rollout(fpv_handle_t h, const fpv_buffers_t* b, int k, int64_t action_stride, int64_t out_stride,
+                void* stream)
+{
+    int rc = check_buffers(h, b, true);
+    if (rc != FPV_OK) return rc;
+    if (k < 0) return fail(FPV_EINVAL, "k must be >= 0");
+    if (action_stride % 4) return fail(FPV_EALIGN, "action_stride must keep 16-byte alignment");
+    if ((rc = bind_device(h)) != FPV_OK) return rc;
+    FpvBufD d = to_device_view(b);
+    const float* a0 = b->action;
+    for (int t = 0; t < k; ++t) {
+        d.action = reinterpret_cast<const float4*>(a0 + (int64_t)t * action_stride);
+        if (out_stride) {
+            if (b->reward) d.reward = b->reward + (int64_t)t * out_stride;
+            if (b->done) d.done = b->done + (int64_t)t * out_stride;
+        }
+        if ((rc = launch_step(h, d, (hipStream_t)stream)) != FPV_OK) return rc;
+    }
+    return FPV_OK;
+}
+
+const char* fpv_last_error(void) { return g_err.c_str(); }
+
+const char* fpv_error_name(int code)
+{
+    switch (code) {
+        case FPV_OK: return "FPV_OK";
+        case FPV_EINVAL: return "FPV_EINVAL";
+        case FPV_EHIP: return "FPV_EHIP";
+        case FPV_ENODEV: return "FPV_ENODEV";
+        case FPV_EALIGN: return "FPV_EALIGN";
+        case FPV_EPARAM: return "FPV_EPARAM";
+        default: return "FPV_E?";
+    }
+}
+
+}  // extern "C"

@@ -1,0 +1,268 @@
+// fpv_math.h - per-drone (per-lane) fp32 arithmetic of the fused step kernel.
+//
+// One call advances ONE drone by one step entirely in registers; fpv_kernels.hip wraps it with the
+// coalesced SoA loads/stores.  The same header is compiled for the host by the test-only lane
+// model (oracle/lane_model.cpp) so that fp32 rounding can be studied without a GPU; the product
+// never runs it on the CPU.
+//
+// Arithmetic follows SURVEY.md App. A (paths relative to /root/reference):
+//   (1)-(3) stick -> rates / thrust low-pass     src/utils/components.py:185-194
+//   (4)     thrust along R[:,2]                  src/utils/kinematics.py:48-49
+//   (5)     body-frame quadratic drag, gravity   src/utils/kinematics.py:33-45
+//           ground flag on the pre-update pose   src/utils/components.py:235-240
+//   (6)     explicit Euler, p first with old v   src/utils/kinematics.py:21-22
+//           attitude R <- R*E^T applied TWICE    src/utils/kinematics.py:23,:27-30 + components.py:218
+// with the attitude carried as a unit quaternion: R*E^T*E^T  <=>  q (x) conj(q_E)^2.
+//
+// Rounding discipline: every a*b+c that matters is an explicit fmaf and the translation units are
+// built with -ffp-contract=off, so the host lane model and the gfx950 kernel agree bit for bit
+// (sqrtf and '/' are correctly rounded on both).
+#pragma once
+
+#include <math.h>
+#include <stdint.h>
+
+#if defined(__HIPCC__)
+#define FPV_HD __host__ __device__ __forceinline__
+#else
+#define FPV_HD static inline
+#endif
+
+// Uniform per-launch constants (kernel argument -> SGPRs).  Derived in double on the host.
+struct FpvK {
+    float dt;
+    float max_rates;        // deg/s
+    float kr, omkr;         // rates_transition_rate, 1 - it
+    float kt, omkt;         // thrust_transition_rate, 1 - it
+    float d3, d2, d1, d0;   // thrust [N] as a cubic in the throttle STICK (x = 50a+50 substituted)
+    float inv_mass;
+    float g;
+    float kdrag_m[3];       // 0.5*rho*Cd_i*A_i / m
+    float half_k;           // 0.5 * pi/180 * dt : deg/s -> half-angle per step
+    float motor_x[4], motor_y[4];
+    float p0[3], v0[3], q0[4];
+    float ceiling;
+    float goal[3];
+    // Racer
+    float r_dt, r_inv_dt, r_inv_mass, r_damp, r_ang_k;
+    float r_dt_over_I[3];
+    float r_pid[3][3];
+    uint32_t flags;
+};
+
+struct FpvQuat { float w, x, y, z; };
+
+// sin and cos for |x| <= pi/4 (half-angles of one step's rotation).  Truncation error
+// < 3e-9 relative; no range reduction, no slow path.
+FPV_HD void fpv_sincos_small(float x, float* s, float* c)
+{
+    const float x2 = x * x;
+    float ps = fmaf(x2, 2.7557319e-6f, -1.9841270e-4f);
+    ps = fmaf(ps, x2, 8.3333333e-3f);
+    ps = fmaf(ps, x2, -1.6666667e-1f);
+    *s = fmaf(x * x2, ps, x);
+    float pc = fmaf(x2, -2.7557319e-7f, 2.4801587e-5f);
+    pc = fmaf(pc, x2, -1.3888889e-3f);
+    pc = fmaf(pc, x2, 4.1666667e-2f);
+    pc = fmaf(pc, x2, -0.5f);
+    *c = fmaf(x2, pc, 1.0f);
+}
+
+// Full-range sin/cos (library range reduction): used when one step can rotate by more than 90
+// degrees about an axis (half-angle > pi/4) and by the Racer, whose per-step angle is unbounded.
+FPV_HD void fpv_sincos_full(float x, float* s, float* c)
+{
+#if defined(__HIP_DEVICE_COMPILE__)
+    sincosf(x, s, c);
+#else
+    *s = sinf(x); *c = cosf(x);
+#endif
+}
+
+template <bool BIG>
+FPV_HD void fpv_sincos(float x, float* s, float* c)
+{
+    if (BIG) fpv_sincos_full(x, s, c);
+    else fpv_sincos_small(x, s, c);
+}
+
+// Rotation matrix columns from a unit quaternion (helper_functions.py:100-117).
+struct FpvRot { float r00, r01, r02, r10, r11, r12, r20, r21, r22; };
+
+FPV_HD FpvRot fpv_rot(FpvQuat q)
+{
+    const float xx = q.x * q.x, yy = q.y * q.y, zz = q.z * q.z;
+    const float xy = q.x * q.y, xz = q.x * q.z, yz = q.y * q.z;
+    const float wx = q.w * q.x, wy = q.w * q.y, wz = q.w * q.z;
+    FpvRot R;
+    R.r00 = fmaf(-2.0f, yy + zz, 1.0f); R.r01 = 2.0f * (xy - wz);           R.r02 = 2.0f * (xz + wy);
+    R.r10 = 2.0f * (xy + wz);           R.r11 = fmaf(-2.0f, xx + zz, 1.0f); R.r12 = 2.0f * (yz - wx);
+    R.r20 = 2.0f * (xz - wy);           R.r21 = 2.0f * (yz + wx);           R.r22 = fmaf(-2.0f, xx + yy, 1.0f);
+    return R;
+}
+
+// q <- normalise(q + q (x) d) for a small-ish quaternion increment d = (dw, dx, dy, dz) (i.e. the
+// full factor is 1 + d).  First-order renormalisation: |q|^2 - 1 stays at rounding level because
+// it is corrected every step.
+FPV_HD FpvQuat fpv_quat_advance(FpvQuat q, float dw, float dx, float dy, float dz)
+{
+    FpvQuat n;
+    n.w = q.w + fmaf(q.w, dw, fmaf(-q.x, dx, fmaf(-q.y, dy, -q.z * dz)));
+    n.x = q.x + fmaf(q.w, dx, fmaf(q.x, dw, fmaf(q.y, dz, -q.z * dy)));
+    n.y = q.y + fmaf(q.w, dy, fmaf(-q.x, dz, fmaf(q.y, dw, q.z * dx)));
+    n.z = q.z + fmaf(q.w, dz, fmaf(q.x, dy, fmaf(-q.y, dx, q.z * dw)));
+    const float e = fmaf(n.w, n.w, fmaf(n.x, n.x, fmaf(n.y, n.y, fmaf(n.z, n.z, -1.0f))));
+    const float k = fmaf(0.375f * e, e, -0.5f * e);      // 1/sqrt(1+e) - 1
+    n.w = fmaf(k, n.w, n.w); n.x = fmaf(k, n.x, n.x); n.y = fmaf(k, n.y, n.y); n.z = fmaf(k, n.z, n.z);
+    return n;
+}
+
+struct FpvDroneState {
+    float px, py, pz, vx, vy, vz;
+    FpvQuat q;
+    float rx, ry, rz;   // prev_rates, deg/s
+    float thrust;       // prev_thrust, N
+};
+
+struct FpvStepOut {
+    float ax, ay, az;   // R_new @ acc
+    float reward;
+    bool done;          // ground flag (reference) OR ceiling (build), before any auto-reset
+};
+
+template <bool BIG>
+FPV_HD FpvStepOut fpv_drone_step_lane(const FpvK& K, FpvDroneState& s, float a0, float a1, float a2, float a3,
+                                      float wx, float wy, float wz)
+{
+    // (1)-(2) stick -> rate command (deg/s), clipped, low-passed          components.py:185-189
+    const float c0 = fminf(fmaxf(-a0 * K.max_rates, -K.max_rates), K.max_rates);
+    const float c1 = fminf(fmaxf(-a1 * K.max_rates, -K.max_rates), K.max_rates);
+    const float c2 = fminf(fmaxf(-a2 * K.max_rates, -K.max_rates), K.max_rates);
+    s.rx = fmaf(c0, K.kr, s.rx * K.omkr);
+    s.ry = fmaf(c1, K.kr, s.ry * K.omkr);
+    s.rz = fmaf(c2, K.kr, s.rz * K.omkr);
+    // (3) thrust cubic (Horner in the stick, no clamp), low-passed          components.py:136,:192-194
+    const float poly = fmaf(fmaf(fmaf(K.d3, a3, K.d2), a3, K.d1), a3, K.d0);
+    s.thrust = fmaf(poly, K.kt, s.thrust * K.omkt);
+
+    const FpvRot R = fpv_rot(s.q);                                         // PRE-update attitude
+
+    // (5) drag: F_b = -k (R^T v_s) |v_s|, back to world; wind is ADDED      kinematics.py:33-38
+    const float ux = s.vx + wx, uy = s.vy + wy, uz = s.vz + wz;
+    const float speed = sqrtf(fmaf(ux, ux, fmaf(uy, uy, uz * uz)));
+    const float bx = fmaf(R.r00, ux, fmaf(R.r10, uy, R.r20 * uz));
+    const float by = fmaf(R.r01, ux, fmaf(R.r11, uy, R.r21 * uz));
+    const float bz = fmaf(R.r02, ux, fmaf(R.r12, uy, R.r22 * uz));
+    const float fx = -K.kdrag_m[0] * bx * speed;
+    const float fy = -K.kdrag_m[1] * by * speed;
+    const float fz = -K.kdrag_m[2] * bz * speed;
+    // (4) thrust along body z (third column), gravity; everything already divided by m
+    const float tm = s.thrust * K.inv_mass;
+    const float accx = fmaf(R.r00, fx, fmaf(R.r01, fy, fmaf(R.r02, fz, tm * R.r02)));
+    const float accy = fmaf(R.r10, fx, fmaf(R.r11, fy, fmaf(R.r12, fz, tm * R.r12)));
+    const float accz = fmaf(R.r20, fx, fmaf(R.r21, fy, fmaf(R.r22, fz, fmaf(tm, R.r22, -K.g))));
+
+    // ground flag: any motor below z = 0 on the PRE-update pose             components.py:235-240
+    bool done = false;
+#pragma unroll
+    for (int m = 0; m < 4; ++m)
+        done = done || (s.pz + fmaf(K.motor_x[m], R.r20, K.motor_y[m] * R.r21) < 0.0f);
+
+    // (6) explicit Euler: p with the OLD v, then v                          kinematics.py:21-22
+    s.px = fmaf(s.vx, K.dt, s.px); s.py = fmaf(s.vy, K.dt, s.py); s.pz = fmaf(s.vz, K.dt, s.pz);
+    s.vx = fmaf(accx, K.dt, s.vx); s.vy = fmaf(accy, K.dt, s.vy); s.vz = fmaf(accz, K.dt, s.vz);
+
+    // attitude: q <- q (x) conj(q_E)^2, q_E = qz(psi) qy(theta) qx(phi)     kinematics.py:27-30 (x2)
+    float sr, cr, sp, cp, sy, cy;
+    fpv_sincos<BIG>(s.rx * K.half_k, &sr, &cr);
+    fpv_sincos<BIG>(s.ry * K.half_k, &sp, &cp);
+    fpv_sincos<BIG>(s.rz * K.half_k, &sy, &cy);
+    const float ew = fmaf(cy * cp, cr, sy * sp * sr);
+    const float ex = fmaf(cy * cp, sr, -(sy * sp * cr));
+    const float ey = fmaf(cy * sp, cr, sy * cp * sr);
+    const float ez = fmaf(sy * cp, cr, -(cy * sp * sr));
+    // conj(q_E)^2 - 1 = (-2|e_v|^2, -2 e_w e_v)
+    const float vv = fmaf(ex, ex, fmaf(ey, ey, ez * ez));
+    const float m2w = -2.0f * ew;
+    s.q = fpv_quat_advance(s.q, -2.0f * vv, m2w * ex, m2w * ey, m2w * ez);
+
+    FpvStepOut o;
+    const FpvRot Rn = fpv_rot(s.q);                                        // components.py:248
+    o.ax = fmaf(Rn.r00, accx, fmaf(Rn.r01, accy, Rn.r02 * accz));
+    o.ay = fmaf(Rn.r10, accx, fmaf(Rn.r11, accy, Rn.r12 * accz));
+    o.az = fmaf(Rn.r20, accx, fmaf(Rn.r21, accy, Rn.r22 * accz));
+    const float gx = s.px - K.goal[0], gy = s.py - K.goal[1], gz = s.pz - K.goal[2];
+    o.reward = -sqrtf(fmaf(gx, gx, fmaf(gy, gy, gz * gz)));
+    o.done = done || !(fabsf(s.pz) <= K.ceiling);
+    return o;
+}
+
+FPV_HD void fpv_drone_reset_lane(const FpvK& K, FpvDroneState& s)
+{
+    s.px = K.p0[0]; s.py = K.p0[1]; s.pz = K.p0[2];
+    s.vx = K.v0[0]; s.vy = K.v0[1]; s.vz = K.v0[2];
+    s.q.w = K.q0[0]; s.q.x = K.q0[1]; s.q.y = K.q0[2]; s.q.z = K.q0[3];
+    s.rx = s.ry = s.rz = 0.0f;
+    s.thrust = 0.0f;
+}
+
+// ------------------------------------------------------------------------------------------------
+// Racer: rate PID -> torque -> omega -> attitude; thrust along body z, damped velocity.
+//   PID.step   tests/racer_drone_test.py:22-32
+//   Racer.step tests/racer_drone_test.py:95-103
+// ------------------------------------------------------------------------------------------------
+struct FpvRacerState {
+    float px, py, pz, vx, vy, vz;
+    FpvQuat q;
+    float w[3], ierr[3], lerr[3];
+    float first;
+};
+
+FPV_HD float fpv_racer_step_lane(const FpvK& K, FpvRacerState& s, float a0, float a1, float a2, float a3)
+{
+    const float act[3] = {a0, a1, a2};
+#pragma unroll
+    for (int i = 0; i < 3; ++i) {
+        const float err = act[i] - s.w[i];                                  // :23
+        s.ierr[i] = fmaf(err, K.r_dt, s.ierr[i]);                           // :25
+        const float derr = (s.first != 0.0f) ? 0.0f : (err - s.lerr[i]) * K.r_inv_dt;   // :26-29
+        s.lerr[i] = err;                                                    // :31
+        const float tq = fmaf(K.r_pid[i][0], err, fmaf(K.r_pid[i][1], s.ierr[i], K.r_pid[i][2] * derr));
+        s.w[i] = fmaf(tq, K.r_dt_over_I[i], s.w[i]);                        // :98
+    }
+    s.first = 0.0f;
+    // :99  q <- q (x) qx(a) (x) qy(b) (x) qz(c)   (intrinsic "XYZ"), angle = omega * r_ang_k
+    float sa, ca, sb, cb, sc, cc;
+    fpv_sincos_full(0.5f * s.w[0] * K.r_ang_k, &sa, &ca);
+    fpv_sincos_full(0.5f * s.w[1] * K.r_ang_k, &sb, &cb);
+    fpv_sincos_full(0.5f * s.w[2] * K.r_ang_k, &sc, &cc);
+    // qx*qy = (ca cb, sa cb, ca sb, sa sb); then * qz
+    const float w1 = ca * cb, x1 = sa * cb, y1 = ca * sb, z1 = sa * sb;
+    const float dw = fmaf(w1, cc, -z1 * sc), dx = fmaf(x1, cc, y1 * sc);
+    const float dy = fmaf(y1, cc, -x1 * sc), dz = fmaf(z1, cc, w1 * sc);
+    FpvQuat n;
+    n.w = fmaf(s.q.w, dw, fmaf(-s.q.x, dx, fmaf(-s.q.y, dy, -s.q.z * dz)));
+    n.x = fmaf(s.q.w, dx, fmaf(s.q.x, dw, fmaf(s.q.y, dz, -s.q.z * dy)));
+    n.y = fmaf(s.q.w, dy, fmaf(-s.q.x, dz, fmaf(s.q.y, dw, s.q.z * dx)));
+    n.z = fmaf(s.q.w, dz, fmaf(s.q.x, dy, fmaf(-s.q.y, dx, s.q.z * dw)));
+    const float inv = 1.0f / sqrtf(fmaf(n.w, n.w, fmaf(n.x, n.x, fmaf(n.y, n.y, n.z * n.z))));
+    s.q.w = n.w * inv; s.q.x = n.x * inv; s.q.y = n.y * inv; s.q.z = n.z * inv;
+    // :100-103 force along the NEW body z, damped velocity, v-then-p
+    const FpvRot R = fpv_rot(s.q);
+    const float f = a3 * K.r_inv_mass * K.r_dt;
+    s.vx = fmaf(K.r_damp, s.vx, f * R.r02);
+    s.vy = fmaf(K.r_damp, s.vy, f * R.r12);
+    s.vz = fmaf(K.r_damp, s.vz, f * R.r22);
+    s.px = fmaf(s.vx, K.r_dt, s.px); s.py = fmaf(s.vy, K.r_dt, s.py); s.pz = fmaf(s.vz, K.r_dt, s.pz);
+    const float gx = s.px - K.goal[0], gy = s.py - K.goal[1], gz = s.pz - K.goal[2];
+    return -sqrtf(fmaf(gx, gx, fmaf(gy, gy, gz * gz)));
+}
+
+FPV_HD void fpv_racer_reset_lane(FpvRacerState& s)
+{
+    s.px = s.py = s.pz = s.vx = s.vy = s.vz = 0.0f;
+    s.q.w = 1.0f; s.q.x = s.q.y = s.q.z = 0.0f;
+#pragma unroll
+    for (int i = 0; i < 3; ++i) { s.w[i] = 0.0f; s.ierr[i] = 0.0f; s.lerr[i] = 0.0f; }
+    s.first = 1.0f;
+}

@@ -1,0 +1,333 @@
+"""Batched host API over the HIP stepper.
+
+`DroneBatch` mirrors the reference's `Drone` (/root/reference/src/utils/components.py:72-248) for N
+drones at once - same method names, argument meaning and return triple:
+
+    Drone.reset(position, velocity, ypr)                       components.py:150-169
+    Drone.step(action, wind_velocity_vector, object_list)      components.py:220-248
+        -> (rotation_matrix.T, angular_velocity_matrix, rotation_matrix @ acceleration)
+    Drone.position / .velocity / .done                         components.py:171-177, :104
+
+`RacerBatch` does the same for `Racer` (/root/reference/tests/racer_drone_test.py:68-103), and
+`FpvVecEnv` is the gym-style `reset() -> obs`, `step(a) -> (obs, reward, done, info)` surface the
+reference's env scripts use (tests/rotation_pid.py:57-78).
+
+All state lives in torch tensors on the GPU; a step is one ctypes call that enqueues one kernel on
+torch's current stream.  Nothing here computes physics on the host.
+"""
+from __future__ import annotations
+
+import ctypes as C
+from typing import Any, Dict, Optional, Sequence, Tuple
+
+import numpy as np
+import torch
+
+from . import _lib
+from .params import DroneParams, MODE_DRONE, MODE_RACER, load_params
+
+
+def _round_up(x: int, m: int) -> int:
+    return (x + m - 1) // m * m
+
+
+class _Batch:
+    """Owns the SoA state tensor and the C handle of one shard of drones on one GPU."""
+
+    def __init__(self, params: DroneParams, num_envs: int, device: Any = "cuda:0", auto_reset: bool = False,
+                 track_episodes: bool = False, with_accel: bool = False, with_done_bits: bool = False):
+        if num_envs <= 0:
+            raise ValueError("num_envs must be positive")
+        self.params = params
+        self.n = int(num_envs)
+        self.device = torch.device(device)
+        if self.device.type != "cuda":
+            raise ValueError("fpyv_amd runs on the GPU only (device must be cuda:N); there is no CPU path")
+        self._L = _lib.lib()
+        self.mode = int(params.mode)
+        self.rows = _lib.state_rows(self.mode)
+        self.ld = _round_up(self.n, 64)
+        dev_index = self.device.index if self.device.index is not None else torch.cuda.current_device()
+        self._handle = C.c_void_p()
+        self._cparams = _lib.pack_params(params, auto_reset=auto_reset)
+        _lib.check(self._L.fpv_create(C.byref(self._cparams), self.n, dev_index, C.byref(self._handle)))
+        f32 = dict(dtype=torch.float32, device=self.device)
+        self.state = torch.zeros((self.rows, self.ld), **f32)
+        self.reward = torch.zeros(self.n, **f32)
+        self.done_u8 = torch.zeros(self.n, dtype=torch.uint8, device=self.device)
+        self.accel = torch.zeros((3, self.ld), **f32) if with_accel else None
+        self.done_bits = (torch.zeros(_round_up(self.n, 64) // 64, dtype=torch.int64, device=self.device)
+                          if with_done_bits else None)
+        if track_episodes:
+            self.ep_return = torch.zeros(self.n, **f32)
+            self.ep_length = torch.zeros(self.n, dtype=torch.int32, device=self.device)
+            self.last_return = torch.zeros(self.n, **f32)
+            self.last_length = torch.zeros(self.n, dtype=torch.int32, device=self.device)
+        else:
+            self.ep_return = self.ep_length = self.last_return = self.last_length = None
+        self._bcast_action = None
+        self._buf = _lib.FpvBuffers()
+        self._fill_buffers()
+
+    # -- plumbing ---------------------------------------------------------------------------------
+    def _fill_buffers(self) -> None:
+        b = self._buf
+        ptr = lambda t: t.data_ptr() if t is not None else None  # noqa: E731
+        b.state, b.ld = self.state.data_ptr(), self.ld
+        b.reward, b.done = self.reward.data_ptr(), self.done_u8.data_ptr()
+        b.done_bits, b.accel = ptr(self.done_bits), ptr(self.accel)
+        b.ep_return, b.ep_length = ptr(self.ep_return), ptr(self.ep_length)
+        b.last_return, b.last_length = ptr(self.last_return), ptr(self.last_length)
+        b.wind[0] = b.wind[1] = b.wind[2] = 0.0
+
+    def _stream(self) -> int:
+        return torch.cuda.current_stream(self.device).cuda_stream
+
+    def _action_ptr(self, action: Any) -> int:
+        if not torch.is_tensor(action):
+            action = torch.as_tensor(np.asarray(action, dtype=np.float32), device=self.device)
+        if action.dim() == 1:
+            if action.numel() != 4:
+                raise ValueError("action must be [4] or [num_envs, 4]")
+            if self._bcast_action is None:
+                self._bcast_action = torch.empty((self.n, 4), dtype=torch.float32, device=self.device)
+            self._bcast_action.copy_(action.to(device=self.device, dtype=torch.float32).expand(self.n, 4))
+            action = self._bcast_action
+        if action.shape != (self.n, 4):
+            raise ValueError(f"action must have shape ({self.n}, 4), got {tuple(action.shape)}")
+        if action.dtype != torch.float32 or action.device != self.state.device or not action.is_contiguous():
+            action = action.to(device=self.device, dtype=torch.float32).contiguous()
+        self._keepalive = action
+        return action.data_ptr()
+
+    def set_tuning(self, drones_per_lane: int) -> None:
+        _lib.check(self._L.fpv_set_tuning(self._handle, int(drones_per_lane)))
+
+    def set_params(self, params: DroneParams, auto_reset: Optional[bool] = None) -> None:
+        flags_auto = bool(self._cparams.flags & _lib.FPV_FLAG_AUTO_RESET) if auto_reset is None else auto_reset
+        cp = _lib.pack_params(params, auto_reset=flags_auto)
+        _lib.check(self._L.fpv_set_params(self._handle, C.byref(cp)))
+        self.params, self._cparams = params, cp
+
+    def close(self) -> None:
+        if getattr(self, "_handle", None) is not None and self._handle.value:
+            self._L.fpv_destroy(self._handle)
+            self._handle = C.c_void_p()
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    # -- raw stepping -----------------------------------------------------------------------------
+    def _reset_raw(self, mask=None, position=None, velocity=None, ypr=None) -> None:
+        def dev3(x):
+            if x is None:
+                return None
+            t = torch.as_tensor(np.asarray(x, dtype=np.float32) if not torch.is_tensor(x) else x,
+                                dtype=torch.float32, device=self.device)
+            return t.expand(self.n, 3).contiguous()
+        pos, vel, ang = dev3(position), dev3(velocity), dev3(ypr)
+        m = None
+        if mask is not None:
+            m = torch.as_tensor(mask, device=self.device).to(torch.uint8).contiguous()
+            if m.shape != (self.n,):
+                raise ValueError("mask must have shape (num_envs,)")
+        ptr = lambda t: t.data_ptr() if t is not None else None  # noqa: E731
+        _lib.check(self._L.fpv_reset(self._handle, C.byref(self._buf), ptr(m), ptr(pos), ptr(vel), ptr(ang),
+                                     self._stream()))
+        self._keepalive_reset = (pos, vel, ang, m)
+
+    def _step_raw(self, action: Any, wind: Optional[Sequence[float]] = None) -> None:
+        b = self._buf
+        b.action = self._action_ptr(action)
+        if wind is not None:
+            b.wind[0], b.wind[1], b.wind[2] = float(wind[0]), float(wind[1]), float(wind[2])
+        _lib.check(self._L.fpv_step(self._handle, C.byref(b), self._stream()))
+
+    def rollout(self, actions: torch.Tensor, wind: Optional[Sequence[float]] = None,
+                rewards: Optional[torch.Tensor] = None, dones: Optional[torch.Tensor] = None) -> None:
+        """k steps back to back without returning to Python: actions [k, num_envs, 4] (one batch
+        per step) or [num_envs, 4] with `rewards`/`dones` of shape [k, num_envs] giving k."""
+        b = self._buf
+        if actions.dim() == 3:
+            k, stride = actions.shape[0], self.n * 4
+            if actions.shape[1:] != (self.n, 4):
+                raise ValueError(f"actions must be [k, {self.n}, 4]")
+        else:
+            if rewards is None and dones is None:
+                raise ValueError("held-action rollouts need rewards/dones [k, num_envs] to define k")
+            k, stride = (rewards if rewards is not None else dones).shape[0], 0
+        if actions.dtype != torch.float32 or not actions.is_contiguous() or actions.device != self.state.device:
+            raise ValueError("actions must be a contiguous float32 tensor on the env's device")
+        b.action = actions.data_ptr()
+        if wind is not None:
+            b.wind[0], b.wind[1], b.wind[2] = float(wind[0]), float(wind[1]), float(wind[2])
+        out_stride = 0
+        saved = (b.reward, b.done)
+        if rewards is not None or dones is not None:
+            out_stride = self.n
+            for t, dt_ in ((rewards, torch.float32), (dones, torch.uint8)):
+                if t is not None and (t.shape != (k, self.n) or t.dtype != dt_ or not t.is_contiguous()):
+                    raise ValueError("rewards must be float32 [k, n], dones uint8 [k, n], contiguous")
+            b.reward = rewards.data_ptr() if rewards is not None else None
+            b.done = dones.data_ptr() if dones is not None else None
+        try:
+            _lib.check(self._L.fpv_rollout(self._handle, C.byref(b), int(k), stride, out_stride, self._stream()))
+        finally:
+            b.reward, b.done = saved
+
+    # -- views ------------------------------------------------------------------------------------
+    @property
+    def position(self) -> torch.Tensor:
+        """[num_envs, 3] view of the state (Drone.position, components.py:171-173)."""
+        return self.state[_lib.PX:_lib.PZ + 1, :self.n].t()
+
+    @property
+    def velocity(self) -> torch.Tensor:
+        return self.state[_lib.VX:_lib.VZ + 1, :self.n].t()
+
+    @property
+    def quaternion(self) -> torch.Tensor:
+        """[num_envs, 4] (w, x, y, z), body -> world."""
+        return self.state[_lib.QW:_lib.QZ + 1, :self.n].t()
+
+    @property
+    def rotation_matrix(self) -> torch.Tensor:
+        """[num_envs, 3, 3], computed from the quaternion (helper_functions.py:100-117)."""
+        return quat_to_matrix(self.quaternion)
+
+    @property
+    def done(self) -> torch.Tensor:
+        return self.done_u8.bool()
+
+
+def quat_to_matrix(q: torch.Tensor) -> torch.Tensor:
+    """(w,x,y,z) [...,4] -> rotation matrices [...,3,3]; a view helper for API parity, not on the
+    step path (/root/reference/src/utils/helper_functions.py:100-117)."""
+    w, x, y, z = q.unbind(-1)
+    return torch.stack([
+        1 - 2 * y * y - 2 * z * z, 2 * x * y - 2 * z * w, 2 * x * z + 2 * y * w,
+        2 * x * y + 2 * z * w, 1 - 2 * x * x - 2 * z * z, 2 * y * z - 2 * x * w,
+        2 * x * z - 2 * y * w, 2 * y * z + 2 * x * w, 1 - 2 * x * x - 2 * y * y], dim=-1).reshape(q.shape[:-1] + (3, 3))
+
+
+def euler_zyx_matrix(angles: torch.Tensor) -> torch.Tensor:
+    """Rz(yaw) Ry(pitch) Rx(roll) for angles [...,3] = (roll, pitch, yaw) in radians
+    (/root/reference/src/utils/helper_functions.py:39-44)."""
+    r, p, y = angles.unbind(-1)
+    cr, sr, cp, sp, cy, sy = r.cos(), r.sin(), p.cos(), p.sin(), y.cos(), y.sin()
+    return torch.stack([cy * cp, cy * sp * sr - sy * cr, cy * sp * cr + sy * sr,
+                        sy * cp, sy * sp * sr + cy * cr, sy * sp * cr - cy * sr,
+                        -sp, cp * sr, cp * cr], dim=-1).reshape(angles.shape[:-1] + (3, 3))
+
+
+class DroneBatch(_Batch):
+    """N reference `Drone`s stepped by one HIP kernel (mode "drone")."""
+
+    def __init__(self, params: Optional[DroneParams] = None, num_envs: int = 1, device: Any = "cuda:0", **kw):
+        params = params if params is not None else load_params()
+        if params.mode != MODE_DRONE:
+            params = params.replace(mode=MODE_DRONE)
+        kw.setdefault("with_accel", True)
+        super().__init__(params, num_envs, device, **kw)
+        self.dt = params.dt
+
+    def reset(self, position=None, velocity=None, ypr=None, mask=None) -> None:
+        """Drone.reset: `ypr` is consumed as (roll, pitch, yaw) in degrees, like the reference
+        (components.py:150-154).  Arguments broadcast from [3] or are per drone [num_envs, 3];
+        None uses params.init_*."""
+        self._reset_raw(mask=mask, position=position, velocity=velocity, ypr=ypr)
+
+    def step(self, action, wind_velocity_vector=None, object_list=(), rotation_matrix=None, thrust_force=None,
+             return_imu: bool = True):
+        """Drone.step for every drone.  `object_list` must be empty (collision objects are outside
+        the batched step) and the guidance overrides `rotation_matrix` / `thrust_force`
+        (components.py:230-232) are not supported."""
+        if action is None:
+            raise ValueError("action=None reads a physical joystick in the reference; pass stick values")
+        if len(object_list):
+            raise NotImplementedError("collision objects are not part of the batched step (object_list must be empty)")
+        if rotation_matrix is not None or thrust_force is not None:
+            raise NotImplementedError("guidance overrides (rotation_matrix=, thrust_force=) are not supported")
+        self._step_raw(action, wind_velocity_vector)
+        if not return_imu:
+            return None
+        R = self.rotation_matrix
+        rates = self.state[_lib.RX:_lib.RZ + 1, :self.n].t()
+        gyro = euler_zyx_matrix(rates)            # deg/s values used as radians, as the reference does (:247)
+        acc = self.accel[:, :self.n].t() if self.accel is not None else None
+        return R.transpose(-1, -2), gyro, acc
+
+    @property
+    def prev_rates(self) -> torch.Tensor:
+        return self.state[_lib.RX:_lib.RZ + 1, :self.n].t()
+
+    @property
+    def prev_thrust(self) -> torch.Tensor:
+        return self.state[_lib.THRUST, :self.n]
+
+
+class RacerBatch(_Batch):
+    """N reference `Racer`s (rate PID -> torque -> omega -> attitude), mode "racer"."""
+
+    def __init__(self, params: Optional[DroneParams] = None, num_envs: int = 1, device: Any = "cuda:0", **kw):
+        params = params if params is not None else load_params(fps=1000)
+        if params.mode != MODE_RACER:
+            params = params.replace(mode=MODE_RACER)
+        super().__init__(params, num_envs, device, **kw)
+
+    def reset(self, mask=None) -> None:
+        self._reset_raw(mask=mask)
+
+    def step(self, action) -> None:
+        """action [num_envs, 4] = desired body rates (3) + thrust force (racer_drone_test.py:95-100)."""
+        self._step_raw(action)
+
+    @property
+    def angular_velocity(self) -> torch.Tensor:
+        return self.state[_lib.R_OMEGA:_lib.R_OMEGA + 3, :self.n].t()
+
+
+class FpvVecEnv:
+    """Gym-style vector env: reset() -> obs, step(action) -> (obs, reward, done, info).
+
+    obs is a zero-copy [num_envs, 13] view of the SoA state (p3, v3, q4 wxyz, rates3): the kernel's
+    state store IS the observation write.  reward = -|p - goal| (the reference defines none for
+    `Drone`); done = ground contact (reference) or |z| > ceiling (build); with auto_reset the lane is
+    re-initialised in the same kernel and obs already shows the fresh episode.
+    """
+
+    def __init__(self, params: Optional[DroneParams] = None, num_envs: int = 1, device: Any = "cuda:0",
+                 mode: str = "drone", auto_reset: bool = True, track_episodes: bool = True,
+                 wind: Sequence[float] = (0.0, 0.0, 0.0)):
+        params = params if params is not None else load_params(fps=1000)
+        cls = DroneBatch if mode == "drone" else RacerBatch
+        kw: Dict[str, Any] = dict(auto_reset=auto_reset, track_episodes=track_episodes)
+        if mode == "drone":
+            kw["with_accel"] = False
+        self.batch = cls(params, num_envs, device, **kw)
+        self.num_envs = self.batch.n
+        self.wind = tuple(float(w) for w in wind)
+        self.obs_dim = 13
+        self.action_dim = 4
+
+    @property
+    def obs(self) -> torch.Tensor:
+        return self.batch.state[:13, :self.num_envs].t()
+
+    def reset(self, mask=None) -> torch.Tensor:
+        self.batch._reset_raw(mask=mask)
+        return self.obs
+
+    def step(self, action) -> Tuple[torch.Tensor, torch.Tensor, torch.Tensor, Dict[str, Any]]:
+        self.batch._step_raw(action, self.wind)
+        info: Dict[str, Any] = {}
+        if self.batch.last_return is not None:
+            info["episode_return"] = self.batch.last_return
+            info["episode_length"] = self.batch.last_length
+        return self.obs, self.batch.reward, self.batch.done_u8, info
+
+    def close(self) -> None:
+        self.batch.close()

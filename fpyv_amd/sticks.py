@@ -48,13 +48,15 @@ def ema_noise(steps: int, drone_ids: Sequence[int], seed: int = 0, transition: f
               clip: Optional[float] = None) -> np.ndarray:
     """EMA-smoothed Gaussian sticks.  Drone `i` draws from default_rng(seed + i), so its stick
     history does not depend on how many other drones exist or which rank owns it."""
-    out = np.empty((steps, len(drone_ids), 4))
-    for k, i in enumerate(drone_ids):
-        x = np.random.default_rng(seed + int(i)).standard_normal((steps, 4))
-        s = np.zeros(4)
-        for t in range(steps):
-            s = s * (1 - transition) + x[t] * transition
-            out[t, k] = s
+    ids = list(drone_ids)
+    x = np.empty((steps, len(ids), 4))
+    for k, i in enumerate(ids):
+        x[:, k] = np.random.default_rng(seed + int(i)).standard_normal((steps, 4))
+    out = np.empty_like(x)
+    s = np.zeros((len(ids), 4))
+    for t in range(steps):
+        s = s * (1 - transition) + x[t] * transition
+        out[t] = s
     if clip is not None:
         out = np.clip(out, -clip, clip)
     return _f32(out)

@@ -1,0 +1,154 @@
+/*
+ * fpv_abi.h - C ABI of the MI355X batched FPV drone stepper (libfpv_hip.so).
+ *
+ * The reference has no FFI for this path: its boundary is the Python method pair
+ *   Drone.reset(position, velocity, ypr)                 /root/reference/src/utils/components.py:150-169
+ *   Drone.step(action, wind_velocity_vector, object_list) /root/reference/src/utils/components.py:220-248
+ * (plus Racer.reset/step, /root/reference/tests/racer_drone_test.py:85-103).  The entry points
+ * below are what a ctypes binding of that pair calls for N drones at once; each one names the
+ * reference lines it replaces.  Plain pointers and sizes only - no torch, no C++ types.
+ *
+ * Conventions
+ *   - every function returns FPV_OK (0) or a negative FPV_E* code; fpv_last_error() gives the
+ *     message of the calling thread's last failure.  Nothing throws across the boundary.
+ *   - device buffers are owned by the caller (the Python host allocates them as torch tensors);
+ *     the library never allocates, frees or copies device state.
+ *   - `stream` is a hipStream_t (NULL = default stream).  Calls only enqueue work; asynchronous
+ *     kernel faults surface at the caller's next synchronisation.
+ *   - a handle is bound to one device and is not thread-safe; use one per GPU / host thread.
+ */
+#ifndef FPV_ABI_H
+#define FPV_ABI_H
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define FPV_ABI_VERSION 1
+
+enum {
+    FPV_OK = 0,
+    FPV_EINVAL = -1,  /* bad argument (null pointer, n <= 0, bad mode, struct_size mismatch) */
+    FPV_EHIP = -2,    /* a HIP runtime call failed; message carries hipGetErrorString */
+    FPV_ENODEV = -3,  /* no usable GPU / device index out of range */
+    FPV_EALIGN = -4,  /* buffer alignment or leading dimension violates the layout rules */
+    FPV_EPARAM = -5   /* physically meaningless parameter (dt <= 0, mass <= 0, ...) */
+};
+
+enum { FPV_MODE_DRONE = 0, FPV_MODE_RACER = 1 };
+
+/* Rows of the SoA state matrix state[rows][ld] (fp32).  Row r of drone i is state[r*ld + i].
+ * FPV_MODE_DRONE: the mutable state of Drone (components.py:151-169) with the attitude held as a
+ * unit quaternion (w,x,y,z), body->world, instead of the 3x3 matrix. */
+enum {
+    FPV_PX = 0, FPV_PY, FPV_PZ,          /* state[0:3]   position, m                     */
+    FPV_VX, FPV_VY, FPV_VZ,              /* state[3:6]   velocity, m/s                   */
+    FPV_QW, FPV_QX, FPV_QY, FPV_QZ,      /* rotation_matrix as quaternion                */
+    FPV_RX, FPV_RY, FPV_RZ,              /* prev_rates, deg/s (components.py:189)        */
+    FPV_THRUST,                          /* prev_thrust, N    (components.py:194)        */
+    FPV_DRONE_ROWS                       /* = 14 */
+};
+/* FPV_MODE_RACER: Racer state (racer_drone_test.py:70-83) + its three PID integrators (:13-20). */
+enum {
+    FPV_R_OMEGA = 10,                    /* rows 10..12 angular_velocity                 */
+    FPV_R_IERR = 13,                     /* rows 13..15 PID i_error                      */
+    FPV_R_LERR = 16,                     /* rows 16..18 PID last_error                   */
+    FPV_R_FIRST = 19,                    /* 1.0 until the first PID step                 */
+    FPV_RACER_ROWS = 20
+};
+
+enum { FPV_FLAG_AUTO_RESET = 1u };       /* re-initialise a lane in-kernel when it reports done */
+
+/* Host-side description of one drone type; doubles, narrowed to fp32 by fpv_create.
+ * Field sources: components.py:92-100 (dt, gravity, mass, drag, areas), :120-125 (motor_xy),
+ * :134-136 (thrust_poly), :185-194 (max_rates, transition rates), kinematics.py:33 (air_density),
+ * racer_drone_test.py:8,:70-83,:102 (racer_*). */
+typedef struct fpv_params {
+    uint32_t struct_size;             /* = sizeof(fpv_params_t) */
+    uint32_t mode;                    /* FPV_MODE_* */
+    uint32_t flags;                   /* FPV_FLAG_* */
+    uint32_t racer_omega_dt;          /* 0: rotate by omega per step as the reference writes it; 1: omega*dt */
+    double dt;
+    double gravity;
+    double mass;                      /* kg */
+    double max_rates;                 /* deg/s */
+    double rates_transition_rate;
+    double thrust_transition_rate;
+    double thrust_poly[4];            /* c3,c2,c1,c0 of thrust[N] over throttle percent */
+    double drag_coefficients[3];
+    double cross_section_areas[3];    /* m^2 */
+    double air_density;
+    double motor_xy[4][2];            /* body-frame motor positions (z = 0), m */
+    double init_position[3];          /* used by fpv_reset defaults and FPV_FLAG_AUTO_RESET */
+    double init_velocity[3];
+    double init_quat[4];              /* w,x,y,z */
+    double ceiling;                   /* auto-reset when |z| > ceiling; +inf disables */
+    double goal[3];                   /* reward = -|p - goal| (build-defined; the reference has none) */
+    double racer_mass;
+    double racer_inertia[3];
+    double racer_pid[3][3];           /* [axis][kP,kI,kD] */
+    double racer_velocity_damping;
+} fpv_params_t;
+
+/* Device buffers of one batch.  Only `state` is mandatory for fpv_reset; `state` and `action`
+ * for fpv_step.  NULL optional pointers skip that output. */
+typedef struct fpv_buffers {
+    float* state;            /* [rows][ld] SoA, 16-byte aligned */
+    int64_t ld;              /* row stride in floats, >= n, multiple of 4 */
+    const float* action;     /* [n][4] = roll, pitch, yaw, throttle per drone (components.py:181-186), 16-byte aligned */
+    float* reward;           /* [n] */
+    uint8_t* done;           /* [n] 0/1  (Drone.done, components.py:236-240) */
+    uint64_t* done_bits;     /* [ceil(n/64)] bit i%64 of word i/64 = done[i]; 8-byte aligned */
+    float* accel;            /* [3][ld] R_new @ acc, the third value Drone.step returns (components.py:248) */
+    float* ep_return;        /* [n] running episode return (read-modify-write) */
+    int32_t* ep_length;      /* [n] running episode length */
+    float* last_return;      /* [n] written when a lane reports done */
+    int32_t* last_length;    /* [n] */
+    float wind[3];           /* wind_velocity_vector of this step (kinematics.py:35: ADDED to v) */
+    uint32_t _pad;
+} fpv_buffers_t;
+
+typedef struct fpv_env* fpv_handle_t;
+
+int fpv_abi_version(void);
+/* rows of the state matrix for a mode (FPV_DRONE_ROWS / FPV_RACER_ROWS), or FPV_EINVAL */
+int fpv_state_rows(int mode);
+/* bytes each env-step must move at minimum (state R+W, action R, reward+done W) - roofline bookkeeping */
+int fpv_algorithmic_bytes(int mode);
+
+/* Replaces Drone.__init__'s physics set-up (components.py:86-142) / Racer.__init__ (:68-83).
+ * Validates and narrows the parameters; binds to `device`.  No device allocation. */
+int fpv_create(const fpv_params_t* params, int64_t n, int device, fpv_handle_t* out);
+void fpv_destroy(fpv_handle_t h);
+
+/* Replaces Drone.reset (components.py:150-169) / Racer.reset (:85-93) for the lanes whose mask
+ * byte is non-zero (mask NULL = all).  position/velocity/ypr_deg are [n][3] device arrays or NULL
+ * (= the defaults in fpv_params_t); ypr is consumed as (roll,pitch,yaw) degrees like the reference.
+ * Zeroes prev_rates, prev_thrust, PID state and episode counters of the reset lanes. */
+int fpv_reset(fpv_handle_t h, const fpv_buffers_t* b, const uint8_t* mask, const float* position,
+              const float* velocity, const float* ypr_deg, void* stream);
+
+/* Replaces one Drone.step (components.py:220-248, object_list == []) / Racer.step (:95-103) per drone. */
+int fpv_step(fpv_handle_t h, const fpv_buffers_t* b, void* stream);
+
+/* k consecutive steps, one launch each, with no host work in between: step t reads
+ * actions + t*action_stride floats (action_stride = 0 holds b->action) and, when the strides are
+ * non-zero, writes reward/done at + t*out_stride elements. */
+int fpv_rollout(fpv_handle_t h, const fpv_buffers_t* b, int k, int64_t action_stride,
+                int64_t out_stride, void* stream);
+
+/* Replace the drone type of a live handle (e.g. domain randomisation between episodes). */
+int fpv_set_params(fpv_handle_t h, const fpv_params_t* params);
+
+/* Launch geometry: drones per lane in {1,2,4}; 0 restores the built-in choice. */
+int fpv_set_tuning(fpv_handle_t h, int drones_per_lane);
+
+const char* fpv_last_error(void);
+const char* fpv_error_name(int code);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* FPV_ABI_H */

@@ -1,0 +1,82 @@
+// lane_model.cpp - the HIP kernel's per-lane fp32 arithmetic (fpyv_amd/csrc/fpv_math.h) compiled
+// for the host.
+//
+// TEST INFRASTRUCTURE ONLY.  It lets the CPU test-suite (a) bound the fp32-vs-float64 error of the
+// kernel's formulation against the oracle before any GPU time is spent and (b) assert on the GPU
+// box that the gfx950 kernel reproduces this arithmetic bit for bit (both sides are built with
+// -ffp-contract=off and use explicit fmaf).  It is NOT a CPU fallback: nothing under fpyv_amd/
+// loads this library, and the product fails with FPV_ENODEV when no GPU is present.
+#include <stdint.h>
+#include <string.h>
+
+#include "../fpyv_amd/csrc/fpv_derive.h"
+#include "../fpyv_amd/csrc/fpv_math.h"
+
+extern "C" {
+
+// state: [rows][ld] SoA like the product.  actions: [steps][n][4] (per_step) or [n][4] held.
+// accel: [3][ld] or NULL; done/reward: [n] or NULL (last step's values).  Returns 0 or FPV_E*.
+int fpvl_run(const fpv_params_t* P, int64_t n, int steps, float* st, int64_t ld, const float* actions,
+             int per_step, const float wind[3], float* accel, uint8_t* done, float* reward)
+{
+    FpvK K;
+    bool big = false;
+    const char* why = "";
+    const int rc = fpv_derive_constants(P, &K, &big, &why);
+    if (rc != FPV_OK) return rc;
+    for (int64_t i = 0; i < n; ++i) {
+        if (P->mode == FPV_MODE_DRONE) {
+            FpvDroneState s;
+            s.px = st[FPV_PX * ld + i]; s.py = st[FPV_PY * ld + i]; s.pz = st[FPV_PZ * ld + i];
+            s.vx = st[FPV_VX * ld + i]; s.vy = st[FPV_VY * ld + i]; s.vz = st[FPV_VZ * ld + i];
+            s.q.w = st[FPV_QW * ld + i]; s.q.x = st[FPV_QX * ld + i]; s.q.y = st[FPV_QY * ld + i]; s.q.z = st[FPV_QZ * ld + i];
+            s.rx = st[FPV_RX * ld + i]; s.ry = st[FPV_RY * ld + i]; s.rz = st[FPV_RZ * ld + i];
+            s.thrust = st[FPV_THRUST * ld + i];
+            FpvStepOut o = {0, 0, 0, 0, false};
+            for (int t = 0; t < steps; ++t) {
+                const float* a = actions + ((per_step ? (int64_t)t * n : 0) + i) * 4;
+                o = big ? fpv_drone_step_lane<true>(K, s, a[0], a[1], a[2], a[3], wind[0], wind[1], wind[2])
+                        : fpv_drone_step_lane<false>(K, s, a[0], a[1], a[2], a[3], wind[0], wind[1], wind[2]);
+                if ((K.flags & FPV_FLAG_AUTO_RESET) && o.done) fpv_drone_reset_lane(K, s);
+            }
+            st[FPV_PX * ld + i] = s.px; st[FPV_PY * ld + i] = s.py; st[FPV_PZ * ld + i] = s.pz;
+            st[FPV_VX * ld + i] = s.vx; st[FPV_VY * ld + i] = s.vy; st[FPV_VZ * ld + i] = s.vz;
+            st[FPV_QW * ld + i] = s.q.w; st[FPV_QX * ld + i] = s.q.x; st[FPV_QY * ld + i] = s.q.y; st[FPV_QZ * ld + i] = s.q.z;
+            st[FPV_RX * ld + i] = s.rx; st[FPV_RY * ld + i] = s.ry; st[FPV_RZ * ld + i] = s.rz;
+            st[FPV_THRUST * ld + i] = s.thrust;
+            if (accel) { accel[i] = o.ax; accel[ld + i] = o.ay; accel[2 * ld + i] = o.az; }
+            if (done) done[i] = o.done ? 1 : 0;
+            if (reward) reward[i] = o.reward;
+        } else {
+            FpvRacerState s;
+            s.px = st[FPV_PX * ld + i]; s.py = st[FPV_PY * ld + i]; s.pz = st[FPV_PZ * ld + i];
+            s.vx = st[FPV_VX * ld + i]; s.vy = st[FPV_VY * ld + i]; s.vz = st[FPV_VZ * ld + i];
+            s.q.w = st[FPV_QW * ld + i]; s.q.x = st[FPV_QX * ld + i]; s.q.y = st[FPV_QY * ld + i]; s.q.z = st[FPV_QZ * ld + i];
+            for (int k = 0; k < 3; ++k) {
+                s.w[k] = st[(FPV_R_OMEGA + k) * ld + i];
+                s.ierr[k] = st[(FPV_R_IERR + k) * ld + i];
+                s.lerr[k] = st[(FPV_R_LERR + k) * ld + i];
+            }
+            s.first = st[FPV_R_FIRST * ld + i];
+            float r = 0;
+            for (int t = 0; t < steps; ++t) {
+                const float* a = actions + ((per_step ? (int64_t)t * n : 0) + i) * 4;
+                r = fpv_racer_step_lane(K, s, a[0], a[1], a[2], a[3]);
+            }
+            st[FPV_PX * ld + i] = s.px; st[FPV_PY * ld + i] = s.py; st[FPV_PZ * ld + i] = s.pz;
+            st[FPV_VX * ld + i] = s.vx; st[FPV_VY * ld + i] = s.vy; st[FPV_VZ * ld + i] = s.vz;
+            st[FPV_QW * ld + i] = s.q.w; st[FPV_QX * ld + i] = s.q.x; st[FPV_QY * ld + i] = s.q.y; st[FPV_QZ * ld + i] = s.q.z;
+            for (int k = 0; k < 3; ++k) {
+                st[(FPV_R_OMEGA + k) * ld + i] = s.w[k];
+                st[(FPV_R_IERR + k) * ld + i] = s.ierr[k];
+                st[(FPV_R_LERR + k) * ld + i] = s.lerr[k];
+            }
+            st[FPV_R_FIRST * ld + i] = s.first;
+            if (reward) reward[i] = r;
+            if (done) done[i] = 0;
+        }
+    }
+    return FPV_OK;
+}
+
+}  // extern "C"

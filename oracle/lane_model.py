@@ -1,0 +1,74 @@
+"""ctypes front-end of oracle/lane_model.cpp - the HIP kernel's per-lane fp32 arithmetic on the host.
+
+TEST INFRASTRUCTURE ONLY (see lane_model.cpp): used by tests to bound fp32-vs-float64 error on the
+CPU and to assert bit-exactness of the gfx950 kernel on the GPU box.  Never imported by fpyv_amd.
+"""
+from __future__ import annotations
+
+import ctypes as C
+import os
+from typing import Optional, Tuple
+
+import numpy as np
+
+from fpyv_amd import _lib as abi
+from . import oracle as _oracle
+
+_L = None
+
+
+def lib() -> C.CDLL:
+    global _L
+    if _L is None:
+        _oracle.build()
+        path = os.path.join(os.path.dirname(os.path.abspath(__file__)), "_build", "libfpv_lane_model.so")
+        if not os.path.isfile(path):
+            _oracle.build(force=True)
+        _L = C.CDLL(path)
+        fp, u8 = C.POINTER(C.c_float), C.POINTER(C.c_uint8)
+        _L.fpvl_run.argtypes = [C.POINTER(abi.FpvParams), C.c_int64, C.c_int, fp, C.c_int64, fp, C.c_int, fp, fp, u8, fp]
+        _L.fpvl_run.restype = C.c_int
+    return _L
+
+
+def initial_state(p, n: int, position=None, velocity=None, ypr_deg=None, ld: Optional[int] = None) -> np.ndarray:
+    """SoA [rows, ld] fp32 state after a reset, built the way the float64 side builds it (host
+    double math, rounded once) - used as the common starting point of parity runs."""
+    from fpyv_amd.params import ypr_to_quat
+    rows = abi.state_rows(int(p.mode))
+    ld = ld or (n + 63) // 64 * 64
+    s = np.zeros((rows, ld), dtype=np.float32)
+    if int(p.mode) == abi.FPV_MODE_DRONE:
+        pos = np.broadcast_to(np.asarray(p.init_position if position is None else position, float), (n, 3))
+        vel = np.broadcast_to(np.asarray(p.init_velocity if velocity is None else velocity, float), (n, 3))
+        ang = np.broadcast_to(np.asarray(p.init_orientation_deg if ypr_deg is None else ypr_deg, float), (n, 3))
+        s[0:3, :n] = pos.T
+        s[3:6, :n] = vel.T
+        s[6:10, :n] = np.stack([ypr_to_quat(*a) for a in ang]).T
+    else:
+        s[abi.QW, :n] = 1.0
+        s[abi.R_FIRST, :n] = 1.0
+    return s
+
+
+def run(p, state: np.ndarray, actions: np.ndarray, steps: Optional[int] = None, wind=(0.0, 0.0, 0.0),
+        n: Optional[int] = None, auto_reset: bool = False) -> Tuple[np.ndarray, np.ndarray, np.ndarray, np.ndarray]:
+    """Advance the SoA fp32 `state` in place.  Returns (state, accel [3,ld], done [n], reward [n])."""
+    assert state.dtype == np.float32 and state.flags.c_contiguous
+    ld = state.shape[1]
+    actions = np.ascontiguousarray(actions, dtype=np.float32)
+    per_step = actions.ndim == 3
+    n = n if n is not None else actions.shape[-2]
+    if per_step:
+        steps = actions.shape[0] if steps is None else steps
+    accel = np.zeros((3, ld), dtype=np.float32)
+    done = np.zeros(n, dtype=np.uint8)
+    reward = np.zeros(n, dtype=np.float32)
+    w = np.asarray(wind, dtype=np.float32)
+    cp = abi.pack_params(p, auto_reset=auto_reset)
+    fp = lambda a: a.ctypes.data_as(C.POINTER(C.c_float))  # noqa: E731
+    rc = lib().fpvl_run(C.byref(cp), n, steps, fp(state), ld, fp(actions), int(per_step), fp(w), fp(accel),
+                        done.ctypes.data_as(C.POINTER(C.c_uint8)), fp(reward))
+    if rc != 0:
+        raise RuntimeError(f"fpvl_run failed with {rc}")
+    return state, accel, done, reward

@@ -42,20 +42,12 @@ def build(force: bool = False) -> None:
                        stdout=subprocess.DEVNULL)
 
 
-def _cpu_has_v3() -> bool:
-    try:
-        flags = open("/proc/cpuinfo").read()
-    except OSError:
-        return False
-    return all(f" {x}" in flags for x in ("avx2", "fma", "bmi2"))
-
-
 _libs = {}
 
 
-def lib(fast: bool = False) -> C.CDLL:
-    """The portable build (checker) or, with fast=True and a capable CPU, the AVX2/FMA build."""
-    name = "libfpv_oracle_v3.so" if (fast and _cpu_has_v3()) else "libfpv_oracle.so"
+def lib() -> C.CDLL:
+    """Portable x86-64 build (gcc -O2, no -march: it must run on whatever CPU the GPU box has)."""
+    name = "libfpv_oracle.so"
     if name not in _libs:
         build()
         L = C.CDLL(os.path.join(_BUILD, name))
@@ -137,7 +129,7 @@ def drone_initial_state(n: int, position, velocity, ypr_deg) -> np.ndarray:
 
 
 def drone_run(p, state: np.ndarray, actions: np.ndarray, steps: Optional[int] = None,
-              wind=(0.0, 0.0, 0.0), threads: int = 1, fast: bool = False
+              wind=(0.0, 0.0, 0.0), threads: int = 1
               ) -> Tuple[np.ndarray, np.ndarray, np.ndarray]:
     """Advance `state` [n,19] in place.  actions: [steps,n,4] (one batch per step) or [n,4]
     (held for `steps` steps).  Returns (state, accel [n,3], done [n]) after the last step."""
@@ -154,7 +146,7 @@ def drone_run(p, state: np.ndarray, actions: np.ndarray, steps: Optional[int] = 
     done = np.zeros(n, dtype=np.uint8)
     w = np.asarray(wind, dtype=np.float64)
     op = pack_params(p)
-    lib(fast).fpvo_drone_step_batch(C.byref(op), n, steps, _dp(state), _dp(actions), int(per_step), _dp(w),
+    lib().fpvo_drone_step_batch(C.byref(op), n, steps, _dp(state), _dp(actions), int(per_step), _dp(w),
                                     _dp(accel), done.ctypes.data_as(C.POINTER(C.c_uint8)), threads)
     return state, accel, done
 

@@ -1,0 +1,122 @@
+"""fp32 error budget of the kernel's per-lane arithmetic (fpyv_amd/csrc/fpv_math.h compiled for
+the host by oracle/lane_model.cpp) against the float64 oracle, on the golden stick profiles.
+Runs without a GPU; the GPU tests then require the gfx950 kernel to reproduce this arithmetic."""
+import numpy as np
+import pytest
+
+from conftest import load_golden
+from oracle import lane_model, oracle
+from parity import REL_TOL, assert_parity, soa_vs_oracle
+
+
+def _both(p, g, steps=None):
+    acts = g["actions"] if steps is None else g["actions"][:steps]
+    n = acts.shape[1]
+    ref = oracle.drone_initial_state(n, g["init_position"], g["init_velocity"], g["init_ypr"])
+    _, ref_acc, ref_done = oracle.drone_run(p, ref, acts.astype(np.float64), wind=g["wind"])
+    s = lane_model.initial_state(p, n, g["init_position"], g["init_velocity"], g["init_ypr"])
+    _, acc, done, rew = lane_model.run(p, s, acts, wind=g["wind"])
+    return s, ref, acc, ref_acc, done, ref_done, rew, n
+
+
+@pytest.mark.parametrize("name", ["g2_sin_4096", "g3_ema_noise", "g4_saturated", "g5_attitude_wind"])
+def test_fp32_within_1e5_after_1000_steps(params_1k, name):
+    s, ref, acc, ref_acc, done, ref_done, rew, n = _both(params_1k, load_golden(name))
+    err = soa_vs_oracle(s, ref, n)
+    assert_parity(err, REL_TOL, name)
+    assert np.array_equal(done, ref_done)
+    np.testing.assert_allclose(acc[:, :n].T, ref_acc, rtol=2e-4, atol=2e-4)   # third return value, R_new @ acc
+    goal = params_1k.goal
+    np.testing.assert_allclose(rew, -np.linalg.norm(ref[:, 0:3] - goal, axis=1), rtol=1e-5, atol=1e-5)
+
+
+def test_fps60_large_step_angles(params_60):
+    """dt = 1/60: 200 deg/s * dt = 3.3 deg per application - the short sin/cos polynomial still holds."""
+    s, ref, *_rest, n = _both(params_60, load_golden("g1b_fps60_sin"))
+    assert_parity(soa_vs_oracle(s, ref, n), REL_TOL, "fps60")
+
+
+def test_config1_10k_steps_fp32_drift(params_1k):
+    """Config 1 (10 000 zero-stick steps, climbing to z ~ 206 m): plain fp32 accumulation is NOT
+    expected to hold 1e-5 (0.02 m increments against 200 m); document what it does hold."""
+    s, ref, *_rest, n = _both(params_1k, load_golden("g1_zero_10k"))
+    err = soa_vs_oracle(s, ref, n)
+    assert err["pos_rel"] < 2e-4 and err["quat_abs"] < 1e-6, err
+    s1k, ref1k, *_r, n = _both(params_1k, load_golden("g1_zero_10k"), steps=1000)
+    assert_parity(soa_vs_oracle(s1k, ref1k, n), REL_TOL, "config1 first 1000 steps")
+
+
+def test_ground_flag_sequence(params_1k):
+    g = load_golden("g6_ground")
+    acts = g["actions"]
+    T, n = acts.shape[:2]
+    s = lane_model.initial_state(params_1k, n, g["init_position"], g["init_velocity"], g["init_ypr"])
+    seq = np.zeros((n, T), dtype=np.uint8)
+    for t in range(T):
+        _, _, done, _ = lane_model.run(params_1k, s, acts[t:t + 1], wind=g["wind"])
+        seq[:, t] = done
+    # fp32 may flip a flag one step early/late exactly at a zero crossing; allow <= 1 step per edge
+    assert (seq != g["done"]).sum() <= 4
+    assert np.array_equal(seq.any(axis=1), g["done"].any(axis=1))
+
+
+def test_big_angle_path_matches_small(params_1k):
+    """max_rates large enough that the derive step selects library sincos: same trajectory."""
+    g = load_golden("g3_ema_noise")
+    n = g["actions"].shape[1]
+    p_big = params_1k.replace(max_rates=2.0e5, dt=1e-3)          # half-angle bound 1.75 rad > pi/4
+    acts = (g["actions"] * np.float32(1e-3)).astype(np.float32)   # same physical rates as max_rates=200
+    acts[..., 3] = g["actions"][..., 3]
+    s_big = lane_model.initial_state(p_big, n)
+    lane_model.run(p_big, s_big, acts)
+    ref = oracle.drone_initial_state(n, p_big.init_position, p_big.init_velocity, [0, 0, 0])
+    oracle.drone_run(p_big, ref, acts.astype(np.float64))
+    assert_parity(soa_vs_oracle(s_big, ref, n), 2e-5, "big-angle")
+
+
+def test_auto_reset_and_ceiling(params_1k):
+    p = params_1k.replace(ceiling=10.5)
+    n = 4
+    s = lane_model.initial_state(p, n)
+    acts = np.zeros((n, 4), dtype=np.float32)
+    acts[:, 3] = [1.0, 0.0, -1.0, 0.3]      # climbers hit the ceiling, the faller hits the ground later
+    hit = np.zeros(n, dtype=bool)
+    for t in range(400):
+        _, _, done, _ = lane_model.run(p, s, acts, steps=1, auto_reset=True)
+        for i in np.flatnonzero(done):
+            hit[i] = True
+            np.testing.assert_array_equal(s[0:3, i], p.init_position.astype(np.float32))
+            np.testing.assert_array_equal(s[10:14, i], 0)
+    assert hit[0] and hit[1], "full/half throttle must cross |z| > ceiling within 400 ms"
+    assert np.all(np.abs(s[2, :n]) <= 10.5 + 0.1)
+
+
+@pytest.mark.parametrize("name,tol", [("g7_racer_main", 2e-3), ("g8_racer_pid_thrust", 2e-3)])
+def test_racer_fp32(params_1k, name, tol):
+    """Racer as written rotates by omega [rad] per STEP (quirk Q7, racer_drone_test.py:99): tens of
+    radians per step, so an fp32 ulp of omega is ~4e-6 rad of attitude per step and the 1e-5 bound
+    of the Drone path does not transfer; the tolerance here is the measured fp32 conditioning."""
+    g = load_golden(name)
+    p = params_1k.replace(mode=1, racer_pid=g["pid"])
+    acts = g["actions"]
+    s = lane_model.initial_state(p, 1)
+    lane_model.run(p, s, acts)
+    np.testing.assert_allclose(s[10:13, 0], g["omega"][0, -1], rtol=1e-5, atol=1e-5)
+    np.testing.assert_allclose(s[0:3, 0], g["position"][0, -1], rtol=tol, atol=tol)
+    M = oracle.quat_to_matrix(s[6:10, 0].astype(np.float64))[0]
+    assert np.abs(M - g["matrix"][0, -1]).max() < tol
+
+
+def test_racer_omega_dt_variant_is_well_conditioned(params_1k):
+    g = load_golden("g8_racer_pid_thrust")
+    p = params_1k.replace(mode=1, racer_pid=g["pid"], racer_omega_dt=True)
+    acts = g["actions"]
+    s = lane_model.initial_state(p, 1)
+    lane_model.run(p, s, acts)
+    ref = oracle.racer_initial_state(1)
+    oracle.racer_run(p, ref, acts.astype(np.float64))
+    qx, qy, qz, qw = ref[0, 6:10]
+    q32 = s[6:10, 0].astype(np.float64)
+    q32 *= np.sign(q32 @ np.array([qw, qx, qy, qz]))
+    assert np.abs(q32 - [qw, qx, qy, qz]).max() < 1e-5
+    np.testing.assert_allclose(s[0:3, 0], ref[0, 0:3], rtol=1e-5, atol=1e-6)

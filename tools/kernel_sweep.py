@@ -1,0 +1,71 @@
+#!/usr/bin/env python3
+"""Interleaved A/B timing of launch geometries (drones per lane) and host paths in ONE process
+(cdna_hip_programming.md 5.4 rule 24).  Prints median / min microseconds per launch and the
+algorithmic-bytes bandwidth it implies."""
+import argparse
+import json
+import os
+import statistics
+import sys
+
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import torch  # noqa: E402
+
+from fpyv_amd import _lib, load_params, sticks  # noqa: E402
+from fpyv_amd.env import DroneBatch  # noqa: E402
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--n", type=int, default=1 << 20)
+    ap.add_argument("--launches", type=int, default=200)
+    ap.add_argument("--rounds", type=int, default=7)
+    ap.add_argument("--ring", type=int, default=32)
+    ap.add_argument("--dpl", type=int, nargs="*", default=[1, 2, 4])
+    ap.add_argument("--out", default=None)
+    a = ap.parse_args()
+    dev = torch.device("cuda:0")
+    p = load_params(fps=1000)
+    acts = sticks.ema_noise_device(a.ring, a.n, dev)
+    envs = {}
+    for d in a.dpl:
+        e = DroneBatch(p, a.n, device=dev, with_accel=False)
+        e.set_tuning(d)
+        e.reset()
+        envs[d] = e
+    variants = [(d, api) for d in a.dpl for api in ("rollout", "step")]
+    times = {v: [] for v in variants}
+    ev0, ev1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    for r in range(a.rounds + 1):
+        for v in variants:
+            d, api = v
+            e = envs[d]
+            torch.cuda.synchronize()
+            ev0.record()
+            done = 0
+            while done < a.launches:
+                span = min(a.ring, a.launches - done)
+                if api == "rollout":
+                    e.rollout(acts[:span])
+                else:
+                    for t in range(span):
+                        e.step(acts[t], return_imu=False)
+                done += span
+            ev1.record()
+            torch.cuda.synchronize()
+            if r:   # round 0 = warm-up
+                times[v].append(ev0.elapsed_time(ev1) * 1e3 / a.launches)
+    B = _lib.algorithmic_bytes(0)
+    res = []
+    for v in variants:
+        med, mn = statistics.median(times[v]), min(times[v])
+        res.append({"dpl": v[0], "api": v[1], "median_us": med, "min_us": mn,
+                    "GBps_alg_median": B * a.n / med / 1e3, "env_steps_per_s_median": a.n / med * 1e6})
+        print(f"dpl={v[0]} api={v[1]:8s} median {med:8.2f} us  min {mn:8.2f} us  "
+              f"{B * a.n / med / 1e3:8.1f} GB/s(alg)  {a.n / med:8.1f} M env-steps/s", flush=True)
+    if a.out:
+        json.dump({"n": a.n, "launches": a.launches, "rounds": a.rounds, "results": res}, open(a.out, "w"), indent=1)
+
+
+if __name__ == "__main__":
+    main()
