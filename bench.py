@@ -31,11 +31,16 @@ def cpu_baseline(params, seconds_budget=12.0):
     """The float64 C oracle (a port of Drone.step; the reference itself is Python and cannot
     travel) timed on this host: all cores via OpenMP, on a bounded sample of the same workload."""
     import numpy as np
-    from fpyv_amd import sticks
     from oracle import oracle
     threads = oracle.max_threads()
-    n = 1 << 16
-    acts = sticks.ema_noise(8, range(n), seed=1234).astype(np.float64)
+    n, chunk = 1 << 18, 32
+    x = np.random.default_rng(1234).standard_normal((chunk, n, 4))
+    acts = np.empty_like(x)
+    s = np.zeros((n, 4))
+    for t in range(chunk):                      # noise_smooth_test.py:11 recurrence
+        s = 0.9 * s + 0.1 * x[t]
+        acts[t] = s
+    del x
     st = oracle.drone_initial_state(n, params.init_position, params.init_velocity, params.init_orientation_deg)
     oracle.drone_run(params, st, acts[:2], threads=threads)          # warm-up (thread pool, page faults)
     steps_done, t0 = 0, time.perf_counter()
@@ -60,12 +65,15 @@ def cpu_baseline(params, seconds_budget=12.0):
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=200)
-    ap.add_argument("--warmup", type=int, default=20)
+    ap.add_argument("--steps", type=int, default=20000)
+    ap.add_argument("--warmup", type=int, default=200)
+    ap.add_argument("--preheat-s", type=float, default=0.5,
+                    help="seconds of untimed launches on a SCRATCH batch before the W warm-up steps, so the "
+                         "GPU has left its idle clocks (the timed region is only K x ~25 us)")
     ap.add_argument("--drones-per-gpu", type=int, default=1 << 20)
     ap.add_argument("--ring", type=int, default=32, help="distinct pre-generated action batches")
     ap.add_argument("--dpl", type=int, default=0, help="drones per lane (0 = library default)")
-    ap.add_argument("--api", choices=["rollout", "step"], default="rollout",
+    ap.add_argument("--api", choices=["rollout", "step"], default="step",
                     help="rollout: K launches from one C call; step: one Python env.step() per launch")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-gather", action="store_true", help="skip the done-mask all-gather (N > 1)")
@@ -128,6 +136,14 @@ def main():
             dist.barrier()
             torch.cuda.synchronize()
 
+    if args.preheat_s > 0:
+        scratch = DroneBatch(params, n, device=dev, with_accel=False)
+        scratch.reset()
+        t_end = time.perf_counter() + args.preheat_s
+        while time.perf_counter() < t_end:
+            scratch.rollout(actions)
+            torch.cuda.synchronize()
+        del scratch
     run(args.warmup, 0)
     fence()
     ev0, ev1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)

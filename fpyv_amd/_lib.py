@@ -26,7 +26,7 @@ R_OMEGA, R_IERR, R_LERR, R_FIRST = 10, 13, 16, 19
 
 # every symbol include/fpv_abi.h declares
 EXPORTS = ("fpv_abi_version", "fpv_state_rows", "fpv_algorithmic_bytes", "fpv_create", "fpv_destroy",
-           "fpv_reset", "fpv_step", "fpv_rollout", "fpv_set_params", "fpv_set_tuning", "fpv_last_error",
+           "fpv_reset", "fpv_step", "fpv_rollout", "fpv_set_params", "fpv_set_tuning", "fpv_diag_stream_copy", "fpv_last_error",
            "fpv_error_name")
 
 
@@ -118,6 +118,7 @@ def lib() -> C.CDLL:
     L.fpv_rollout.argtypes = [vp, pb, C.c_int, i64, i64, vp]
     L.fpv_set_params.argtypes = [vp, pp]
     L.fpv_set_tuning.argtypes = [vp, C.c_int]
+    L.fpv_diag_stream_copy.argtypes = [vp, vp, i64, vp]
     L.fpv_last_error.restype = C.c_char_p
     L.fpv_error_name.argtypes = [C.c_int]
     L.fpv_error_name.restype = C.c_char_p

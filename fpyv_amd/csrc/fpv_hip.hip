@@ -199,6 +199,16 @@ __global__ __launch_bounds__(kBlock) void fpv_reset_kernel(const FpvK K, const F
     if (B.ep_return) { B.ep_return[i] = 0.0f; B.ep_length[i] = 0; }
 }
 
+// Counter calibration: a copy with the step kernel's access shape (one dword per lane per
+// instruction, 256 contiguous bytes per wave) and an exactly known byte count, so FETCH_SIZE /
+// WRITE_SIZE read under rocprofv3 can be scaled (MI355X_MICROARCH.md, HBM section).
+__global__ __launch_bounds__(kBlock) void fpv_diag_copy_kernel(float* __restrict__ dst, const float* __restrict__ src,
+                                                               const int64_t n)
+{
+    const int64_t i = (int64_t)blockIdx.x * kBlock + threadIdx.x;
+    if (i < n) dst[i] = src[i];
+}
+
 thread_local std::string g_err;
 
 int fail(int code, const std::string& msg)
@@ -405,6 +415,16 @@ int fpv_rollout(fpv_handle_t h, const fpv_buffers_t* b, int k, int64_t action_st
         }
         if ((rc = launch_step(h, d, (hipStream_t)stream)) != FPV_OK) return rc;
     }
+    return FPV_OK;
+}
+
+int fpv_diag_stream_copy(float* dst, const float* src, int64_t n_floats, void* stream)
+{
+    if (!dst || !src || n_floats <= 0) return fail(FPV_EINVAL, "bad argument");
+    const dim3 grid((unsigned)((n_floats + kBlock - 1) / kBlock));
+    hipLaunchKernelGGL(fpv_diag_copy_kernel, grid, dim3(kBlock), 0, (hipStream_t)stream, dst, src, n_floats);
+    const hipError_t e = hipGetLastError();
+    if (e != hipSuccess) return hip_fail(e, "diag copy launch");
     return FPV_OK;
 }
 

@@ -145,6 +145,10 @@ int fpv_set_params(fpv_handle_t h, const fpv_params_t* params);
 /* Launch geometry: drones per lane in {1,2,4}; 0 restores the built-in choice. */
 int fpv_set_tuning(fpv_handle_t h, int drones_per_lane);
 
+/* Diagnostics only: dst[i] = src[i] for n_floats fp32 values with the step kernel's access shape
+ * (one dword per lane); a known-byte-count launch for calibrating rocprofv3 byte counters. */
+int fpv_diag_stream_copy(float* dst, const float* src, int64_t n_floats, void* stream);
+
 const char* fpv_last_error(void);
 const char* fpv_error_name(int code);
 

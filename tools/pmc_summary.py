@@ -1,0 +1,101 @@
+#!/usr/bin/env python3
+"""Turn rocprofv3 CSV output (kernel trace + separate --pmc FETCH_SIZE / WRITE_SIZE passes of
+tools/pmc_probe.py) into the committed summaries under profiles/:
+
+    python tools/pmc_summary.py --round r01 --kt gpurun_out/prof_kt --fetch gpurun_out/pmc_fetch \
+        --write gpurun_out/pmc_write
+
+Traffic is corrected as MI355X_MICROARCH.md (HBM section) prescribes: counters come from separate
+passes, are in KiB, and the read side is scaled by the factor measured on the calibration copy
+(fpv_diag_stream_copy: same one-dword-per-lane access shape, exactly known bytes) that runs in the
+same pass - on gfx950 FETCH_SIZE reads half of a coalesced streaming read."""
+import argparse
+import collections
+import csv
+import glob
+import json
+import os
+
+REPO = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def counters(d):
+    f = glob.glob(os.path.join(d, "**", "*_counter_collection.csv"), recursive=True)[0]
+    agg = collections.defaultdict(list)
+    for r in csv.DictReader(open(f)):
+        k = r["Kernel_Name"]
+        short = "step" if "fpv_drone_step" in k else ("copy" if "fpv_diag_copy" in k else None)
+        if short:
+            agg[(short, r["Counter_Name"])].append(
+                (float(r["Counter_Value"]), int(r["End_Timestamp"]) - int(r["Start_Timestamp"]), int(r["Grid_Size"])))
+    return agg
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--round", default="r01")
+    ap.add_argument("--kt", required=True)
+    ap.add_argument("--fetch", required=True)
+    ap.add_argument("--write", required=True)
+    ap.add_argument("--n", type=int, default=1 << 20)
+    ap.add_argument("--calib-floats", type=int, default=1 << 27)
+    a = ap.parse_args()
+    out_dir = os.path.join(REPO, "profiles")
+    os.makedirs(out_dir, exist_ok=True)
+
+    # kernel-trace stats: keep our kernels' rows verbatim
+    ks = glob.glob(os.path.join(a.kt, "**", "*_kernel_stats.csv"), recursive=True)[0]
+    rows = list(csv.reader(open(ks)))
+    keep = [rows[0]] + [r for r in rows[1:] if "fpv_" in r[0]]
+    with open(os.path.join(out_dir, f"{a.round}_kernel_stats.csv"), "w", newline="") as f:
+        csv.writer(f).writerows(keep)
+    step_row = [r for r in keep[1:] if "fpv_drone_step" in r[0]][0]
+    avg_ns, calls = float(step_row[3]), int(step_row[1])
+
+    fe, wr = counters(a.fetch), counters(a.write)
+    mean = lambda v: sum(x[0] for x in v) / len(v)  # noqa: E731
+    calib_kib = a.calib_floats * 4 / 1024
+    f_scale = calib_kib / mean(fe[("copy", "FETCH_SIZE")])
+    w_scale = calib_kib / mean(wr[("copy", "WRITE_SIZE")])
+    fetch_kib = mean(fe[("step", "FETCH_SIZE")]) * f_scale
+    write_kib = mean(wr[("step", "WRITE_SIZE")]) * w_scale
+    alg_read, alg_write = (56 + 16) * a.n, (56 + 4 + 1) * a.n
+    res = {
+        "source": f"profiles/{a.round}_pmc_summary.md (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE, separate passes, "
+                  f"calibrated on fpv_diag_stream_copy)",
+        "kernel": "fpv_drone_step_kernel<1,false>", "drones": a.n,
+        "fetch_raw_kib": mean(fe[("step", "FETCH_SIZE")]), "write_raw_kib": mean(wr[("step", "WRITE_SIZE")]),
+        "fetch_scale": f_scale, "write_scale": w_scale,
+        "read_bytes_per_launch": fetch_kib * 1024, "write_bytes_per_launch": write_kib * 1024,
+        "hbm_bytes_per_launch": (fetch_kib + write_kib) * 1024,
+        "algorithmic_bytes_per_launch": alg_read + alg_write,
+        "traffic_over_algorithmic": (fetch_kib + write_kib) * 1024 / (alg_read + alg_write),
+        "kernel_trace_avg_ns": avg_ns, "kernel_trace_calls": calls,
+        "pmc_pass_step_kernel_avg_ns": sum(x[1] for x in fe[("step", "FETCH_SIZE")]) / len(fe[("step", "FETCH_SIZE")]),
+    }
+    json.dump(res, open(os.path.join(out_dir, "pmc_traffic.json"), "w"), indent=1)
+    with open(os.path.join(out_dir, f"{a.round}_pmc_summary.md"), "w") as f:
+        f.write(f"# {a.round}: rocprofv3 summary of the step kernel (N = {a.n} drones, dt = 1 ms, EMA-noise sticks)\n\n")
+        f.write("Commands (GPU box, one MI355X):\n\n```\n"
+                "rocprofv3 --kernel-trace --stats --output-format csv -d prof_kt -- python3 bench.py --steps 2000 --warmup 200 --no-cpu-baseline\n"
+                "rocprofv3 --kernel-trace --pmc FETCH_SIZE --output-format csv -d pmc_fetch -- python3 tools/pmc_probe.py\n"
+                "rocprofv3 --kernel-trace --pmc WRITE_SIZE --output-format csv -d pmc_write -- python3 tools/pmc_probe.py\n```\n\n")
+        f.write("## kernel trace (--stats)\n\n| kernel | calls | avg ns | min ns | max ns |\n|---|---:|---:|---:|---:|\n")
+        for r in keep[1:]:
+            f.write(f"| `{r[0][:90]}` | {r[1]} | {float(r[3]):.0f} | {r[5]} | {r[6]} |\n")
+        f.write("\n## byte counters (separate passes; KiB)\n\n| kernel | counter | launches | mean raw | scale | corrected KiB |\n|---|---|---:|---:|---:|---:|\n")
+        for (k, c), v in list(fe.items()) + list(wr.items()):
+            sc = f_scale if c == "FETCH_SIZE" else w_scale
+            f.write(f"| {k} | {c} | {len(v)} | {mean(v):.1f} | {sc:.5f} | {mean(v) * sc:.1f} |\n")
+        f.write(f"\nCalibration copy moves exactly {calib_kib:.0f} KiB each way per launch "
+                f"(one dword per lane, the step kernel's access shape).\n\n")
+        f.write(f"Step kernel per launch: read {fetch_kib * 1024 / 1e6:.2f} MB (algorithmic {(alg_read) / 1e6:.2f} MB), "
+                f"write {write_kib * 1024 / 1e6:.2f} MB (algorithmic {alg_write / 1e6:.2f} MB); "
+                f"traffic / algorithmic = {res['traffic_over_algorithmic']:.4f}.\n")
+        f.write(f"At the kernel-trace average of {avg_ns / 1e3:.2f} us per launch that is "
+                f"{(alg_read + alg_write) / avg_ns:.1f} GB/s algorithmic = {(alg_read + alg_write) / avg_ns / 8000 * 100:.1f} % of the 8 TB/s HBM peak.\n")
+    print(json.dumps(res, indent=1))
+
+
+if __name__ == "__main__":
+    main()
