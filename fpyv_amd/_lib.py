@@ -26,7 +26,8 @@ R_OMEGA, R_IERR, R_LERR, R_FIRST = 10, 13, 16, 19
 
 # every symbol include/fpv_abi.h declares
 EXPORTS = ("fpv_abi_version", "fpv_state_rows", "fpv_algorithmic_bytes", "fpv_create", "fpv_destroy",
-           "fpv_reset", "fpv_step", "fpv_rollout", "fpv_set_params", "fpv_set_tuning", "fpv_diag_stream_copy", "fpv_last_error",
+           "fpv_reset", "fpv_step", "fpv_rollout", "fpv_set_params", "fpv_set_tuning", "fpv_recommended_ld",
+           "fpv_diag_stream_copy", "fpv_last_error",
            "fpv_error_name")
 
 
@@ -117,7 +118,9 @@ def lib() -> C.CDLL:
     L.fpv_step.argtypes = [vp, pb, vp]
     L.fpv_rollout.argtypes = [vp, pb, C.c_int, i64, i64, vp]
     L.fpv_set_params.argtypes = [vp, pp]
-    L.fpv_set_tuning.argtypes = [vp, C.c_int]
+    L.fpv_set_tuning.argtypes = [vp, C.c_int, C.c_int]
+    L.fpv_recommended_ld.argtypes = [i64]
+    L.fpv_recommended_ld.restype = i64
     L.fpv_diag_stream_copy.argtypes = [vp, vp, i64, vp]
     L.fpv_last_error.restype = C.c_char_p
     L.fpv_error_name.argtypes = [C.c_int]

@@ -1,7 +1,12 @@
 // fpv_hip.hip - gfx950 kernels + the C ABI of include/fpv_abi.h.
 //
 // One lane = one drone (or DPL drones, strided by the block width so every wave instruction still
-// touches 256 contiguous bytes of each SoA row).  A step is: 14 row loads + one 16-byte action
+// touches 256 contiguous bytes of each SoA row).  Measured on MI355X at 2^20 drones (tools/exp,
+// profiles/r01_exp_*.log): 128-thread workgroups beat 64/256/512/1024, one drone per lane beats
+// 2/4 (scalar or float2/float4 rows), persistent/grid-stride/prefetch loops lose to plain
+// oversubscription, non-temporal hints on the once-touched operands (action in, reward/done out)
+// are worth ~0.5 %, and a row stride that is NOT a multiple of 8 KiB is worth 6-9 %
+// (fpv_recommended_ld).  A step is: 14 row loads + one 16-byte action
 // load per drone -> ~250 flop in registers (fpv_math.h) -> 14 row stores + reward + done.  There is
 // no reuse, no cross-lane data flow and no dense contraction, so the kernel is bound by HBM / the
 // Infinity Cache; the only wave-level primitive on the data path is the ballot that bit-packs the
@@ -60,6 +65,16 @@ __device__ __forceinline__ void st_drone(float* __restrict__ st, int64_t ld, int
     st[FPV_THRUST * ld + i] = s.thrust;
 }
 
+typedef float fpv_v4f __attribute__((ext_vector_type(4)));
+
+// The action batch is read once and reward/done are written once per step: non-temporal, so they
+// do not displace the state rows, which are re-read next step, from L2 / Infinity Cache.
+__device__ __forceinline__ float4 ld_action(const float4* __restrict__ a, int64_t i)
+{
+    const fpv_v4f v = __builtin_nontemporal_load(reinterpret_cast<const fpv_v4f*>(a + i));
+    return make_float4(v.x, v.y, v.z, v.w);
+}
+
 // Episode bookkeeping + done outputs shared by both modes.  `done` is wave-divergent data;
 // all pointer tests are wave-uniform scalar branches.
 __device__ __forceinline__ void emit_outputs(const FpvBufD& B, int64_t i, bool live, float reward, bool done)
@@ -68,8 +83,8 @@ __device__ __forceinline__ void emit_outputs(const FpvBufD& B, int64_t i, bool l
     const unsigned long long mask = __ballot(live && done);
     if (B.done_bits && (threadIdx.x & 63) == 0 && live) B.done_bits[i >> 6] = mask;
     if (!live) return;
-    if (B.reward) B.reward[i] = reward;
-    if (B.done) B.done[i] = done ? 1 : 0;
+    if (B.reward) __builtin_nontemporal_store(reward, &B.reward[i]);
+    if (B.done) __builtin_nontemporal_store((uint8_t)(done ? 1 : 0), &B.done[i]);
     if (B.ep_return) {
         const float r = B.ep_return[i] + reward;
         const int32_t l = B.ep_length[i] + 1;
@@ -82,26 +97,26 @@ __device__ __forceinline__ void emit_outputs(const FpvBufD& B, int64_t i, bool l
     }
 }
 
-template <int DPL, bool BIG>
-__global__ __launch_bounds__(kBlock) void fpv_drone_step_kernel(const FpvK K, const FpvBufD B, const int64_t n)
+template <int BS, int DPL, bool BIG>
+__global__ __launch_bounds__(BS) void fpv_drone_step_kernel(const FpvK K, const FpvBufD B, const int64_t n)
 {
-    const int64_t base = (int64_t)blockIdx.x * (kBlock * DPL) + threadIdx.x;
+    const int64_t base = (int64_t)blockIdx.x * (BS * DPL) + threadIdx.x;
     FpvDroneState s[DPL];
     float4 a[DPL];
     bool live[DPL];
     // issue every load of every drone of this lane before the first use
 #pragma unroll
     for (int j = 0; j < DPL; ++j) {
-        const int64_t i = base + (int64_t)j * kBlock;
+        const int64_t i = base + (int64_t)j * BS;
         live[j] = i < n;
         if (live[j]) {
-            a[j] = B.action[i];
+            a[j] = ld_action(B.action, i);
             ld_drone(B.state, B.ld, i, s[j]);
         }
     }
 #pragma unroll
     for (int j = 0; j < DPL; ++j) {
-        const int64_t i = base + (int64_t)j * kBlock;
+        const int64_t i = base + (int64_t)j * BS;
         FpvStepOut o;
         o.done = false; o.reward = 0.0f; o.ax = o.ay = o.az = 0.0f;
         if (live[j]) {
@@ -152,7 +167,7 @@ __global__ __launch_bounds__(kBlock) void fpv_racer_step_kernel(const FpvK K, co
     bool done = false;
     if (live) {
         FpvRacerState s;
-        const float4 a = B.action[i];
+        const float4 a = ld_action(B.action, i);
         ld_racer(B.state, B.ld, i, s);
         reward = fpv_racer_step_lane(K, s, a.x, a.y, a.z, a.w);
         done = !(fabsf(s.pz) <= K.ceiling);            // the Racer has no ground; build-defined ceiling only
@@ -232,6 +247,7 @@ struct fpv_env {
     int device;
     int mode;
     int dpl;        // drones per lane (1, 2 or 4)
+    int block;      // threads per workgroup of the drone step kernel (128 or 256)
     bool big_angle;
 };
 
@@ -278,25 +294,32 @@ int bind_device(const fpv_env* h)
     return FPV_OK;
 }
 
-template <int DPL>
+template <int BS, int DPL>
 void launch_drone(const fpv_env* h, const FpvBufD& d, hipStream_t s)
 {
-    const int64_t per_block = (int64_t)kBlock * DPL;
+    const int64_t per_block = (int64_t)BS * DPL;
     const dim3 grid((unsigned)((h->n + per_block - 1) / per_block));
     if (h->big_angle)
-        hipLaunchKernelGGL((fpv_drone_step_kernel<DPL, true>), grid, dim3(kBlock), 0, s, h->K, d, h->n);
+        hipLaunchKernelGGL((fpv_drone_step_kernel<BS, DPL, true>), grid, dim3(BS), 0, s, h->K, d, h->n);
     else
-        hipLaunchKernelGGL((fpv_drone_step_kernel<DPL, false>), grid, dim3(kBlock), 0, s, h->K, d, h->n);
+        hipLaunchKernelGGL((fpv_drone_step_kernel<BS, DPL, false>), grid, dim3(BS), 0, s, h->K, d, h->n);
+}
+
+template <int BS>
+void launch_drone_bs(const fpv_env* h, const FpvBufD& d, hipStream_t s)
+{
+    switch (h->dpl) {
+        case 4: launch_drone<BS, 4>(h, d, s); break;
+        case 2: launch_drone<BS, 2>(h, d, s); break;
+        default: launch_drone<BS, 1>(h, d, s); break;
+    }
 }
 
 int launch_step(const fpv_env* h, const FpvBufD& d, hipStream_t s)
 {
     if (h->mode == FPV_MODE_DRONE) {
-        switch (h->dpl) {
-            case 4: launch_drone<4>(h, d, s); break;
-            case 2: launch_drone<2>(h, d, s); break;
-            default: launch_drone<1>(h, d, s); break;
-        }
+        if (h->block == 256) launch_drone_bs<256>(h, d, s);
+        else launch_drone_bs<128>(h, d, s);
     } else {
         const dim3 grid((unsigned)((h->n + kBlock - 1) / kBlock));
         hipLaunchKernelGGL(fpv_racer_step_kernel, grid, dim3(kBlock), 0, s, h->K, d, h->n);
@@ -345,7 +368,7 @@ int fpv_create(const fpv_params_t* params, int64_t n, int device, fpv_handle_t* 
     fpv_env* h = new (std::nothrow) fpv_env;
     if (!h) return fail(FPV_EINVAL, "out of host memory");
     h->K = K; h->P = *params; h->n = n; h->device = device; h->mode = (int)params->mode;
-    h->dpl = 1; h->big_angle = big;
+    h->dpl = 1; h->block = 128; h->big_angle = big;
     *out = h;
     return FPV_OK;
 }
@@ -365,14 +388,28 @@ int fpv_set_params(fpv_handle_t h, const fpv_params_t* params)
     return FPV_OK;
 }
 
-int fpv_set_tuning(fpv_handle_t h, int drones_per_lane)
+int fpv_set_tuning(fpv_handle_t h, int drones_per_lane, int block_threads)
 {
     if (!h) return fail(FPV_EINVAL, "null handle");
     if (drones_per_lane == 0) drones_per_lane = 1;
+    if (block_threads == 0) block_threads = 128;
     if (drones_per_lane != 1 && drones_per_lane != 2 && drones_per_lane != 4)
         return fail(FPV_EINVAL, "drones_per_lane must be 0, 1, 2 or 4");
+    if (block_threads != 128 && block_threads != 256)
+        return fail(FPV_EINVAL, "block_threads must be 0, 128 or 256");
     h->dpl = drones_per_lane;
+    h->block = block_threads;
     return FPV_OK;
+}
+
+int64_t fpv_recommended_ld(int64_t n)
+{
+    if (n <= 0) return fail(FPV_EINVAL, "n must be positive");
+    int64_t ld = (n + 63) / 64 * 64;
+    // 14 rows whose stride is a multiple of 8 KiB land on the same HBM channel/bank set and cost
+    // 6-9 % at 2^20 drones; one extra KiB per row spreads them.
+    if (ld % 2048 == 0) ld += 256;
+    return ld;
 }
 
 int fpv_reset(fpv_handle_t h, const fpv_buffers_t* b, const uint8_t* mask, const float* position,

@@ -46,7 +46,7 @@ class _Batch:
         self._L = _lib.lib()
         self.mode = int(params.mode)
         self.rows = _lib.state_rows(self.mode)
-        self.ld = _round_up(self.n, 64)
+        self.ld = int(self._L.fpv_recommended_ld(self.n))
         dev_index = self.device.index if self.device.index is not None else torch.cuda.current_device()
         self._handle = C.c_void_p()
         self._cparams = _lib.pack_params(params, auto_reset=auto_reset)
@@ -100,8 +100,8 @@ class _Batch:
         self._keepalive = action
         return action.data_ptr()
 
-    def set_tuning(self, drones_per_lane: int) -> None:
-        _lib.check(self._L.fpv_set_tuning(self._handle, int(drones_per_lane)))
+    def set_tuning(self, drones_per_lane: int = 0, block_threads: int = 0) -> None:
+        _lib.check(self._L.fpv_set_tuning(self._handle, int(drones_per_lane), int(block_threads)))
 
     def set_params(self, params: DroneParams, auto_reset: Optional[bool] = None) -> None:
         flags_auto = bool(self._cparams.flags & _lib.FPV_FLAG_AUTO_RESET) if auto_reset is None else auto_reset

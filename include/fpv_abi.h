@@ -142,8 +142,14 @@ int fpv_rollout(fpv_handle_t h, const fpv_buffers_t* b, int k, int64_t action_st
 /* Replace the drone type of a live handle (e.g. domain randomisation between episodes). */
 int fpv_set_params(fpv_handle_t h, const fpv_params_t* params);
 
-/* Launch geometry: drones per lane in {1,2,4}; 0 restores the built-in choice. */
-int fpv_set_tuning(fpv_handle_t h, int drones_per_lane);
+/* Launch geometry: drones per lane in {1,2,4} and threads per workgroup in {128,256}; 0 restores
+ * the built-in choice (1 drone per lane, 128 threads - the fastest measured on MI355X). */
+int fpv_set_tuning(fpv_handle_t h, int drones_per_lane, int block_threads);
+
+/* Row stride (in floats) to allocate for n drones: n rounded up to 64, plus 256 when that would
+ * make the stride a multiple of 8 KiB (power-of-two strides put all 14 rows on the same HBM
+ * channel/bank set).  Any ld >= n that is a multiple of 4 is accepted by fpv_step. */
+int64_t fpv_recommended_ld(int64_t n);
 
 /* Diagnostics only: dst[i] = src[i] for n_floats fp32 values with the step kernel's access shape
  * (one dword per lane); a known-byte-count launch for calibrating rocprofv3 byte counters. */

@@ -1,0 +1,232 @@
+// Experimental launch geometries / access shapes for the step kernel.  NOT part of the product:
+// built into tools/exp/libfpv_exp.so by tools/exp/run_exp.py and timed A/B in one process.
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+#include "../../include/fpv_abi.h"
+#include "../../fpyv_amd/csrc/fpv_derive.h"
+#include "../../fpyv_amd/csrc/fpv_math.h"
+
+struct Buf {
+    float* state; int64_t ld; const float4* action; float* reward; uint8_t* done; float wx, wy, wz;
+};
+
+typedef float v4f __attribute__((ext_vector_type(4)));
+__device__ __forceinline__ float4 nt_load4(const float4* p)
+{
+    v4f v = __builtin_nontemporal_load(reinterpret_cast<const v4f*>(p));
+    return make_float4(v.x, v.y, v.z, v.w);
+}
+
+#define LD(row) st[(int64_t)(row) * ld + i]
+
+__device__ __forceinline__ void ld_drone(const float* __restrict__ st, int64_t ld, int64_t i, FpvDroneState& s)
+{
+    s.px = LD(0); s.py = LD(1); s.pz = LD(2); s.vx = LD(3); s.vy = LD(4); s.vz = LD(5);
+    s.q.w = LD(6); s.q.x = LD(7); s.q.y = LD(8); s.q.z = LD(9); s.rx = LD(10); s.ry = LD(11); s.rz = LD(12); s.thrust = LD(13);
+}
+__device__ __forceinline__ void st_drone(float* __restrict__ st, int64_t ld, int64_t i, const FpvDroneState& s)
+{
+    LD(0) = s.px; LD(1) = s.py; LD(2) = s.pz; LD(3) = s.vx; LD(4) = s.vy; LD(5) = s.vz;
+    LD(6) = s.q.w; LD(7) = s.q.x; LD(8) = s.q.y; LD(9) = s.q.z; LD(10) = s.rx; LD(11) = s.ry; LD(12) = s.rz; LD(13) = s.thrust;
+}
+
+// V0: product shape, block size BS, optional passthrough (no physics) and nt hints
+template <int BS, bool PASS, bool NT>
+__global__ __launch_bounds__(BS) void k_base(const FpvK K, const Buf B, const int64_t n)
+{
+    const int64_t i = (int64_t)blockIdx.x * BS + threadIdx.x;
+    if (i >= n) return;
+    FpvDroneState s;
+    float4 a = NT ? nt_load4(&B.action[i]) : B.action[i];
+    ld_drone(B.state, B.ld, i, s);
+    float reward; bool done;
+    if (PASS) {
+        s.px += a.x * 1e-9f; s.py += a.y * 1e-9f; s.pz += a.z * 1e-9f; s.thrust += a.w * 1e-9f;
+        reward = s.vx; done = s.vy > 1e30f;
+    } else {
+        FpvStepOut o = fpv_drone_step_lane<false>(K, s, a.x, a.y, a.z, a.w, B.wx, B.wy, B.wz);
+        reward = o.reward; done = o.done;
+    }
+    st_drone(B.state, B.ld, i, s);
+    if (NT) { __builtin_nontemporal_store(reward, &B.reward[i]); __builtin_nontemporal_store((uint8_t)(done ? 1 : 0), &B.done[i]); }
+    else { B.reward[i] = reward; B.done[i] = done ? 1 : 0; }
+}
+
+// V1: 4 consecutive drones per lane, float4 row loads/stores; actions as 4 float4 loads (64 B per lane)
+template <bool PASS>
+__global__ __launch_bounds__(256) void k_vec4(const FpvK K, const Buf B, const int64_t n)
+{
+    const int64_t i0 = ((int64_t)blockIdx.x * 256 + threadIdx.x) * 4;
+    if (i0 >= n) return;   // n % 4 == 0 required
+    float4 r[14];
+#pragma unroll
+    for (int k = 0; k < 14; ++k) r[k] = *reinterpret_cast<const float4*>(&B.state[(int64_t)k * B.ld + i0]);
+    float4 a[4];
+#pragma unroll
+    for (int j = 0; j < 4; ++j) a[j] = B.action[i0 + j];
+    float rew[4]; uint8_t dn[4];
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+        FpvDroneState s;
+        const float* f = reinterpret_cast<const float*>(r);
+        s.px = f[0 * 4 + j]; s.py = f[1 * 4 + j]; s.pz = f[2 * 4 + j]; s.vx = f[3 * 4 + j]; s.vy = f[4 * 4 + j]; s.vz = f[5 * 4 + j];
+        s.q.w = f[6 * 4 + j]; s.q.x = f[7 * 4 + j]; s.q.y = f[8 * 4 + j]; s.q.z = f[9 * 4 + j];
+        s.rx = f[10 * 4 + j]; s.ry = f[11 * 4 + j]; s.rz = f[12 * 4 + j]; s.thrust = f[13 * 4 + j];
+        if (PASS) {
+            s.px += a[j].x * 1e-9f; s.py += a[j].y * 1e-9f; s.pz += a[j].z * 1e-9f; s.thrust += a[j].w * 1e-9f;
+            rew[j] = s.vx; dn[j] = s.vy > 1e30f;
+        } else {
+            FpvStepOut o = fpv_drone_step_lane<false>(K, s, a[j].x, a[j].y, a[j].z, a[j].w, B.wx, B.wy, B.wz);
+            rew[j] = o.reward; dn[j] = o.done;
+        }
+        float* g = reinterpret_cast<float*>(r);
+        g[0 * 4 + j] = s.px; g[1 * 4 + j] = s.py; g[2 * 4 + j] = s.pz; g[3 * 4 + j] = s.vx; g[4 * 4 + j] = s.vy; g[5 * 4 + j] = s.vz;
+        g[6 * 4 + j] = s.q.w; g[7 * 4 + j] = s.q.x; g[8 * 4 + j] = s.q.y; g[9 * 4 + j] = s.q.z;
+        g[10 * 4 + j] = s.rx; g[11 * 4 + j] = s.ry; g[12 * 4 + j] = s.rz; g[13 * 4 + j] = s.thrust;
+    }
+#pragma unroll
+    for (int k = 0; k < 14; ++k) *reinterpret_cast<float4*>(&B.state[(int64_t)k * B.ld + i0]) = r[k];
+    *reinterpret_cast<float4*>(&B.reward[i0]) = make_float4(rew[0], rew[1], rew[2], rew[3]);
+    *reinterpret_cast<uchar4*>(&B.done[i0]) = make_uchar4(dn[0], dn[1], dn[2], dn[3]);
+}
+
+// V2: persistent waves, register double buffer: loads of tile t+1 are in flight while tile t computes
+template <bool PASS>
+__global__ __launch_bounds__(256) void k_prefetch(const FpvK K, const Buf B, const int64_t n)
+{
+    const int64_t stride = (int64_t)gridDim.x * 256;
+    int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    FpvDroneState s, sn;
+    float4 a, an;
+    if (i < n) { a = B.action[i]; ld_drone(B.state, B.ld, i, s); }
+    while (i < n) {
+        const int64_t inext = i + stride;
+        if (inext < n) { an = B.action[inext]; ld_drone(B.state, B.ld, inext, sn); }
+        float reward; bool done;
+        if (PASS) {
+            s.px += a.x * 1e-9f; s.py += a.y * 1e-9f; s.pz += a.z * 1e-9f; s.thrust += a.w * 1e-9f;
+            reward = s.vx; done = s.vy > 1e30f;
+        } else {
+            FpvStepOut o = fpv_drone_step_lane<false>(K, s, a.x, a.y, a.z, a.w, B.wx, B.wy, B.wz);
+            reward = o.reward; done = o.done;
+        }
+        st_drone(B.state, B.ld, i, s);
+        B.reward[i] = reward; B.done[i] = done ? 1 : 0;
+        s = sn; a = an; i = inext;
+    }
+}
+
+// V3: plain grid-stride loop (no explicit prefetch), G blocks
+template <bool PASS>
+__global__ __launch_bounds__(256) void k_gridstride(const FpvK K, const Buf B, const int64_t n)
+{
+    const int64_t stride = (int64_t)gridDim.x * 256;
+    for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < n; i += stride) {
+        FpvDroneState s;
+        float4 a = B.action[i];
+        ld_drone(B.state, B.ld, i, s);
+        float reward; bool done;
+        if (PASS) {
+            s.px += a.x * 1e-9f; s.py += a.y * 1e-9f; s.pz += a.z * 1e-9f; s.thrust += a.w * 1e-9f;
+            reward = s.vx; done = s.vy > 1e30f;
+        } else {
+            FpvStepOut o = fpv_drone_step_lane<false>(K, s, a.x, a.y, a.z, a.w, B.wx, B.wy, B.wz);
+            reward = o.reward; done = o.done;
+        }
+        st_drone(B.state, B.ld, i, s);
+        B.reward[i] = reward; B.done[i] = done ? 1 : 0;
+    }
+}
+
+
+// V4: generalised vector shape: V consecutive drones per lane (V = 1, 2, 4), block BS, nt hints on the
+// streamed operands (action in; reward/done out)
+template <int V> struct VecT;
+template <> struct VecT<1> { typedef float T; };
+template <> struct VecT<2> { typedef float __attribute__((ext_vector_type(2))) T; };
+template <> struct VecT<4> { typedef float __attribute__((ext_vector_type(4))) T; };
+
+template <int V, int BS, bool NT, bool NTS, int MINW>
+__global__ __launch_bounds__(BS, MINW) void k_vecg(const FpvK K, const Buf B, const int64_t n)
+{
+    typedef typename VecT<V>::T vt;
+    const int64_t i0 = ((int64_t)blockIdx.x * BS + threadIdx.x) * V;
+    if (i0 >= n) return;   // n % V == 0 required
+    vt r[14];
+#pragma unroll
+    for (int k = 0; k < 14; ++k) r[k] = *reinterpret_cast<const vt*>(&B.state[(int64_t)k * B.ld + i0]);
+    v4f a[V];
+#pragma unroll
+    for (int j = 0; j < V; ++j) {
+        const v4f* ap = reinterpret_cast<const v4f*>(&B.action[i0 + j]);
+        a[j] = NT ? __builtin_nontemporal_load(ap) : *ap;
+    }
+    float rew[V]; uint8_t dn[V];
+    float* f = reinterpret_cast<float*>(r);
+#pragma unroll
+    for (int j = 0; j < V; ++j) {
+        FpvDroneState s;
+        s.px = f[0 * V + j]; s.py = f[1 * V + j]; s.pz = f[2 * V + j]; s.vx = f[3 * V + j]; s.vy = f[4 * V + j]; s.vz = f[5 * V + j];
+        s.q.w = f[6 * V + j]; s.q.x = f[7 * V + j]; s.q.y = f[8 * V + j]; s.q.z = f[9 * V + j];
+        s.rx = f[10 * V + j]; s.ry = f[11 * V + j]; s.rz = f[12 * V + j]; s.thrust = f[13 * V + j];
+        FpvStepOut o = fpv_drone_step_lane<false>(K, s, a[j].x, a[j].y, a[j].z, a[j].w, B.wx, B.wy, B.wz);
+        rew[j] = o.reward; dn[j] = o.done;
+        f[0 * V + j] = s.px; f[1 * V + j] = s.py; f[2 * V + j] = s.pz; f[3 * V + j] = s.vx; f[4 * V + j] = s.vy; f[5 * V + j] = s.vz;
+        f[6 * V + j] = s.q.w; f[7 * V + j] = s.q.x; f[8 * V + j] = s.q.y; f[9 * V + j] = s.q.z;
+        f[10 * V + j] = s.rx; f[11 * V + j] = s.ry; f[12 * V + j] = s.rz; f[13 * V + j] = s.thrust;
+    }
+#pragma unroll
+    for (int k = 0; k < 14; ++k) {
+        vt* dp = reinterpret_cast<vt*>(&B.state[(int64_t)k * B.ld + i0]);
+        if (NTS) __builtin_nontemporal_store(r[k], dp); else *dp = r[k];
+    }
+    vt rv; float* rf = reinterpret_cast<float*>(&rv);
+#pragma unroll
+    for (int j = 0; j < V; ++j) rf[j] = rew[j];
+    if (NT) __builtin_nontemporal_store(rv, reinterpret_cast<vt*>(&B.reward[i0])); else *reinterpret_cast<vt*>(&B.reward[i0]) = rv;
+    if (V == 4) {
+        const uint32_t w = dn[0] | (dn[1] << 8) | (dn[V > 2 ? 2 : 0] << 16) | (dn[V > 3 ? 3 : 0] << 24);
+        if (NT) __builtin_nontemporal_store(w, reinterpret_cast<uint32_t*>(&B.done[i0])); else *reinterpret_cast<uint32_t*>(&B.done[i0]) = w;
+    } else if (V == 2) {
+        const uint16_t w = dn[0] | (dn[V > 1 ? 1 : 0] << 8);
+        if (NT) __builtin_nontemporal_store(w, reinterpret_cast<uint16_t*>(&B.done[i0])); else *reinterpret_cast<uint16_t*>(&B.done[i0]) = w;
+    } else {
+        if (NT) __builtin_nontemporal_store(dn[0], &B.done[i0]); else B.done[i0] = dn[0];
+    }
+}
+
+#define VG(id, V, BS, NT, NTS, W) case id: hipLaunchKernelGGL((k_vecg<V, BS, NT, NTS, W>), dim3((unsigned)((n / V + BS - 1) / BS)), dim3(BS), 0, s, K, B, n); break;
+
+extern "C" int exp_step(const fpv_params_t* P, float* state, int64_t ld, const float* action, float* reward,
+                        uint8_t* done, int64_t n, int variant, int grid_blocks, void* stream)
+{
+    FpvK K; bool big; const char* why;
+    if (fpv_derive_constants(P, &K, &big, &why) != 0) return -1;
+    Buf B{state, ld, reinterpret_cast<const float4*>(action), reward, done, 0.f, 0.f, 0.f};
+    hipStream_t s = (hipStream_t)stream;
+    auto G = [&](int bs) { return dim3((unsigned)((n + bs - 1) / bs)); };
+    switch (variant) {
+        case 0: hipLaunchKernelGGL((k_base<256, false, false>), G(256), dim3(256), 0, s, K, B, n); break;
+        case 1: hipLaunchKernelGGL((k_base<256, true, false>), G(256), dim3(256), 0, s, K, B, n); break;
+        case 2: hipLaunchKernelGGL((k_base<64, false, false>), G(64), dim3(64), 0, s, K, B, n); break;
+        case 3: hipLaunchKernelGGL((k_base<128, false, false>), G(128), dim3(128), 0, s, K, B, n); break;
+        case 4: hipLaunchKernelGGL((k_base<512, false, false>), G(512), dim3(512), 0, s, K, B, n); break;
+        case 5: hipLaunchKernelGGL((k_base<1024, false, false>), G(1024), dim3(1024), 0, s, K, B, n); break;
+        case 6: hipLaunchKernelGGL((k_base<256, false, true>), G(256), dim3(256), 0, s, K, B, n); break;
+        case 7: hipLaunchKernelGGL((k_base<256, true, true>), G(256), dim3(256), 0, s, K, B, n); break;
+        case 10: hipLaunchKernelGGL((k_vec4<false>), G(1024), dim3(256), 0, s, K, B, n); break;
+        case 11: hipLaunchKernelGGL((k_vec4<true>), G(1024), dim3(256), 0, s, K, B, n); break;
+        case 20: hipLaunchKernelGGL((k_prefetch<false>), dim3(grid_blocks), dim3(256), 0, s, K, B, n); break;
+        case 21: hipLaunchKernelGGL((k_prefetch<true>), dim3(grid_blocks), dim3(256), 0, s, K, B, n); break;
+        case 30: hipLaunchKernelGGL((k_gridstride<false>), dim3(grid_blocks), dim3(256), 0, s, K, B, n); break;
+        case 31: hipLaunchKernelGGL((k_gridstride<true>), dim3(grid_blocks), dim3(256), 0, s, K, B, n); break;
+        VG(100, 1, 128, false, false, 1) VG(101, 1, 128, true, false, 1) VG(102, 1, 256, true, false, 1) VG(103, 1, 64, true, false, 1)
+        VG(110, 2, 64, false, false, 1) VG(111, 2, 128, false, false, 1) VG(112, 2, 256, false, false, 1) VG(113, 2, 128, true, false, 1) VG(114, 2, 64, true, false, 1)
+        VG(120, 4, 64, false, false, 1) VG(121, 4, 128, false, false, 1) VG(122, 4, 256, false, false, 1) VG(123, 4, 128, true, false, 1) VG(124, 4, 64, true, false, 1)
+        VG(125, 4, 256, true, false, 1) VG(126, 4, 128, true, true, 1) VG(127, 4, 128, true, false, 4) VG(128, 4, 64, true, false, 4) VG(129, 4, 256, true, false, 4)
+        VG(130, 2, 128, true, true, 1) VG(131, 1, 128, true, true, 1)
+        default: return -2;
+    }
+    return hipGetLastError() == hipSuccess ? 0 : -3;
+}

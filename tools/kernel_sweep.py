@@ -21,25 +21,27 @@ def main():
     ap.add_argument("--launches", type=int, default=200)
     ap.add_argument("--rounds", type=int, default=7)
     ap.add_argument("--ring", type=int, default=32)
-    ap.add_argument("--dpl", type=int, nargs="*", default=[1, 2, 4])
+    ap.add_argument("--geom", type=str, nargs="*", default=["1x128", "1x256", "2x128", "4x128"],
+                    help="<drones per lane>x<threads per workgroup>")
     ap.add_argument("--out", default=None)
     a = ap.parse_args()
     dev = torch.device("cuda:0")
     p = load_params(fps=1000)
     acts = sticks.ema_noise_device(a.ring, a.n, dev)
     envs = {}
-    for d in a.dpl:
-        e = DroneBatch(p, a.n, device=dev, with_accel=False)
-        e.set_tuning(d)
-        e.reset()
-        envs[d] = e
-    variants = [(d, api) for d in a.dpl for api in ("rollout", "step")]
+    # ONE state buffer for every geometry: timings depend on buffer placement
+    shared = DroneBatch(p, a.n, device=dev, with_accel=False)
+    shared.reset()
+    for g in a.geom:
+        envs[g] = shared
+    variants = [(g, api) for g in a.geom for api in ("rollout", "step")]
     times = {v: [] for v in variants}
     ev0, ev1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
     for r in range(a.rounds + 1):
         for v in variants:
             d, api = v
             e = envs[d]
+            e.set_tuning(*[int(x) for x in d.split("x")])
             torch.cuda.synchronize()
             ev0.record()
             done = 0
@@ -59,9 +61,9 @@ def main():
     res = []
     for v in variants:
         med, mn = statistics.median(times[v]), min(times[v])
-        res.append({"dpl": v[0], "api": v[1], "median_us": med, "min_us": mn,
+        res.append({"geom": v[0], "api": v[1], "median_us": med, "min_us": mn,
                     "GBps_alg_median": B * a.n / med / 1e3, "env_steps_per_s_median": a.n / med * 1e6})
-        print(f"dpl={v[0]} api={v[1]:8s} median {med:8.2f} us  min {mn:8.2f} us  "
+        print(f"geom={v[0]} api={v[1]:8s} median {med:8.2f} us  min {mn:8.2f} us  "
               f"{B * a.n / med / 1e3:8.1f} GB/s(alg)  {a.n / med:8.1f} M env-steps/s", flush=True)
     if a.out:
         json.dump({"n": a.n, "launches": a.launches, "rounds": a.rounds, "results": res}, open(a.out, "w"), indent=1)
