@@ -62,7 +62,9 @@ class DoneGather:
         self.group = group
         self.world = dist.get_world_size(group)
         self.local = [torch.zeros(shard_shape, dtype=dtype, device=device) for _ in range(2)]
-        self.gathered = [torch.zeros((self.world,) + tuple(shard_shape), dtype=dtype, device=device) for _ in range(2)]
+        # flat concatenation: the one output shape both RCCL and gloo accept for all_gather_into_tensor
+        self._flat = [torch.zeros(self.world * self.local[0].numel(), dtype=dtype, device=device) for _ in range(2)]
+        self.gathered = [f.view((self.world,) + tuple(shard_shape)) for f in self._flat]
         self.pending: List[Optional[object]] = [None, None]
 
     def slot(self, t: int) -> torch.Tensor:
@@ -74,7 +76,7 @@ class DoneGather:
 
     def launch(self, t: int) -> None:
         k = t & 1
-        self.pending[k] = self._dist.all_gather_into_tensor(self.gathered[k], self.local[k], group=self.group,
+        self.pending[k] = self._dist.all_gather_into_tensor(self._flat[k], self.local[k].view(-1), group=self.group,
                                                             async_op=True)
 
     def result(self, t: int) -> torch.Tensor:

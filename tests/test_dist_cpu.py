@@ -1,0 +1,95 @@
+"""Multi-GPU host logic on CPU: world_size-2 gloo runs of the sharding + done-mask all-gather used by
+bench.py --gpus N (on the GPU box the same code runs over RCCL).  The per-shard done masks come from
+the oracle (checker), so no GPU and no product compute call is involved."""
+import os
+import socket
+
+import numpy as np
+import pytest
+import torch
+import torch.distributed as dist
+import torch.multiprocessing as mp
+
+from fpyv_amd import load_params, sticks
+from fpyv_amd.dist import DoneGather, pack_done_bits, shard_range, shard_sizes, unpack_done_bits
+
+
+def test_shard_ranges_cover_and_are_contiguous():
+    for n, w in [(8, 8), (10, 4), (1 << 23, 8), (7, 3), (5, 8)]:
+        lo_prev = 0
+        for r in range(w):
+            lo, hi = shard_range(n, w, r)
+            assert lo == lo_prev and hi >= lo
+            lo_prev = hi
+        assert lo_prev == n and sum(shard_sizes(n, w)) == n
+    assert shard_range(1 << 23, 8, 3) == (3 << 20, 4 << 20)
+    with pytest.raises(ValueError):
+        shard_range(8, 2, 2)
+
+
+def test_done_bit_packing_roundtrip():
+    rng = np.random.default_rng(0)
+    for n in (1, 63, 64, 65, 1000, 4096):
+        d = torch.from_numpy(rng.integers(0, 2, n).astype(np.uint8))
+        bits = pack_done_bits(d)
+        assert bits.dtype == torch.int64 and bits.numel() == (n + 63) // 64
+        assert torch.equal(unpack_done_bits(bits, n), d)
+        ref = np.zeros((n + 63) // 64, dtype=np.uint64)     # same layout as the kernel's wave ballot
+        for i in np.flatnonzero(d.numpy()):
+            ref[i // 64] |= np.uint64(1) << np.uint64(i % 64)
+        assert np.array_equal(bits.numpy().view(np.uint64), ref)
+
+
+def _free_port():
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        return s.getsockname()[1]
+
+
+def _worker(rank, world, port, n_total, steps, out_dir):
+    os.environ["MASTER_ADDR"], os.environ["MASTER_PORT"] = "127.0.0.1", str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        from oracle import oracle
+        p = load_params(fps=1000).replace(init_position=np.array([0.0, 0.0, 0.2]))
+        lo, hi = shard_range(n_total, world, rank)
+        n = hi - lo
+        # global-id keyed sticks: drone i sees the same stream whatever shard it lands in
+        acts = sticks.ema_noise(steps, range(lo, hi), seed=3).astype(np.float64)
+        acts[..., 3] -= 0.9                                   # low throttle: many drones reach the ground
+        st = oracle.drone_initial_state(n, p.init_position, p.init_velocity, [0, 0, 0])
+        g = DoneGather(((n + 63) // 64,), torch.int64, "cpu")
+        seen = []
+        for t in range(steps):
+            _, _, done = oracle.drone_run(p, st, acts[t:t + 1])
+            g.slot(t).copy_(pack_done_bits(torch.from_numpy(done)))
+            g.launch(t)
+            if t >= 1:
+                seen.append(g.result(t - 1).clone())
+        seen.append(g.result(steps - 1).clone())
+        g.drain()
+        np.save(os.path.join(out_dir, f"gathered_{rank}.npy"), torch.stack(seen).numpy())
+    finally:
+        dist.destroy_process_group()
+
+
+def test_world2_gloo_done_allgather_matches_single_process(tmp_path):
+    from oracle import oracle
+    world, n_total, steps = 2, 256, 260
+    mp.spawn(_worker, args=(world, _free_port(), n_total, steps, str(tmp_path)), nprocs=world, join=True)
+    g0 = np.load(tmp_path / "gathered_0.npy")
+    g1 = np.load(tmp_path / "gathered_1.npy")
+    assert np.array_equal(g0, g1), "every rank must see the same global mask"
+    # single-process reference over all drones
+    p = load_params(fps=1000).replace(init_position=np.array([0.0, 0.0, 0.2]))
+    acts = sticks.ema_noise(steps, range(n_total), seed=3).astype(np.float64)
+    acts[..., 3] -= 0.9
+    st = oracle.drone_initial_state(n_total, p.init_position, p.init_velocity, [0, 0, 0])
+    any_done = False
+    for t in range(steps):
+        _, _, done = oracle.drone_run(p, st, acts[t:t + 1])
+        any_done |= bool(done.any())
+        got = np.concatenate([unpack_done_bits(torch.from_numpy(g0[t, r]), n_total // world).numpy()
+                              for r in range(world)])
+        assert np.array_equal(got, done), f"step {t}: gathered mask != concatenation of shard masks"
+    assert any_done, "the scenario must actually produce done flags"
