@@ -77,6 +77,8 @@ def main():
                     help="rollout: K launches from one C call; step: one Python env.step() per launch")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-gather", action="store_true", help="skip the done-mask all-gather (N > 1)")
+    ap.add_argument("--force-dist", action="store_true",
+                    help="rehearsal: run the RCCL process group + all-gather path even with one rank")
     args = ap.parse_args()
 
     import torch
@@ -94,12 +96,15 @@ def main():
         raise SystemExit("bench.py needs a GPU: the stepper has no CPU path")
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
-    if world > 1:
+    multi = world > 1 or args.force_dist
+    if multi:
+        if "MASTER_ADDR" not in os.environ:
+            os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT="29517", RANK="0", WORLD_SIZE="1")
         dist.init_process_group(backend="nccl", device_id=dev)
 
     n = args.drones_per_gpu
     params = load_params(fps=1000)                      # dt = 1 ms
-    env = DroneBatch(params, n, device=dev, auto_reset=False, with_accel=False, with_done_bits=world > 1)
+    env = DroneBatch(params, n, device=dev, auto_reset=False, with_accel=False, with_done_bits=multi)
     if args.dpl:
         env.set_tuning(args.dpl)
     env.reset()
@@ -110,7 +115,7 @@ def main():
     actions = sticks.ema_noise_device(ring, n, dev, seed=1234 + rank)
 
     gather = None
-    if world > 1 and not args.no_gather:
+    if multi and not args.no_gather:
         gather = DoneGather((env.done_bits.numel(),), torch.int64, dev)
 
     def run(k, t_base):
@@ -132,7 +137,7 @@ def main():
 
     def fence():
         torch.cuda.synchronize()
-        if world > 1:
+        if multi:
             dist.barrier()
             torch.cuda.synchronize()
 
@@ -157,7 +162,7 @@ def main():
     elapsed = time.perf_counter() - t0
     dev_ms = ev0.elapsed_time(ev1)
 
-    if world > 1:
+    if multi:
         t = torch.tensor([elapsed], dtype=torch.float64, device=dev)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = float(t.item())
@@ -194,7 +199,7 @@ def main():
         if not args.no_cpu_baseline and world == 1:
             out["cpu_baseline"] = cpu_baseline(params)
         print(json.dumps(out), flush=True)
-    if world > 1:
+    if multi:
         dist.barrier()
         dist.destroy_process_group()
 

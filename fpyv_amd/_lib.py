@@ -19,13 +19,16 @@ FPV_OK = 0
 FPV_MODE_DRONE, FPV_MODE_RACER = 0, 1
 FPV_DRONE_ROWS, FPV_RACER_ROWS = 14, 20
 FPV_FLAG_AUTO_RESET = 1
+FPV_FLAG_GROUND = 2
+FPV_FLAG_FP16_STATE = 4
+FPV_HALF_ROWS = 11
 
 # state rows (fpv_abi.h)
 PX, PY, PZ, VX, VY, VZ, QW, QX, QY, QZ, RX, RY, RZ, THRUST = range(14)
 R_OMEGA, R_IERR, R_LERR, R_FIRST = 10, 13, 16, 19
 
 # every symbol include/fpv_abi.h declares
-EXPORTS = ("fpv_abi_version", "fpv_state_rows", "fpv_algorithmic_bytes", "fpv_create", "fpv_destroy",
+EXPORTS = ("fpv_abi_version", "fpv_state_rows", "fpv_algorithmic_bytes", "fpv_handle_algorithmic_bytes", "fpv_create", "fpv_destroy",
            "fpv_reset", "fpv_step", "fpv_rollout", "fpv_set_params", "fpv_set_tuning", "fpv_recommended_ld",
            "fpv_diag_stream_copy", "fpv_last_error",
            "fpv_error_name")
@@ -44,6 +47,7 @@ class FpvParams(C.Structure):
         ("ceiling", C.c_double), ("goal", C.c_double * 3),
         ("racer_mass", C.c_double), ("racer_inertia", C.c_double * 3), ("racer_pid", (C.c_double * 3) * 3),
         ("racer_velocity_damping", C.c_double),
+        ("motor_radius", C.c_double), ("ground_spring", C.c_double), ("ground_damping", C.c_double),
     ]
 
 
@@ -52,16 +56,17 @@ class FpvBuffers(C.Structure):
         ("state", C.c_void_p), ("ld", C.c_int64), ("action", C.c_void_p), ("reward", C.c_void_p),
         ("done", C.c_void_p), ("done_bits", C.c_void_p), ("accel", C.c_void_p), ("ep_return", C.c_void_p),
         ("ep_length", C.c_void_p), ("last_return", C.c_void_p), ("last_length", C.c_void_p),
-        ("wind", C.c_float * 3), ("_pad", C.c_uint32),
+        ("wind", C.c_float * 3), ("rounding_seed", C.c_uint32), ("state_h", C.c_void_p),
     ]
 
 
-def pack_params(p, auto_reset: bool = False) -> FpvParams:
+def pack_params(p, auto_reset: bool = False, fp16_state: bool = False) -> FpvParams:
     """DroneParams -> fpv_params_t."""
     s = FpvParams()
     s.struct_size = C.sizeof(FpvParams)
     s.mode = int(p.mode)
-    s.flags = FPV_FLAG_AUTO_RESET if auto_reset else 0
+    s.flags = ((FPV_FLAG_AUTO_RESET if auto_reset else 0) | (FPV_FLAG_GROUND if getattr(p, "ground", False) else 0)
+               | (FPV_FLAG_FP16_STATE if fp16_state else 0))
     s.racer_omega_dt = int(bool(p.racer_omega_dt))
     s.dt, s.gravity, s.mass, s.max_rates = float(p.dt), float(p.gravity), float(p.mass), float(p.max_rates)
     s.rates_transition_rate = float(p.rates_transition_rate)
@@ -83,6 +88,7 @@ def pack_params(p, auto_reset: bool = False) -> FpvParams:
         for j in range(3):
             s.racer_pid[i][j] = float(p.racer_pid[i][j])
     s.racer_velocity_damping = float(p.racer_velocity_damping)
+    s.motor_radius, s.ground_spring, s.ground_damping = float(p.motor_radius), float(p.ground_spring), float(p.ground_damping)
     return s
 
 
@@ -111,6 +117,7 @@ def lib() -> C.CDLL:
     L.fpv_abi_version.restype = C.c_int
     L.fpv_state_rows.argtypes = [C.c_int]
     L.fpv_algorithmic_bytes.argtypes = [C.c_int]
+    L.fpv_handle_algorithmic_bytes.argtypes = [vp]
     L.fpv_create.argtypes = [pp, i64, C.c_int, C.POINTER(vp)]
     L.fpv_destroy.argtypes = [vp]
     L.fpv_destroy.restype = None

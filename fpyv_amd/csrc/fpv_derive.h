@@ -22,6 +22,7 @@ static inline int fpv_derive_constants(const fpv_params_t* P, FpvK* K, bool* big
     *why = "";
     if (P->struct_size != sizeof(fpv_params_t)) { *why = "fpv_params_t.struct_size does not match this library"; return FPV_EINVAL; }
     if (P->mode != FPV_MODE_DRONE && P->mode != FPV_MODE_RACER) { *why = "unknown mode"; return FPV_EINVAL; }
+    if ((P->flags & FPV_FLAG_FP16_STATE) && P->mode != FPV_MODE_DRONE) { *why = "FPV_FLAG_FP16_STATE is a drone-mode layout"; return FPV_EINVAL; }
     if (!(P->dt > 0) || !isfinite(P->dt)) { *why = "dt must be positive and finite"; return FPV_EPARAM; }
     if (!(P->mass > 0)) { *why = "mass must be positive"; return FPV_EPARAM; }
     if (!(P->max_rates >= 0) || !isfinite(P->max_rates)) { *why = "max_rates must be finite and >= 0"; return FPV_EPARAM; }
@@ -65,6 +66,9 @@ static inline int fpv_derive_constants(const fpv_params_t* P, FpvK* K, bool* big
         K->r_dt_over_I[i] = (float)(P->dt / (P->racer_inertia[i] > 0 ? P->racer_inertia[i] : 1.0));
         for (int j = 0; j < 3; ++j) K->r_pid[i][j] = (float)P->racer_pid[i][j];
     }
+    K->motor_radius = (float)P->motor_radius;
+    K->ground_k_m = (float)(P->ground_spring / P->mass);
+    K->ground_c_m = (float)(P->ground_damping / P->mass);
     K->flags = P->flags;
     // |rates| <= max_rates always (clip + convex low-pass from 0), so the largest half-angle of one
     // step is known here; beyond pi/4 the short polynomial is no longer exact to fp32.

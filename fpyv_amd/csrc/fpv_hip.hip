@@ -45,6 +45,8 @@ struct FpvBufD {
     float* last_return;
     int32_t* last_length;
     float wx, wy, wz;
+    uint16_t* state_h;     // FPV_FLAG_FP16_STATE: [11][ld] binary16 rows (v, q, rates, thrust)
+    uint32_t seed;         // stochastic-rounding seed of this launch
 };
 
 __device__ __forceinline__ void ld_drone(const float* __restrict__ st, int64_t ld, int64_t i, FpvDroneState& s)
@@ -77,12 +79,18 @@ __device__ __forceinline__ float4 ld_action(const float4* __restrict__ a, int64_
 
 // Episode bookkeeping + done outputs shared by both modes.  `done` is wave-divergent data;
 // all pointer tests are wave-uniform scalar branches.
+__device__ __forceinline__ void emit_lane_outputs(const FpvBufD& B, int64_t i, float reward, bool done);
+
 __device__ __forceinline__ void emit_outputs(const FpvBufD& B, int64_t i, bool live, float reward, bool done)
 {
     // done_bits: one ballot per 64 consecutive drones; i - lane is a multiple of 64 by construction
     const unsigned long long mask = __ballot(live && done);
     if (B.done_bits && (threadIdx.x & 63) == 0 && live) B.done_bits[i >> 6] = mask;
-    if (!live) return;
+    if (live) emit_lane_outputs(B, i, reward, done);
+}
+
+__device__ __forceinline__ void emit_lane_outputs(const FpvBufD& B, int64_t i, float reward, bool done)
+{
     if (B.reward) __builtin_nontemporal_store(reward, &B.reward[i]);
     if (B.done) __builtin_nontemporal_store((uint8_t)(done ? 1 : 0), &B.done[i]);
     if (B.ep_return) {
@@ -128,6 +136,115 @@ __global__ __launch_bounds__(BS) void fpv_drone_step_kernel(const FpvK K, const 
             st_drone(B.state, B.ld, i, s[j]);
         }
         emit_outputs(B, i, live[j], o.reward, o.done);
+    }
+}
+
+// fp16-storage variant (BASELINE config 4): position rows fp32, the other 11 rows binary16.
+// 89 algorithmic bytes per env-step instead of 133; arithmetic and the lane function are unchanged.
+__device__ __forceinline__ void ld_drone_h(const FpvBufD& B, int64_t i, FpvDroneState& s)
+{
+    s.px = B.state[0 * B.ld + i]; s.py = B.state[1 * B.ld + i]; s.pz = B.state[2 * B.ld + i];
+    FpvHalfState h;
+    const uint16_t* __restrict__ sh = B.state_h;
+    h.v[0] = sh[0 * B.ld + i]; h.v[1] = sh[1 * B.ld + i]; h.v[2] = sh[2 * B.ld + i];
+    h.q[0] = sh[3 * B.ld + i]; h.q[1] = sh[4 * B.ld + i]; h.q[2] = sh[5 * B.ld + i]; h.q[3] = sh[6 * B.ld + i];
+    h.r[0] = sh[7 * B.ld + i]; h.r[1] = sh[8 * B.ld + i]; h.r[2] = sh[9 * B.ld + i];
+    h.t = sh[10 * B.ld + i];
+    fpv_unpack_half(h, s);
+}
+
+__device__ __forceinline__ void st_drone_h(const FpvBufD& B, int64_t i, const FpvDroneState& s)
+{
+    B.state[0 * B.ld + i] = s.px; B.state[1 * B.ld + i] = s.py; B.state[2 * B.ld + i] = s.pz;
+    FpvHalfState h;
+    fpv_pack_half(s, B.seed, (uint32_t)i, h);
+    uint16_t* __restrict__ sh = B.state_h;
+    sh[0 * B.ld + i] = h.v[0]; sh[1 * B.ld + i] = h.v[1]; sh[2 * B.ld + i] = h.v[2];
+    sh[3 * B.ld + i] = h.q[0]; sh[4 * B.ld + i] = h.q[1]; sh[5 * B.ld + i] = h.q[2]; sh[6 * B.ld + i] = h.q[3];
+    sh[7 * B.ld + i] = h.r[0]; sh[8 * B.ld + i] = h.r[1]; sh[9 * B.ld + i] = h.r[2];
+    sh[10 * B.ld + i] = h.t;
+}
+
+// V consecutive drones per lane (V = 2 or 4): every fp16 row access is then one dword / qword per
+// lane (two-byte accesses waste the memory pipeline: the one-drone-per-lane form of this kernel ran
+// SLOWER than the fp32 kernel despite moving 2/3 of the bytes), position rows are float2/float4.
+// Lanes past the end re-store what they loaded, so padding columns keep their values.
+template <int V> struct FpvVec;
+template <> struct FpvVec<2> { typedef uint32_t H; typedef float __attribute__((ext_vector_type(2))) F; };
+template <> struct FpvVec<4> { typedef uint2 H; typedef float __attribute__((ext_vector_type(4))) F; };
+
+template <int V, int BS, bool BIG>
+__global__ __launch_bounds__(BS) void fpv_drone_step_h_kernel(const FpvK K, const FpvBufD B, const int64_t n)
+{
+    typedef typename FpvVec<V>::H hv_t;
+    typedef typename FpvVec<V>::F fv_t;
+    const int64_t i0 = ((int64_t)blockIdx.x * BS + threadIdx.x) * V;
+    const bool any_live = i0 < n;
+    fv_t pr[3];
+    hv_t hr[FPV_HALF_ROWS];
+    float4 act[V];
+    if (any_live) {
+#pragma unroll
+        for (int j = 0; j < V; ++j)
+            act[j] = (i0 + j < n) ? ld_action(B.action, i0 + j) : make_float4(0.f, 0.f, 0.f, 0.f);
+#pragma unroll
+        for (int k = 0; k < 3; ++k) pr[k] = *reinterpret_cast<const fv_t*>(&B.state[(int64_t)k * B.ld + i0]);
+#pragma unroll
+        for (int k = 0; k < FPV_HALF_ROWS; ++k) hr[k] = *reinterpret_cast<const hv_t*>(&B.state_h[(int64_t)k * B.ld + i0]);
+    }
+    unsigned long long my_done = 0;
+    if (any_live) {
+        float* pf = reinterpret_cast<float*>(pr);
+        uint16_t* hh = reinterpret_cast<uint16_t*>(hr);
+#pragma unroll
+        for (int j = 0; j < V; ++j) {
+            const int64_t i = i0 + j;
+            if (i < n) {
+                FpvDroneState s;
+                FpvHalfState h;
+                s.px = pf[0 * V + j]; s.py = pf[1 * V + j]; s.pz = pf[2 * V + j];
+#pragma unroll
+                for (int k = 0; k < 3; ++k) h.v[k] = hh[(0 + k) * V + j];
+#pragma unroll
+                for (int k = 0; k < 4; ++k) h.q[k] = hh[(3 + k) * V + j];
+#pragma unroll
+                for (int k = 0; k < 3; ++k) h.r[k] = hh[(7 + k) * V + j];
+                h.t = hh[10 * V + j];
+                fpv_unpack_half(h, s);
+                const FpvStepOut o = fpv_drone_step_lane<BIG>(K, s, act[j].x, act[j].y, act[j].z, act[j].w, B.wx, B.wy, B.wz);
+                if (B.accel) {
+                    B.accel[0 * B.ld + i] = o.ax; B.accel[1 * B.ld + i] = o.ay; B.accel[2 * B.ld + i] = o.az;
+                }
+                if ((K.flags & FPV_FLAG_AUTO_RESET) && o.done) fpv_drone_reset_lane(K, s);
+                fpv_pack_half(s, B.seed, (uint32_t)i, h);
+                pf[0 * V + j] = s.px; pf[1 * V + j] = s.py; pf[2 * V + j] = s.pz;
+#pragma unroll
+                for (int k = 0; k < 3; ++k) hh[(0 + k) * V + j] = h.v[k];
+#pragma unroll
+                for (int k = 0; k < 4; ++k) hh[(3 + k) * V + j] = h.q[k];
+#pragma unroll
+                for (int k = 0; k < 3; ++k) hh[(7 + k) * V + j] = h.r[k];
+                hh[10 * V + j] = h.t;
+                emit_lane_outputs(B, i, o.reward, o.done);
+                my_done |= (unsigned long long)(o.done ? 1 : 0) << j;
+            }
+        }
+#pragma unroll
+        for (int k = 0; k < 3; ++k) *reinterpret_cast<fv_t*>(&B.state[(int64_t)k * B.ld + i0]) = pr[k];
+#pragma unroll
+        for (int k = 0; k < FPV_HALF_ROWS; ++k) *reinterpret_cast<hv_t*>(&B.state_h[(int64_t)k * B.ld + i0]) = hr[k];
+    }
+    if (B.done_bits) {
+        // lane l owns bits [V*l, V*l+V) of its wave's V consecutive mask words: OR-reduce the 64/V lanes
+        // that share a word with xor-shuffles, the first lane of each group stores it
+        const int lane = threadIdx.x & 63;
+        unsigned long long w = my_done << ((V * lane) & 63);
+#pragma unroll
+        for (int off = 1; off < 64 / V; off <<= 1) {
+            const uint32_t lo = __shfl_xor((uint32_t)w, off), hi = __shfl_xor((uint32_t)(w >> 32), off);
+            w |= ((unsigned long long)hi << 32) | lo;
+        }
+        if ((lane % (64 / V)) == 0 && any_live) B.done_bits[i0 >> 6] = w;
     }
 }
 
@@ -204,7 +321,8 @@ __global__ __launch_bounds__(kBlock) void fpv_reset_kernel(const FpvK K, const F
             s.q.y = fmaf(cy * sp, cr, sy * cp * sr);
             s.q.z = fmaf(sy * cp, cr, -(cy * sp * sr));
         }
-        st_drone(B.state, B.ld, i, s);
+        if (K.flags & FPV_FLAG_FP16_STATE) st_drone_h(B, i, s);
+        else st_drone(B.state, B.ld, i, s);
     } else {
         FpvRacerState s;
         fpv_racer_reset_lane(s);
@@ -248,12 +366,13 @@ struct fpv_env {
     int mode;
     int dpl;        // drones per lane (1, 2 or 4)
     int block;      // threads per workgroup of the drone step kernel (128 or 256)
+    uint32_t launches;   // counts step launches; feeds the stochastic-rounding seed
     bool big_angle;
 };
 
 namespace {
 
-int check_buffers(const fpv_env* h, const fpv_buffers_t* b, bool need_action)
+int check_buffers(const fpv_env* h, const fpv_buffers_t* b, bool need_action)  // NOLINT
 {
     if (!h) return fail(FPV_EINVAL, "null handle");
     if (!b) return fail(FPV_EINVAL, "null fpv_buffers_t");
@@ -264,6 +383,10 @@ int check_buffers(const fpv_env* h, const fpv_buffers_t* b, bool need_action)
     if (((uintptr_t)b->state & 15) || ((uintptr_t)b->action & 15))
         return fail(FPV_EALIGN, "state and action must be 16-byte aligned");
     if ((uintptr_t)b->done_bits & 7) return fail(FPV_EALIGN, "done_bits must be 8-byte aligned");
+    if (h->K.flags & FPV_FLAG_FP16_STATE) {
+        if (!b->state_h) return fail(FPV_EINVAL, "FPV_FLAG_FP16_STATE needs fpv_buffers_t.state_h");
+        if ((uintptr_t)b->state_h & 7) return fail(FPV_EALIGN, "state_h must be 8-byte aligned");
+    }
     if ((b->ep_return == nullptr) != (b->ep_length == nullptr))
         return fail(FPV_EINVAL, "ep_return and ep_length must be given together");
     if ((b->last_return || b->last_length) && !b->ep_return)
@@ -279,6 +402,7 @@ FpvBufD to_device_view(const fpv_buffers_t* b)
     d.accel = b->accel; d.ep_return = b->ep_return; d.ep_length = b->ep_length;
     d.last_return = b->last_return; d.last_length = b->last_length;
     d.wx = b->wind[0]; d.wy = b->wind[1]; d.wz = b->wind[2];
+    d.state_h = b->state_h; d.seed = b->rounding_seed;
     return d;
 }
 
@@ -315,9 +439,24 @@ void launch_drone_bs(const fpv_env* h, const FpvBufD& d, hipStream_t s)
     }
 }
 
-int launch_step(const fpv_env* h, const FpvBufD& d, hipStream_t s)
+int launch_step(fpv_env* h, const FpvBufD& d_in, hipStream_t s)
 {
-    if (h->mode == FPV_MODE_DRONE) {
+    FpvBufD d = d_in;
+    d.seed = d_in.seed + h->launches++;
+    if (h->mode == FPV_MODE_DRONE && (h->K.flags & FPV_FLAG_FP16_STATE)) {
+        const int v = h->dpl == 4 ? 4 : 2;
+        const int64_t per_block = (int64_t)h->block * v;
+        const dim3 grid((unsigned)((h->n + per_block - 1) / per_block));
+#define FPV_LAUNCH_H(V, BS, BIG) hipLaunchKernelGGL((fpv_drone_step_h_kernel<V, BS, BIG>), grid, dim3(BS), 0, s, h->K, d, h->n)
+        if (v == 4) {
+            if (h->block == 256) { if (h->big_angle) FPV_LAUNCH_H(4, 256, true); else FPV_LAUNCH_H(4, 256, false); }
+            else { if (h->big_angle) FPV_LAUNCH_H(4, 128, true); else FPV_LAUNCH_H(4, 128, false); }
+        } else {
+            if (h->block == 256) { if (h->big_angle) FPV_LAUNCH_H(2, 256, true); else FPV_LAUNCH_H(2, 256, false); }
+            else { if (h->big_angle) FPV_LAUNCH_H(2, 128, true); else FPV_LAUNCH_H(2, 128, false); }
+        }
+#undef FPV_LAUNCH_H
+    } else if (h->mode == FPV_MODE_DRONE) {
         if (h->block == 256) launch_drone_bs<256>(h, d, s);
         else launch_drone_bs<128>(h, d, s);
     } else {
@@ -349,6 +488,14 @@ int fpv_algorithmic_bytes(int mode)
     return rows * 4 * 2 + 16 + 4 + 1;   // state read + write, action read, reward + done write
 }
 
+int fpv_handle_algorithmic_bytes(fpv_handle_t h)
+{
+    if (!h) return fail(FPV_EINVAL, "null handle");
+    if (h->mode == FPV_MODE_DRONE && (h->K.flags & FPV_FLAG_FP16_STATE))
+        return (3 * 4 + FPV_HALF_ROWS * 2) * 2 + 16 + 4 + 1;   // 89
+    return fpv_algorithmic_bytes(h->mode);
+}
+
 int fpv_create(const fpv_params_t* params, int64_t n, int device, fpv_handle_t* out)
 {
     if (!params || !out) return fail(FPV_EINVAL, "null argument");
@@ -368,7 +515,7 @@ int fpv_create(const fpv_params_t* params, int64_t n, int device, fpv_handle_t* 
     fpv_env* h = new (std::nothrow) fpv_env;
     if (!h) return fail(FPV_EINVAL, "out of host memory");
     h->K = K; h->P = *params; h->n = n; h->device = device; h->mode = (int)params->mode;
-    h->dpl = 1; h->block = 128; h->big_angle = big;
+    h->dpl = 1; h->block = 128; h->big_angle = big; h->launches = 0;
     *out = h;
     return FPV_OK;
 }
@@ -379,6 +526,8 @@ int fpv_set_params(fpv_handle_t h, const fpv_params_t* params)
 {
     if (!h || !params) return fail(FPV_EINVAL, "null argument");
     if ((int)params->mode != h->mode) return fail(FPV_EINVAL, "mode cannot change on a live handle (state layout differs)");
+    if ((params->flags ^ h->P.flags) & FPV_FLAG_FP16_STATE)
+        return fail(FPV_EINVAL, "FPV_FLAG_FP16_STATE cannot change on a live handle (state layout differs)");
     FpvK K;
     bool big = false;
     const char* why = "";

@@ -28,6 +28,9 @@
 #define FPV_HD static inline
 #endif
 
+#define FPV_MATH_FLAG_AUTO_RESET 1u   // = FPV_FLAG_AUTO_RESET (include/fpv_abi.h)
+#define FPV_MATH_FLAG_GROUND 2u       // = FPV_FLAG_GROUND
+
 // Uniform per-launch constants (kernel argument -> SGPRs).  Derived in double on the host.
 struct FpvK {
     float dt;
@@ -47,6 +50,7 @@ struct FpvK {
     float r_dt, r_inv_dt, r_inv_mass, r_damp, r_ang_k;
     float r_dt_over_I[3];
     float r_pid[3][3];
+    float motor_radius, ground_k_m, ground_c_m;   // contact distance; spring and damping already divided by m
     uint32_t flags;
 };
 
@@ -124,6 +128,109 @@ struct FpvDroneState {
     float thrust;       // prev_thrust, N
 };
 
+// ------------------------------------------------------------------------------------------------
+// fp16 storage (BASELINE config 4: "fp16 state / fp32 integrator"): v, q, prev_rates, prev_thrust
+// live in HBM as IEEE binary16, position stays fp32, all arithmetic stays fp32.  Conversions are
+// integer bit manipulation so the host lane model and the kernel agree bit for bit.
+//   * low-pass states (rates, thrust) are rounded to nearest-even: their error does not accumulate;
+//   * integrator states (v, q) are rounded STOCHASTICALLY: at dt = 1 ms one step's increment is
+//     often below half an fp16 ulp (0.03 m/s against ulp 0.016 at 20 m/s; 3e-4 of quaternion against
+//     ulp 5e-4), and round-to-nearest would simply stall them.  Unbiased rounding keeps the
+//     expected trajectory and turns the stall into a random walk of ~ulp*sqrt(steps).
+// ------------------------------------------------------------------------------------------------
+FPV_HD uint32_t fpv_f32_bits(float x) { uint32_t u; memcpy(&u, &x, 4); return u; }
+FPV_HD float fpv_bits_f32(uint32_t u) { float x; memcpy(&x, &u, 4); return x; }
+
+// binary16 <-> fp32.  On the device these are the hardware conversions (v_cvt_f32_f16 /
+// v_cvt_f16_f32, round-to-nearest-even, subnormals honoured); the host lane model does the same
+// arithmetic with integer bit manipulation (checked against numpy.float16 in the tests).
+FPV_HD float fpv_f16_to_f32(uint16_t h)
+{
+#if defined(__HIP_DEVICE_COMPILE__)
+    _Float16 f;
+    memcpy(&f, &h, 2);
+    return (float)f;
+#else
+    const uint32_t sign = ((uint32_t)h & 0x8000u) << 16, em = h & 0x7fffu;
+    if (em >= 0x7c00u) return fpv_bits_f32(sign | 0x7f800000u | ((em & 0x3ffu) << 13));   // inf / nan
+    if (em < 0x0400u) {                                                                    // subnormal: em * 2^-24
+        const float m = (float)em * 5.9604644775390625e-08f;
+        return fpv_bits_f32(sign | fpv_f32_bits(m));
+    }
+    return fpv_bits_f32(sign | ((em << 13) + 0x38000000u));
+#endif
+}
+
+FPV_HD uint16_t fpv_f32_to_f16_rn(float x)
+{
+#if defined(__HIP_DEVICE_COMPILE__)
+    const _Float16 f = (_Float16)x;
+    uint16_t h;
+    memcpy(&h, &f, 2);
+    return h;
+#else
+    const uint32_t b = fpv_f32_bits(x), sign = (b >> 16) & 0x8000u;
+    uint32_t a = b & 0x7fffffffu;
+    if (a > 0x7f800000u) return (uint16_t)(sign | 0x7e00u);                                // nan
+    if (a >= 0x477ff000u) return (uint16_t)(sign | 0x7c00u);                               // >= 65520 -> inf
+    if (a < 0x38800000u) {                                                                 // below the smallest normal half
+        const float t = fpv_bits_f32(a) * 16777216.0f;                                     // value / 2^-24, exact
+        uint32_t q = (uint32_t)(t + 0.5f);
+        if ((t + 0.5f) == (float)q && (q & 1u)) q -= 1u;                                   // ties to even
+        return (uint16_t)(sign | q);
+    }
+    a += 0xfffu + ((a >> 13) & 1u);
+    return (uint16_t)(sign | ((a - 0x38000000u) >> 13));
+#endif
+}
+
+// Stochastic rounding: in the normal binary16 range add 13 uniform random bits below the kept
+// mantissa and truncate (unbiased: E[result] = x); the result is exactly representable, so the
+// final conversion is exact.  Below 2^-14 (irrelevant for the dynamics) plain nearest-even.
+FPV_HD uint16_t fpv_f32_to_f16_sr(float x, uint32_t rnd13)
+{
+    uint32_t b = fpv_f32_bits(x);
+    const uint32_t a = b & 0x7fffffffu;
+    if (a >= 0x38800000u && a < 0x7f800000u) b = (b + rnd13) & 0xffffe000u;
+    return fpv_f32_to_f16_rn(fpv_bits_f32(b));
+}
+
+// three 32-bit hashes of (seed, drone) give the 7 x 13 random bits one step needs
+FPV_HD uint32_t fpv_mix32(uint32_t x)
+{
+    x ^= x >> 16; x *= 0x7feb352du; x ^= x >> 15; x *= 0x846ca68bu; x ^= x >> 16;
+    return x;
+}
+
+struct FpvHalfState { uint16_t v[3], q[4], r[3], t; };   // the 11 fp16 rows of one drone
+
+FPV_HD void fpv_unpack_half(const FpvHalfState& h, FpvDroneState& s)
+{
+    s.vx = fpv_f16_to_f32(h.v[0]); s.vy = fpv_f16_to_f32(h.v[1]); s.vz = fpv_f16_to_f32(h.v[2]);
+    s.q.w = fpv_f16_to_f32(h.q[0]); s.q.x = fpv_f16_to_f32(h.q[1]); s.q.y = fpv_f16_to_f32(h.q[2]); s.q.z = fpv_f16_to_f32(h.q[3]);
+    s.rx = fpv_f16_to_f32(h.r[0]); s.ry = fpv_f16_to_f32(h.r[1]); s.rz = fpv_f16_to_f32(h.r[2]);
+    s.thrust = fpv_f16_to_f32(h.t);
+    // a stored quaternion is unit only to ~1e-3; the fp32 integrator wants |q| = 1.
+    // 1/sqrt(1+e) = 1 - e/2 + 3e^2/8 - 5e^3/16 (+4e-12 at |e| = 2e-3): FMAs only, no sqrt/divide
+    const float e = fmaf(s.q.w, s.q.w, fmaf(s.q.x, s.q.x, fmaf(s.q.y, s.q.y, fmaf(s.q.z, s.q.z, -1.0f))));
+    const float k = fmaf(fmaf(fmaf(-0.3125f, e, 0.375f), e, -0.5f), e, 0.0f);
+    s.q.w = fmaf(k, s.q.w, s.q.w); s.q.x = fmaf(k, s.q.x, s.q.x); s.q.y = fmaf(k, s.q.y, s.q.y); s.q.z = fmaf(k, s.q.z, s.q.z);
+}
+
+FPV_HD void fpv_pack_half(const FpvDroneState& s, uint32_t seed, uint32_t drone, FpvHalfState& h)
+{
+    const uint32_t r0 = fpv_mix32(seed * 0x9e3779b9u + drone), r1 = fpv_mix32(r0 + 0x85ebca6bu), r2 = fpv_mix32(r1 + 0xc2b2ae35u);
+    h.v[0] = fpv_f32_to_f16_sr(s.vx, r0 & 0x1fffu);
+    h.v[1] = fpv_f32_to_f16_sr(s.vy, (r0 >> 13) & 0x1fffu);
+    h.v[2] = fpv_f32_to_f16_sr(s.vz, r1 & 0x1fffu);
+    h.q[0] = fpv_f32_to_f16_sr(s.q.w, (r1 >> 13) & 0x1fffu);
+    h.q[1] = fpv_f32_to_f16_sr(s.q.x, r2 & 0x1fffu);
+    h.q[2] = fpv_f32_to_f16_sr(s.q.y, (r2 >> 13) & 0x1fffu);
+    h.q[3] = fpv_f32_to_f16_sr(s.q.z, ((r0 >> 26) | ((r1 >> 26) << 6) | ((r2 >> 26) << 12)) & 0x1fffu);
+    h.r[0] = fpv_f32_to_f16_rn(s.rx); h.r[1] = fpv_f32_to_f16_rn(s.ry); h.r[2] = fpv_f32_to_f16_rn(s.rz);
+    h.t = fpv_f32_to_f16_rn(s.thrust);
+}
+
 struct FpvStepOut {
     float ax, ay, az;   // R_new @ acc
     float reward;
@@ -160,13 +267,22 @@ FPV_HD FpvStepOut fpv_drone_step_lane(const FpvK& K, FpvDroneState& s, float a0,
     const float tm = s.thrust * K.inv_mass;
     const float accx = fmaf(R.r00, fx, fmaf(R.r01, fy, fmaf(R.r02, fz, tm * R.r02)));
     const float accy = fmaf(R.r10, fx, fmaf(R.r11, fy, fmaf(R.r12, fz, tm * R.r12)));
-    const float accz = fmaf(R.r20, fx, fmaf(R.r21, fy, fmaf(R.r22, fz, fmaf(tm, R.r22, -K.g))));
+    float accz = fmaf(R.r20, fx, fmaf(R.r21, fy, fmaf(R.r22, fz, fmaf(tm, R.r22, -K.g))));
 
     // ground flag: any motor below z = 0 on the PRE-update pose             components.py:235-240
+    // ground contact (object_list = [Ground]): each motor closer than motor_radius to z = 0 adds a
+    // spring force along +z; if ANY motor is below the plane the reference reports a crash and
+    // returns before adding any force                                        components.py:198-214
     bool done = false;
+    float contact = 0.0f;
 #pragma unroll
-    for (int m = 0; m < 4; ++m)
-        done = done || (s.pz + fmaf(K.motor_x[m], R.r20, K.motor_y[m] * R.r21) < 0.0f);
+    for (int m = 0; m < 4; ++m) {
+        const float mz = s.pz + fmaf(K.motor_x[m], R.r20, K.motor_y[m] * R.r21);
+        done = done || (mz < 0.0f);
+        const float d = mz - K.motor_radius;
+        if (d < 0.0f) contact += fmaf(-K.ground_k_m, d, -K.ground_c_m * s.vz);   // kinematics.py:56-59, normal = +z
+    }
+    if ((K.flags & FPV_MATH_FLAG_GROUND) && !done) accz += contact;
 
     // (6) explicit Euler: p with the OLD v, then v                          kinematics.py:21-22
     s.px = fmaf(s.vx, K.dt, s.px); s.py = fmaf(s.vy, K.dt, s.py); s.pz = fmaf(s.vz, K.dt, s.pz);

@@ -35,7 +35,8 @@ class _Batch:
     """Owns the SoA state tensor and the C handle of one shard of drones on one GPU."""
 
     def __init__(self, params: DroneParams, num_envs: int, device: Any = "cuda:0", auto_reset: bool = False,
-                 track_episodes: bool = False, with_accel: bool = False, with_done_bits: bool = False):
+                 track_episodes: bool = False, with_accel: bool = False, with_done_bits: bool = False,
+                 fp16_state: bool = False, rounding_seed: int = 0):
         if num_envs <= 0:
             raise ValueError("num_envs must be positive")
         self.params = params
@@ -49,10 +50,18 @@ class _Batch:
         self.ld = int(self._L.fpv_recommended_ld(self.n))
         dev_index = self.device.index if self.device.index is not None else torch.cuda.current_device()
         self._handle = C.c_void_p()
-        self._cparams = _lib.pack_params(params, auto_reset=auto_reset)
+        self.fp16_state = bool(fp16_state)
+        self.rounding_seed = int(rounding_seed) & 0xFFFFFFFF
+        self._cparams = _lib.pack_params(params, auto_reset=auto_reset, fp16_state=self.fp16_state)
         _lib.check(self._L.fpv_create(C.byref(self._cparams), self.n, dev_index, C.byref(self._handle)))
         f32 = dict(dtype=torch.float32, device=self.device)
-        self.state = torch.zeros((self.rows, self.ld), **f32)
+        if self.fp16_state:
+            # BASELINE config 4: position rows fp32, the other 11 rows binary16 (89 B per env-step)
+            self.state = torch.zeros((3, self.ld), **f32)
+            self.state_h = torch.zeros((_lib.FPV_HALF_ROWS, self.ld), dtype=torch.float16, device=self.device)
+        else:
+            self.state = torch.zeros((self.rows, self.ld), **f32)
+            self.state_h = None
         self.reward = torch.zeros(self.n, **f32)
         self.done_u8 = torch.zeros(self.n, dtype=torch.uint8, device=self.device)
         self.accel = torch.zeros((3, self.ld), **f32) if with_accel else None
@@ -79,6 +88,22 @@ class _Batch:
         b.ep_return, b.ep_length = ptr(self.ep_return), ptr(self.ep_length)
         b.last_return, b.last_length = ptr(self.last_return), ptr(self.last_length)
         b.wind[0] = b.wind[1] = b.wind[2] = 0.0
+        b.state_h, b.rounding_seed = ptr(self.state_h), self.rounding_seed
+
+    def rows_f32(self, r0: int, r1: int) -> torch.Tensor:
+        """[num_envs, r1-r0] fp32 values of state rows r0..r1-1 (fpv_abi.h row numbering), whatever the
+        storage format; a zero-copy view for fp32 storage, a converted copy for fp16 rows."""
+        if not self.fp16_state:
+            return self.state[r0:r1, :self.n].t()
+        parts = []
+        if r0 < 3:
+            parts.append(self.state[r0:min(r1, 3), :self.n])
+        if r1 > 3:
+            parts.append(self.state_h[max(r0, 3) - 3:r1 - 3, :self.n].float())
+        return torch.cat(parts, dim=0).t()
+
+    def algorithmic_bytes(self) -> int:
+        return int(self._L.fpv_handle_algorithmic_bytes(self._handle))
 
     def _stream(self) -> int:
         return torch.cuda.current_stream(self.device).cuda_stream
@@ -105,7 +130,7 @@ class _Batch:
 
     def set_params(self, params: DroneParams, auto_reset: Optional[bool] = None) -> None:
         flags_auto = bool(self._cparams.flags & _lib.FPV_FLAG_AUTO_RESET) if auto_reset is None else auto_reset
-        cp = _lib.pack_params(params, auto_reset=flags_auto)
+        cp = _lib.pack_params(params, auto_reset=flags_auto, fp16_state=self.fp16_state)
         _lib.check(self._L.fpv_set_params(self._handle, C.byref(cp)))
         self.params, self._cparams = params, cp
 
@@ -182,16 +207,16 @@ class _Batch:
     @property
     def position(self) -> torch.Tensor:
         """[num_envs, 3] view of the state (Drone.position, components.py:171-173)."""
-        return self.state[_lib.PX:_lib.PZ + 1, :self.n].t()
+        return self.rows_f32(_lib.PX, _lib.PZ + 1)
 
     @property
     def velocity(self) -> torch.Tensor:
-        return self.state[_lib.VX:_lib.VZ + 1, :self.n].t()
+        return self.rows_f32(_lib.VX, _lib.VZ + 1)
 
     @property
     def quaternion(self) -> torch.Tensor:
         """[num_envs, 4] (w, x, y, z), body -> world."""
-        return self.state[_lib.QW:_lib.QZ + 1, :self.n].t()
+        return self.rows_f32(_lib.QW, _lib.QZ + 1)
 
     @property
     def rotation_matrix(self) -> torch.Tensor:
@@ -255,18 +280,18 @@ class DroneBatch(_Batch):
         if not return_imu:
             return None
         R = self.rotation_matrix
-        rates = self.state[_lib.RX:_lib.RZ + 1, :self.n].t()
+        rates = self.rows_f32(_lib.RX, _lib.RZ + 1)
         gyro = euler_zyx_matrix(rates)            # deg/s values used as radians, as the reference does (:247)
         acc = self.accel[:, :self.n].t() if self.accel is not None else None
         return R.transpose(-1, -2), gyro, acc
 
     @property
     def prev_rates(self) -> torch.Tensor:
-        return self.state[_lib.RX:_lib.RZ + 1, :self.n].t()
+        return self.rows_f32(_lib.RX, _lib.RZ + 1)
 
     @property
     def prev_thrust(self) -> torch.Tensor:
-        return self.state[_lib.THRUST, :self.n]
+        return self.rows_f32(_lib.THRUST, _lib.THRUST + 1)[:, 0]
 
 
 class RacerBatch(_Batch):
@@ -315,7 +340,7 @@ class FpvVecEnv:
 
     @property
     def obs(self) -> torch.Tensor:
-        return self.batch.state[:13, :self.num_envs].t()
+        return self.batch.rows_f32(0, 13)
 
     def reset(self, mask=None) -> torch.Tensor:
         self.batch._reset_raw(mask=mask)

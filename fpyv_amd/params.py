@@ -125,6 +125,11 @@ class DroneParams:
     racer_pid: np.ndarray = dataclasses.field(default_factory=lambda: np.zeros((3, 3)))
     racer_velocity_damping: float = 0.9
     racer_omega_dt: bool = False    # False = rotate by omega per step as the reference writes it
+    # ground plane in object_list (components.py:198-214, :121; Ground.calculate_distance = z, :674-677)
+    ground: bool = False
+    motor_radius: float = 0.1
+    ground_spring: float = 100.0
+    ground_damping: float = 0.0
 
     @property
     def init_quat(self) -> np.ndarray:
@@ -210,6 +215,10 @@ def params_from_dict(cfg: Dict[str, Any], yaml_dir: str = _DATA_DIR, mode: Any =
         racer_pid=np.asarray([pid["roll"], pid["pitch"], pid["yaw"]], dtype=np.float64),
         racer_velocity_damping=float(racer.get("velocity_damping", 0.9)),
         racer_omega_dt=bool(racer.get("omega_dt", False)),
+        ground=bool(st.get("ground", False)),
+        motor_radius=float(st.get("motor_radius", 0.1)),
+        ground_spring=float(st.get("ground_spring", 100.0)),
+        ground_damping=float(st.get("ground_damping", 0.0)),
     )
     # 5 % throttle floor / full throttle, components.py:139-142
     p.min_throttle_in_force = float(p.thrust_from_stick(-1 + 5 / 100 * 2))

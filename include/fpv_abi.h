@@ -59,7 +59,16 @@ enum {
     FPV_RACER_ROWS = 20
 };
 
-enum { FPV_FLAG_AUTO_RESET = 1u };       /* re-initialise a lane in-kernel when it reports done */
+enum {
+    FPV_FLAG_AUTO_RESET = 1u,   /* re-initialise a lane in-kernel when it reports done */
+    FPV_FLAG_GROUND = 2u,       /* ground plane z = 0 in object_list: per-motor spring contact,
+                                   Drone.handle_collisions with a Ground object (components.py:198-214) */
+    FPV_FLAG_FP16_STATE = 4u    /* drone mode only: v, q, prev_rates, prev_thrust stored as IEEE binary16 in
+                                   fpv_buffers_t.state_h[11][ld]; fpv_buffers_t.state holds only the 3 position
+                                   rows in fp32; arithmetic stays fp32 (BASELINE config 4) */
+};
+/* rows of state_h under FPV_FLAG_FP16_STATE: row (FPV_VX - 3) .. (FPV_THRUST - 3) */
+#define FPV_HALF_ROWS 11
 
 /* Host-side description of one drone type; doubles, narrowed to fp32 by fpv_create.
  * Field sources: components.py:92-100 (dt, gravity, mass, drag, areas), :120-125 (motor_xy),
@@ -90,6 +99,9 @@ typedef struct fpv_params {
     double racer_inertia[3];
     double racer_pid[3][3];           /* [axis][kP,kI,kD] */
     double racer_velocity_damping;
+    double motor_radius;              /* contact starts at distance < motor_radius (components.py:121), m */
+    double ground_spring;             /* N/m   (handle_collisions default 100, components.py:198) */
+    double ground_damping;            /* N s/m (handle_collisions default 0) */
 } fpv_params_t;
 
 /* Device buffers of one batch.  Only `state` is mandatory for fpv_reset; `state` and `action`
@@ -107,7 +119,8 @@ typedef struct fpv_buffers {
     float* last_return;      /* [n] written when a lane reports done */
     int32_t* last_length;    /* [n] */
     float wind[3];           /* wind_velocity_vector of this step (kinematics.py:35: ADDED to v) */
-    uint32_t _pad;
+    uint32_t rounding_seed;  /* FPV_FLAG_FP16_STATE: mixed with the handle's launch counter for the stochastic rounding */
+    uint16_t* state_h;       /* FPV_FLAG_FP16_STATE: [FPV_HALF_ROWS][ld] binary16, 8-byte aligned; else unused */
 } fpv_buffers_t;
 
 typedef struct fpv_env* fpv_handle_t;
@@ -117,6 +130,8 @@ int fpv_abi_version(void);
 int fpv_state_rows(int mode);
 /* bytes each env-step must move at minimum (state R+W, action R, reward+done W) - roofline bookkeeping */
 int fpv_algorithmic_bytes(int mode);
+/* same for a live handle (accounts for FPV_FLAG_FP16_STATE: 3*4 + 11*2 bytes of state each way = 89 B) */
+int fpv_handle_algorithmic_bytes(fpv_handle_t h);
 
 /* Replaces Drone.__init__'s physics set-up (components.py:86-142) / Racer.__init__ (:68-83).
  * Validates and narrows the parameters; binds to `device`.  No device allocation. */

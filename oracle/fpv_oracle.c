@@ -95,17 +95,41 @@ void fpvo_drone_step(const fpvo_params* P, double* s, const double action[4], co
     /* kinematics.py:41-45 */
     const double grav[3] = {0, 0, -P->gravity * P->mass};
 
-    /* components.py:235-240: any motor below z = 0, evaluated on the PRE-update p and R, not latched */
+    /* components.py:235: motor positions in the world, pre-update pose */
+    double mpos[4][3];
+    for (int m = 0; m < 4; ++m)
+        for (int j = 0; j < 3; ++j)
+            mpos[m][j] = p[j] + (P->motor_xy[m][0] * R[3 * j + 0] + P->motor_xy[m][1] * R[3 * j + 1] + 0.0 * R[3 * j + 2]);
+
+    /* components.py:198-214 (handle_collisions) for object_list = [Ground]: distance = z
+     * (Ground.calculate_distance, :674-677), normal = [0,0,1].  The crash test `any(distances < 0)`
+     * sits INSIDE the per-motor loop and returns the forces summed so far - on the first iteration,
+     * i.e. zero (quirk Q5). */
+    double coll[3] = {0, 0, 0};
     uint8_t done = 0;
-    for (int m = 0; m < 4; ++m) {
-        const double mz = P->motor_xy[m][0] * R[6] + P->motor_xy[m][1] * R[7] + 0.0 * R[8];
-        if (p[2] + mz < 0.0) done = 1;
+    if (P->ground) {
+        int any_below = 0;
+        for (int m = 0; m < 4; ++m) any_below |= (mpos[m][2] < 0);
+        if (any_below) {
+            done = 1;
+        } else {
+            for (int m = 0; m < 4; ++m) {
+                const double d = mpos[m][2] - P->motor_radius;
+                if (d < 0) {   /* kinematics.py:56-59 spring_force(d, normal, velocity, k, c) */
+                    const double vn = v[0] * 0 + v[1] * 0 + v[2] * 1;
+                    coll[2] += (-P->ground_spring * d - P->ground_damping * vn) * 1.0;
+                }
+            }
+        }
     }
+    /* components.py:239-240: any motor below z = 0, evaluated on the PRE-update pose, not latched */
+    for (int m = 0; m < 4; ++m)
+        if (mpos[m][2] < 0.0) done = 1;
 
     /* components.py:242-243 */
     double acc[3];
     for (int i = 0; i < 3; ++i)
-        acc[i] = (thrust[i] + grav[i] + drag[i] + 0.0) / P->mass;
+        acc[i] = (thrust[i] + grav[i] + drag[i] + coll[i]) / P->mass;
 
     /* kinematics.py:21-23: p with the OLD v, then v, then one attitude increment ... */
     for (int i = 0; i < 3; ++i) p[i] += v[i] * P->dt;

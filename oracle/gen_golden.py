@@ -61,8 +61,9 @@ def ref_params(yaml_helper, fps):
     return p
 
 
-def run_drone(Drone, params, actions, position, velocity, ypr, wind=(0, 0, 0), stride=10):
+def run_drone(Drone, params, actions, position, velocity, ypr, wind=(0, 0, 0), stride=10, object_list=()):
     """actions [T,4] float32.  Snapshots after steps stride, 2*stride, ..., and always after T."""
+    object_list = list(object_list)
     T = actions.shape[0]
     a64 = actions.astype(np.float64)
     wind = np.asarray(wind, dtype=np.float64)
@@ -74,7 +75,7 @@ def run_drone(Drone, params, actions, position, velocity, ypr, wind=(0, 0, 0), s
         d.reset(position=np.asarray(position, float), velocity=np.asarray(velocity, float),
                 ypr=np.asarray(ypr, float))
         for t in range(T):
-            ret = d.step(action=a64[t].copy(), wind_velocity_vector=wind, object_list=[])
+            ret = d.step(action=a64[t].copy(), wind_velocity_vector=wind, object_list=object_list)
             done[t] = bool(d.done)
             if t + 1 in snaps:
                 rec["state"].append(d.state.copy())
@@ -187,6 +188,18 @@ def main():
     cs = [run_drone(Drone, P1k, a[:, k], ip[k], iv[k], io_[k], stride=1)[0] for k in range(3)]
     save("g6_ground", dt=1e-3, actions=a, init_position=ip, init_velocity=iv, init_ypr=io_, wind=np.zeros(3),
          **stack(cs))
+
+    # ---- G9: ground plane in object_list - per-motor spring contact + crash (components.py:198-214) ----
+    from utils.components import Ground
+    ground = Ground(size=60, resolution=4, random=False)
+    ip = np.array([[0, 0, 0.3], [0, 0, 0.25], [0, 0, 0.5], [0, 0, 0.2]])
+    iv = np.array([[0.5, 0, 0], [0, 0.3, -0.2], [0, 0, -4.0], [0, 0, 0.0]])
+    io_ = np.array([[0, 0, 0], [12.0, -8.0, 40.0], [0, 0, 0], [30.0, 20.0, 0]])
+    acts = np.array([[0, 0, 0, -0.80], [0.02, -0.01, 0, -0.78], [0, 0, 0, -1.0], [0, 0, 0, -0.7]])
+    a = np.stack([sticks.constant(600, 1, x)[:, 0] for x in acts], axis=1)
+    cs = [run_drone(Drone, P1k, a[:, k], ip[k], iv[k], io_[k], stride=1, object_list=[ground])[0] for k in range(4)]
+    save("g9_ground_contact", dt=1e-3, actions=a, init_position=ip, init_velocity=iv, init_ypr=io_,
+         wind=np.zeros(3), **stack(cs))
 
     # ---- G7/G8: Racer (rate PID -> torque) ----
     def run_racer(actions, pid_values, stride=10):

@@ -80,3 +80,46 @@ int fpvl_run(const fpv_params_t* P, int64_t n, int steps, float* st, int64_t ld,
 }
 
 }  // extern "C"
+
+// fp16-storage variant: pos [3][ld] fp32, sh [11][ld] binary16; every step goes through the same
+// unpack -> step -> pack (stochastic rounding keyed by seed0 + t) as fpv_drone_step_h_kernel.
+extern "C" int fpvl_run_h(const fpv_params_t* P, int64_t n, int steps, float* pos, uint16_t* sh, int64_t ld,
+                          const float* actions, int per_step, const float wind[3], uint32_t seed0,
+                          uint8_t* done, float* reward)
+{
+    FpvK K;
+    bool big = false;
+    const char* why = "";
+    const int rc = fpv_derive_constants(P, &K, &big, &why);
+    if (rc != FPV_OK) return rc;
+    for (int64_t i = 0; i < n; ++i) {
+        FpvStepOut o = {0, 0, 0, 0, false};
+        for (int t = 0; t < steps; ++t) {
+            FpvDroneState s;
+            FpvHalfState h;
+            s.px = pos[0 * ld + i]; s.py = pos[1 * ld + i]; s.pz = pos[2 * ld + i];
+            for (int k = 0; k < 3; ++k) h.v[k] = sh[(0 + k) * ld + i];
+            for (int k = 0; k < 4; ++k) h.q[k] = sh[(3 + k) * ld + i];
+            for (int k = 0; k < 3; ++k) h.r[k] = sh[(7 + k) * ld + i];
+            h.t = sh[10 * ld + i];
+            fpv_unpack_half(h, s);
+            const float* a = actions + ((per_step ? (int64_t)t * n : 0) + i) * 4;
+            o = big ? fpv_drone_step_lane<true>(K, s, a[0], a[1], a[2], a[3], wind[0], wind[1], wind[2])
+                    : fpv_drone_step_lane<false>(K, s, a[0], a[1], a[2], a[3], wind[0], wind[1], wind[2]);
+            if ((K.flags & FPV_FLAG_AUTO_RESET) && o.done) fpv_drone_reset_lane(K, s);
+            fpv_pack_half(s, seed0 + (uint32_t)t, (uint32_t)i, h);
+            pos[0 * ld + i] = s.px; pos[1 * ld + i] = s.py; pos[2 * ld + i] = s.pz;
+            for (int k = 0; k < 3; ++k) sh[(0 + k) * ld + i] = h.v[k];
+            for (int k = 0; k < 4; ++k) sh[(3 + k) * ld + i] = h.q[k];
+            for (int k = 0; k < 3; ++k) sh[(7 + k) * ld + i] = h.r[k];
+            sh[10 * ld + i] = h.t;
+        }
+        if (done) done[i] = o.done ? 1 : 0;
+        if (reward) reward[i] = o.reward;
+    }
+    return FPV_OK;
+}
+
+// conversion helpers exposed for the unit tests
+extern "C" uint16_t fpvl_f32_to_f16(float x, uint32_t rnd13, int stochastic) { return stochastic ? fpv_f32_to_f16_sr(x, rnd13) : fpv_f32_to_f16_rn(x); }
+extern "C" float fpvl_f16_to_f32(uint16_t h) { return fpv_f16_to_f32(h); }

@@ -72,3 +72,48 @@ def run(p, state: np.ndarray, actions: np.ndarray, steps: Optional[int] = None, 
     if rc != 0:
         raise RuntimeError(f"fpvl_run failed with {rc}")
     return state, accel, done, reward
+
+
+def run_h(p, pos: np.ndarray, sh: np.ndarray, actions: np.ndarray, steps: Optional[int] = None,
+          wind=(0.0, 0.0, 0.0), seed0: int = 0, n: Optional[int] = None, auto_reset: bool = False):
+    """fp16-storage variant: pos [3, ld] float32 and sh [11, ld] uint16 (binary16 bits), advanced in
+    place exactly like fpv_drone_step_h_kernel.  Returns (done [n], reward [n])."""
+    L = lib()
+    if not hasattr(L, "_h_ready"):
+        L.fpvl_run_h.argtypes = [C.POINTER(abi.FpvParams), C.c_int64, C.c_int, C.POINTER(C.c_float),
+                                 C.POINTER(C.c_uint16), C.c_int64, C.POINTER(C.c_float), C.c_int,
+                                 C.POINTER(C.c_float), C.c_uint32, C.POINTER(C.c_uint8), C.POINTER(C.c_float)]
+        L.fpvl_run_h.restype = C.c_int
+        L.fpvl_f32_to_f16.argtypes = [C.c_float, C.c_uint32, C.c_int]
+        L.fpvl_f32_to_f16.restype = C.c_uint16
+        L.fpvl_f16_to_f32.argtypes = [C.c_uint16]
+        L.fpvl_f16_to_f32.restype = C.c_float
+        L._h_ready = True
+    assert pos.dtype == np.float32 and sh.dtype == np.uint16 and pos.flags.c_contiguous and sh.flags.c_contiguous
+    ld = pos.shape[1]
+    assert sh.shape == (11, ld)
+    actions = np.ascontiguousarray(actions, dtype=np.float32)
+    per_step = actions.ndim == 3
+    n = n if n is not None else actions.shape[-2]
+    if per_step:
+        steps = actions.shape[0] if steps is None else steps
+    done = np.zeros(n, dtype=np.uint8)
+    reward = np.zeros(n, dtype=np.float32)
+    w = np.asarray(wind, dtype=np.float32)
+    cp = abi.pack_params(p, auto_reset=auto_reset, fp16_state=True)
+    fp = lambda a: a.ctypes.data_as(C.POINTER(C.c_float))  # noqa: E731
+    rc = L.fpvl_run_h(C.byref(cp), n, steps, fp(pos), sh.ctypes.data_as(C.POINTER(C.c_uint16)), ld, fp(actions),
+                      int(per_step), fp(w), seed0, done.ctypes.data_as(C.POINTER(C.c_uint8)), fp(reward))
+    if rc != 0:
+        raise RuntimeError(f"fpvl_run_h failed with {rc}")
+    return done, reward
+
+
+def split_half(state: np.ndarray):
+    """[14, ld] fp32 SoA -> (pos [3, ld] fp32, sh [11, ld] uint16) with round-to-nearest halves
+    (a freshly reset state is exactly representable, so the rounding mode does not matter)."""
+    return np.ascontiguousarray(state[0:3]), np.ascontiguousarray(state[3:14].astype(np.float16).view(np.uint16))
+
+
+def join_half(pos: np.ndarray, sh: np.ndarray) -> np.ndarray:
+    return np.concatenate([pos, sh.view(np.float16).astype(np.float32)], axis=0)

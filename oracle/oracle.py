@@ -31,7 +31,8 @@ class OracleParams(C.Structure):
         ("racer_mass", C.c_double), ("racer_inertia", C.c_double * 3),
         ("racer_pid", (C.c_double * 3) * 3),
         ("racer_velocity_damping", C.c_double),
-        ("racer_omega_dt", C.c_int32), ("_pad", C.c_int32),
+        ("racer_omega_dt", C.c_int32), ("ground", C.c_int32),
+        ("motor_radius", C.c_double), ("ground_spring", C.c_double), ("ground_damping", C.c_double),
     ]
 
 
@@ -83,6 +84,8 @@ def pack_params(p) -> OracleParams:
             o.racer_pid[i][j] = float(p.racer_pid[i][j])
     o.racer_velocity_damping = p.racer_velocity_damping
     o.racer_omega_dt = int(bool(p.racer_omega_dt))
+    o.ground = int(bool(getattr(p, "ground", False)))
+    o.motor_radius, o.ground_spring, o.ground_damping = p.motor_radius, p.ground_spring, p.ground_damping
     return o
 
 

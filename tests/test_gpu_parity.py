@@ -156,6 +156,28 @@ def test_ground_contact_done_sequence(params_1k):
     assert seq[2].any() and not seq[2][-1], "done is recomputed every step, not latched (components.py:236)"
 
 
+def test_ground_plane_contact_vs_reference_capture(params_1k):
+    """FPV_FLAG_GROUND = Drone.step(..., object_list=[Ground]) (components.py:198-214)."""
+    g = load_golden("g9_ground_contact")
+    p = params_1k.replace(ground=True)
+    acts = g["actions"]
+    T, n = acts.shape[:2]
+    env = _drone_batch(p, n)
+    model = lane_model.initial_state(p, n, g["init_position"], g["init_velocity"], g["init_ypr"])
+    env.state[:, :n] = torch.from_numpy(model[:, :n]).to(DEV)     # identical fp32 start for the bitwise check
+    dones = torch.zeros((T, n), dtype=torch.uint8, device=DEV)
+    env.rollout(torch.from_numpy(acts).to(DEV), dones=dones)
+    torch.cuda.synchronize()
+    assert (dones.cpu().numpy().T != g["done"]).sum() <= 2
+    ref = np.concatenate([g["state"][:, -1], g["R"][:, -1].reshape(n, 9), g["prev_rates"][:, -1],
+                          g["prev_thrust"][:, -1:]], axis=1)
+    got = env.state.cpu().numpy()
+    err = soa_vs_oracle(got, ref, n)
+    assert err["pos_comp"] < 2e-5 and err["quat_abs"] < 1e-5, err
+    lane_model.run(p, model, acts)
+    assert np.array_equal(got[:, :n].view(np.uint32), model[:, :n].view(np.uint32))
+
+
 def test_reset_mask_and_per_drone_initial_conditions(params_1k):
     n = 300
     rng = np.random.default_rng(3)
@@ -368,3 +390,47 @@ def test_argument_errors(params_1k):
     assert L.fpv_create(C.byref(_lib.pack_params(params_1k)), 8, 99, C.byref(h)) == -3
     with pytest.raises(_lib.FpvError):
         env.set_tuning(3)
+
+
+# ---- BASELINE config 4: fp16 state / fp32 integrator -------------------------------------------------
+def test_fp16_state_bitwise_vs_lane_model_and_restated_tolerance(params_1k):
+    from test_lane_model import FP16_TOL
+    g = load_golden("g3_ema_noise")
+    acts = g["actions"]
+    T, n = acts.shape[:2]
+    env = _drone_batch(params_1k, n, fp16_state=True, rounding_seed=5, with_accel=False)
+    assert env.algorithmic_bytes() == 89 and env.state.shape[0] == 3 and env.state_h.dtype == torch.float16
+    env.reset()
+    env.rollout(torch.from_numpy(acts).to(DEV))
+    torch.cuda.synchronize()
+    pos, sh = lane_model.split_half(lane_model.initial_state(params_1k, n))
+    lane_model.run_h(params_1k, pos, sh, acts, seed0=5)
+    assert np.array_equal(env.state.cpu().numpy()[:, :n].view(np.uint32), pos[:, :n].view(np.uint32))
+    assert np.array_equal(env.state_h.cpu().numpy()[:, :n].view(np.uint16), sh[:, :n])
+    ref = oracle.drone_initial_state(n, params_1k.init_position, params_1k.init_velocity, [0, 0, 0])
+    oracle.drone_run(params_1k, ref, acts.astype(np.float64))
+    got = np.concatenate([env.state.cpu().numpy(), env.state_h.float().cpu().numpy()], axis=0)
+    err = soa_vs_oracle(got, ref, n)
+    for k, tol in FP16_TOL.items():
+        assert err[k] <= tol, (k, err[k])
+    np.testing.assert_allclose(env.velocity.cpu().numpy(), ref[:, 3:6], rtol=5e-2, atol=5e-2)
+
+
+def test_fp16_state_full_size_vs_fp32_run():
+    """Config 4 at full size: same sticks through the fp32 and the fp16-storage kernels; the
+    distribution of the difference after 500 steps must sit inside the restated tolerance."""
+    n, k = 1 << 20, 500
+    p = load_params(fps=1000)
+    acts = sticks.ema_noise_device(50, n, DEV, seed=99)
+    e32 = _drone_batch(p, n, with_accel=False)
+    e16 = _drone_batch(p, n, with_accel=False, fp16_state=True)
+    e32.reset(); e16.reset()
+    for _ in range(k // 50):
+        e32.rollout(acts); e16.rollout(acts)
+    torch.cuda.synchronize()
+    dp = (e16.position - e32.position).norm(dim=1) / e32.position.norm(dim=1)
+    q16, q32 = e16.quaternion, e32.quaternion
+    dq = (q16 * torch.sign((q16 * q32).sum(dim=1, keepdim=True)) - q32).abs().amax(dim=1)
+    assert float(dp.max()) < 2e-2 and float(dp.mean()) < 2e-3, (float(dp.max()), float(dp.mean()))
+    assert float(dq.max()) < 3e-2 and float(dq.mean()) < 3e-3, (float(dq.max()), float(dq.mean()))
+    assert bool(torch.isfinite(e16.state_h.float()).all())

@@ -109,3 +109,19 @@ def test_racer_spot_value(params_1k):
     g = load_golden("g7_racer_main")
     np.testing.assert_allclose(g["omega"][0, -1], [-30, -50, 0], atol=1e-9)
     np.testing.assert_allclose(g["inertia"][0], 0.002016125, rtol=1e-12)
+
+
+def test_ground_plane_contact_matches_reference(params_1k):
+    """object_list = [Ground]: per-motor spring inside motor_radius, crash when a motor goes below
+    the plane (components.py:198-214, quirk Q5: the crash returns zero collision force)."""
+    g = load_golden("g9_ground_contact")
+    p = params_1k.replace(ground=True)
+    _, done_all, _ = _replay_drone(p, g)
+    assert np.array_equal(done_all, g["done"])
+    assert g["done"][2].any() and not g["done"][0].any()
+    zmin = g["state"][:, :, 2].min(axis=1)
+    assert 0 < zmin[0] < 0.1 and 0 < zmin[1] < 0.1, "cases 0/1 must enter the spring zone without crashing"
+    # without the flag the same inputs fall through the plane: the contact force is what differs
+    s = oracle.drone_initial_state(4, g["init_position"], g["init_velocity"], g["init_ypr"])
+    oracle.drone_run(params_1k, s, g["actions"].astype(np.float64))
+    assert s[0, 2] < 0 < g["state"][0, -1, 2]

@@ -23,6 +23,7 @@ def main():
     ap.add_argument("--ring", type=int, default=32)
     ap.add_argument("--geom", type=str, nargs="*", default=["1x128", "1x256", "2x128", "4x128"],
                     help="<drones per lane>x<threads per workgroup>")
+    ap.add_argument("--fp16", action="store_true", help="also time the fp16-storage kernel (config 4, 89 B/env-step)")
     ap.add_argument("--out", default=None)
     a = ap.parse_args()
     dev = torch.device("cuda:0")
@@ -34,6 +35,12 @@ def main():
     shared.reset()
     for g in a.geom:
         envs[g] = shared
+    if a.fp16:
+        e16 = DroneBatch(p, a.n, device=dev, with_accel=False, fp16_state=True)
+        e16.reset()
+        for g in ("h2x128", "h4x128", "h2x256", "h4x256"):      # fp16 storage: V drones per lane x block
+            envs[g] = e16
+        a.geom = list(a.geom) + ["h2x128", "h4x128", "h2x256", "h4x256"]
     variants = [(g, api) for g in a.geom for api in ("rollout", "step")]
     times = {v: [] for v in variants}
     ev0, ev1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
@@ -41,7 +48,7 @@ def main():
         for v in variants:
             d, api = v
             e = envs[d]
-            e.set_tuning(*[int(x) for x in d.split("x")])
+            e.set_tuning(*[int(x) for x in d.lstrip("h").split("x")])
             torch.cuda.synchronize()
             ev0.record()
             done = 0
@@ -57,9 +64,9 @@ def main():
             torch.cuda.synchronize()
             if r:   # round 0 = warm-up
                 times[v].append(ev0.elapsed_time(ev1) * 1e3 / a.launches)
-    B = _lib.algorithmic_bytes(0)
     res = []
     for v in variants:
+        B = envs[v[0]].algorithmic_bytes()
         med, mn = statistics.median(times[v]), min(times[v])
         res.append({"geom": v[0], "api": v[1], "median_us": med, "min_us": mn,
                     "GBps_alg_median": B * a.n / med / 1e3, "env_steps_per_s_median": a.n / med * 1e6})
