@@ -76,7 +76,13 @@ def main():
     ap.add_argument("--api", choices=["rollout", "step"], default="step",
                     help="rollout: K launches from one C call; step: one Python env.step() per launch")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--ceiling", type=float, default=100.0, help="auto-reset when |z| exceeds this (m)")
+    ap.add_argument("--no-auto-reset", action="store_true")
+    ap.add_argument("--fp16-state", action="store_true",
+                    help="BASELINE configs[3]: v,q,rates,thrust stored as binary16 (89 B/env-step); not the headline")
     ap.add_argument("--no-gather", action="store_true", help="skip the done-mask all-gather (N > 1)")
+    ap.add_argument("--gather-block", type=int, default=64,
+                    help="steps of done masks bucketed into one all-gather (N > 1)")
     ap.add_argument("--force-dist", action="store_true",
                     help="rehearsal: run the RCCL process group + all-gather path even with one rank")
     args = ap.parse_args()
@@ -103,8 +109,11 @@ def main():
         dist.init_process_group(backend="nccl", device_id=dev)
 
     n = args.drones_per_gpu
-    params = load_params(fps=1000)                      # dt = 1 ms
-    env = DroneBatch(params, n, device=dev, auto_reset=False, with_accel=False, with_done_bits=multi)
+    # dt = 1 ms; lanes that hit the ground or leave |z| <= ceiling are re-initialised in-kernel
+    # (BASELINE configs[4] semantics; costs no extra bytes), so a long run stays a flight workload
+    params = load_params(fps=1000, ceiling=args.ceiling)
+    env = DroneBatch(params, n, device=dev, auto_reset=not args.no_auto_reset, with_accel=False,
+                     with_done_bits=multi, fp16_state=args.fp16_state)
     if args.dpl:
         env.set_tuning(args.dpl)
     env.reset()
@@ -116,7 +125,7 @@ def main():
 
     gather = None
     if multi and not args.no_gather:
-        gather = DoneGather((env.done_bits.numel(),), torch.int64, dev)
+        gather = DoneGather((env.done_bits.numel(),), torch.int64, dev, block=args.gather_block)
 
     def run(k, t_base):
         """k steps = k launches.  Without the gather: whole ring spans go through fpv_rollout."""
@@ -130,10 +139,10 @@ def main():
         else:
             for t in range(t_base, t_base + k):
                 if gather is not None:
-                    env._buf.done_bits = gather.slot(t).data_ptr()
+                    env._buf.done_bits = gather.row_ptr(t)
                 env.step(actions[t % ring], return_imu=False)
                 if gather is not None:
-                    gather.launch(t)
+                    gather.step_done(t)
 
     def fence():
         torch.cuda.synchronize()
@@ -142,7 +151,7 @@ def main():
             torch.cuda.synchronize()
 
     if args.preheat_s > 0:
-        scratch = DroneBatch(params, n, device=dev, with_accel=False)
+        scratch = DroneBatch(params, n, device=dev, with_accel=False, fp16_state=args.fp16_state)
         scratch.reset()
         t_end = time.perf_counter() + args.preheat_s
         while time.perf_counter() < t_end:
@@ -157,6 +166,7 @@ def main():
     run(args.steps, args.warmup)
     ev1.record()
     if gather is not None:
+        gather.flush(args.warmup + args.steps - 1)
         gather.drain()
     fence()
     elapsed = time.perf_counter() - t0
@@ -170,12 +180,12 @@ def main():
     assert bool(torch.isfinite(env.state).all()), "non-finite state after the benchmark"
 
     if rank == 0:
-        bytes_per_step = _lib.algorithmic_bytes(_lib.FPV_MODE_DRONE)        # 133 B
+        bytes_per_step = env.algorithmic_bytes()                             # 133 B fp32 / 89 B fp16 state
         kernel_s = dev_ms * 1e-3 / args.steps                                # avg launch-to-launch on the stream
         achieved = bytes_per_step * n / kernel_s / 1e9
         traffic, traffic_src = None, None
         tp = os.path.join(REPO, "profiles", "pmc_traffic.json")
-        if os.path.isfile(tp):
+        if os.path.isfile(tp) and not args.fp16_state:
             tj = json.load(open(tp))
             traffic, traffic_src = tj.get("hbm_bytes_per_launch"), tj.get("source")
         out = {
@@ -186,13 +196,16 @@ def main():
             "ms_per_step": elapsed * 1e3 / args.steps,
             "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
             "dtype": "f32", "data": "synthetic",
-            "config": {"workload": "configs[2]: 1.05M drones/GPU, EMA-noise sticks (noise_smooth_test profile), fp32, dt=1ms",
+            "state_storage": "f16(v,q,rates,thrust)+f32(p)" if args.fp16_state else "f32",
+            "config": {"workload": ("configs[3]: fp16 state / fp32 integrator, " if args.fp16_state else "configs[2]: ")
+                       + "1.05M drones/GPU, EMA-noise sticks (noise_smooth_test profile), fp32 math, dt=1ms, "
+                       + ("no auto-reset" if args.no_auto_reset else f"in-kernel auto-reset on ground contact or |z|>{args.ceiling:g} m"),
                        "drones_per_gpu": n, "global_drones": n * world, "action_ring": ring, "api": args.api,
-                       "parallelism": f"shard{world}" + ("+allgather(done_bits)" if gather is not None else ""),
+                       "parallelism": f"shard{world}" + ("+allgather(done_bits x" + str(args.gather_block) + " steps)" if gather is not None else ""),
                        "drones_per_lane": args.dpl or "default"},
             "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": achieved / HBM_PEAK_GBS, "traffic": traffic, "traffic_source": traffic_src,
-                         "kernel": "fpv_drone_step_kernel", "algorithmic_bytes_per_env_step": bytes_per_step,
+                         "kernel": "fpv_drone_step_h_kernel" if args.fp16_state else "fpv_drone_step_kernel", "algorithmic_bytes_per_env_step": bytes_per_step,
                          "avg_launch_us": kernel_s * 1e6,
                          "note": "avg = HIP-event time over the timed region / launches (includes inter-launch gaps)"},
         }

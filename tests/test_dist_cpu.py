@@ -58,17 +58,20 @@ def _worker(rank, world, port, n_total, steps, out_dir):
         acts = sticks.ema_noise(steps, range(lo, hi), seed=3).astype(np.float64)
         acts[..., 3] -= 0.9                                   # low throttle: many drones reach the ground
         st = oracle.drone_initial_state(n, p.init_position, p.init_velocity, [0, 0, 0])
-        g = DoneGather(((n + 63) // 64,), torch.int64, "cpu")
+        block = 7                                              # does not divide `steps`: exercises flush()
+        g = DoneGather(((n + 63) // 64,), torch.int64, "cpu", block=block)
         seen = []
         for t in range(steps):
             _, _, done = oracle.drone_run(p, st, acts[t:t + 1])
-            g.slot(t).copy_(pack_done_bits(torch.from_numpy(done)))
-            g.launch(t)
-            if t >= 1:
-                seen.append(g.result(t - 1).clone())
-        seen.append(g.result(steps - 1).clone())
+            g.row(t).copy_(pack_done_bits(torch.from_numpy(done)))
+            g.step_done(t)
+            if (t + 1) % block == 0:
+                seen.append(g.result(t // block).clone())         # [world, block, words]
+        g.flush(steps - 1)
+        seen.append(g.result((steps - 1) // block).clone()[:, :steps % block])
         g.drain()
-        np.save(os.path.join(out_dir, f"gathered_{rank}.npy"), torch.stack(seen).numpy())
+        seen = [torch.cat(seen, dim=1).permute(1, 0, 2)]       # -> [steps, world, words]
+        np.save(os.path.join(out_dir, f"gathered_{rank}.npy"), seen[0].contiguous().numpy())
     finally:
         dist.destroy_process_group()
 
