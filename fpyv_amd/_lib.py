@@ -22,6 +22,7 @@ FPV_FLAG_AUTO_RESET = 1
 FPV_FLAG_GROUND = 2
 FPV_FLAG_FP16_STATE = 4
 FPV_HALF_ROWS = 11
+FPV_OBS_AOS_DIM = 16
 
 # state rows (fpv_abi.h)
 PX, PY, PZ, VX, VY, VZ, QW, QX, QY, QZ, RX, RY, RZ, THRUST = range(14)
@@ -57,6 +58,7 @@ class FpvBuffers(C.Structure):
         ("done", C.c_void_p), ("done_bits", C.c_void_p), ("accel", C.c_void_p), ("ep_return", C.c_void_p),
         ("ep_length", C.c_void_p), ("last_return", C.c_void_p), ("last_length", C.c_void_p),
         ("wind", C.c_float * 3), ("rounding_seed", C.c_uint32), ("state_h", C.c_void_p),
+        ("obs_aos", C.c_void_p),
     ]
 
 

@@ -45,6 +45,7 @@ struct FpvBufD {
     float* last_return;
     int32_t* last_length;
     float wx, wy, wz;
+    float* obs_aos;        // [n][16] row-major observation (p3 v3 q4 rates3 accel3) or null
     uint16_t* state_h;     // FPV_FLAG_FP16_STATE: [11][ld] binary16 rows (v, q, rates, thrust)
     uint32_t seed;         // stochastic-rounding seed of this launch
 };
@@ -136,6 +137,53 @@ __global__ __launch_bounds__(BS) void fpv_drone_step_kernel(const FpvK K, const 
             st_drone(B.state, B.ld, i, s[j]);
         }
         emit_outputs(B, i, live[j], o.reward, o.done);
+    }
+}
+
+// Same step + an array-of-structures observation row per drone, obs_aos[i][16] =
+// (p3, v3, q4 wxyz, rates3, R_new@acc 3): what a learner that wants an [N, D] matrix consumes, and
+// the reference's IMU-style return values (components.py:247-248) in one place.  A lane owns a
+// 64-byte row, so storing it directly would scatter 16 dwords at a 64-byte stride; instead each
+// wave transposes its 64 x 16 tile through LDS (row pitch 17 words: conflict-free writes) and
+// stores it as 4 fully coalesced 1-KiB float4 instructions.  This is the one place on the path
+// where LDS staging pays; the SoA state rows never need it.
+template <int BS, bool BIG>
+__global__ __launch_bounds__(BS) void fpv_drone_step_aos_kernel(const FpvK K, const FpvBufD B, const int64_t n)
+{
+    constexpr int kPitch = 17;
+    __shared__ float tile[BS / 64][64 * kPitch];
+    const int64_t i = (int64_t)blockIdx.x * BS + threadIdx.x;
+    const bool live = i < n;
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    FpvStepOut o;
+    o.done = false; o.reward = 0.0f; o.ax = o.ay = o.az = 0.0f;
+    if (live) {
+        FpvDroneState s;
+        const float4 a = ld_action(B.action, i);
+        ld_drone(B.state, B.ld, i, s);
+        o = fpv_drone_step_lane<BIG>(K, s, a.x, a.y, a.z, a.w, B.wx, B.wy, B.wz);
+        if (B.accel) {
+            B.accel[0 * B.ld + i] = o.ax; B.accel[1 * B.ld + i] = o.ay; B.accel[2 * B.ld + i] = o.az;
+        }
+        if ((K.flags & FPV_FLAG_AUTO_RESET) && o.done) fpv_drone_reset_lane(K, s);
+        st_drone(B.state, B.ld, i, s);
+        float* row = &tile[wave][lane * kPitch];
+        row[0] = s.px; row[1] = s.py; row[2] = s.pz; row[3] = s.vx; row[4] = s.vy; row[5] = s.vz;
+        row[6] = s.q.w; row[7] = s.q.x; row[8] = s.q.y; row[9] = s.q.z; row[10] = s.rx; row[11] = s.ry; row[12] = s.rz;
+        row[13] = o.ax; row[14] = o.ay; row[15] = o.az;
+    }
+    emit_outputs(B, i, live, o.reward, o.done);
+    __syncthreads();
+    const int64_t wave_first = i - lane;                 // first drone of this wave's tile
+    float4* out = reinterpret_cast<float4*>(B.obs_aos) + wave_first * 4;
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+        const int f4 = j * 64 + lane;                    // float4 index inside the 64 x 16 tile
+        const int d = f4 >> 2, c = (f4 & 3) * 4;
+        if (wave_first + d < n) {
+            const float* src = &tile[wave][d * kPitch + c];
+            out[f4] = make_float4(src[0], src[1], src[2], src[3]);
+        }
     }
 }
 
@@ -383,6 +431,11 @@ int check_buffers(const fpv_env* h, const fpv_buffers_t* b, bool need_action)  /
     if (((uintptr_t)b->state & 15) || ((uintptr_t)b->action & 15))
         return fail(FPV_EALIGN, "state and action must be 16-byte aligned");
     if ((uintptr_t)b->done_bits & 7) return fail(FPV_EALIGN, "done_bits must be 8-byte aligned");
+    if (b->obs_aos) {
+        if (h->mode != FPV_MODE_DRONE || (h->K.flags & FPV_FLAG_FP16_STATE))
+            return fail(FPV_EINVAL, "obs_aos is available in drone mode with fp32 state only");
+        if ((uintptr_t)b->obs_aos & 15) return fail(FPV_EALIGN, "obs_aos must be 16-byte aligned");
+    }
     if (h->K.flags & FPV_FLAG_FP16_STATE) {
         if (!b->state_h) return fail(FPV_EINVAL, "FPV_FLAG_FP16_STATE needs fpv_buffers_t.state_h");
         if ((uintptr_t)b->state_h & 7) return fail(FPV_EALIGN, "state_h must be 8-byte aligned");
@@ -402,7 +455,7 @@ FpvBufD to_device_view(const fpv_buffers_t* b)
     d.accel = b->accel; d.ep_return = b->ep_return; d.ep_length = b->ep_length;
     d.last_return = b->last_return; d.last_length = b->last_length;
     d.wx = b->wind[0]; d.wy = b->wind[1]; d.wz = b->wind[2];
-    d.state_h = b->state_h; d.seed = b->rounding_seed;
+    d.state_h = b->state_h; d.seed = b->rounding_seed; d.obs_aos = b->obs_aos;
     return d;
 }
 
@@ -456,6 +509,15 @@ int launch_step(fpv_env* h, const FpvBufD& d_in, hipStream_t s)
             else { if (h->big_angle) FPV_LAUNCH_H(2, 128, true); else FPV_LAUNCH_H(2, 128, false); }
         }
 #undef FPV_LAUNCH_H
+    } else if (h->mode == FPV_MODE_DRONE && d.obs_aos) {
+        const dim3 grid((unsigned)((h->n + h->block - 1) / h->block));
+        if (h->block == 256) {
+            if (h->big_angle) hipLaunchKernelGGL((fpv_drone_step_aos_kernel<256, true>), grid, dim3(256), 0, s, h->K, d, h->n);
+            else hipLaunchKernelGGL((fpv_drone_step_aos_kernel<256, false>), grid, dim3(256), 0, s, h->K, d, h->n);
+        } else {
+            if (h->big_angle) hipLaunchKernelGGL((fpv_drone_step_aos_kernel<128, true>), grid, dim3(128), 0, s, h->K, d, h->n);
+            else hipLaunchKernelGGL((fpv_drone_step_aos_kernel<128, false>), grid, dim3(128), 0, s, h->K, d, h->n);
+        }
     } else if (h->mode == FPV_MODE_DRONE) {
         if (h->block == 256) launch_drone_bs<256>(h, d, s);
         else launch_drone_bs<128>(h, d, s);

@@ -36,7 +36,7 @@ class _Batch:
 
     def __init__(self, params: DroneParams, num_envs: int, device: Any = "cuda:0", auto_reset: bool = False,
                  track_episodes: bool = False, with_accel: bool = False, with_done_bits: bool = False,
-                 fp16_state: bool = False, rounding_seed: int = 0):
+                 fp16_state: bool = False, rounding_seed: int = 0, with_obs_aos: bool = False):
         if num_envs <= 0:
             raise ValueError("num_envs must be positive")
         self.params = params
@@ -74,6 +74,8 @@ class _Batch:
             self.last_length = torch.zeros(self.n, dtype=torch.int32, device=self.device)
         else:
             self.ep_return = self.ep_length = self.last_return = self.last_length = None
+        # optional row-major [num_envs, 16] observation written by the kernel through an LDS transpose
+        self.obs_aos = (torch.zeros((self.n, _lib.FPV_OBS_AOS_DIM), **f32) if with_obs_aos else None)
         self._bcast_action = None
         self._buf = _lib.FpvBuffers()
         self._fill_buffers()
@@ -89,6 +91,7 @@ class _Batch:
         b.last_return, b.last_length = ptr(self.last_return), ptr(self.last_length)
         b.wind[0] = b.wind[1] = b.wind[2] = 0.0
         b.state_h, b.rounding_seed = ptr(self.state_h), self.rounding_seed
+        b.obs_aos = ptr(self.obs_aos)
 
     def rows_f32(self, r0: int, r1: int) -> torch.Tensor:
         """[num_envs, r1-r0] fp32 values of state rows r0..r1-1 (fpv_abi.h row numbering), whatever the

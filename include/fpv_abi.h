@@ -69,6 +69,7 @@ enum {
 };
 /* rows of state_h under FPV_FLAG_FP16_STATE: row (FPV_VX - 3) .. (FPV_THRUST - 3) */
 #define FPV_HALF_ROWS 11
+#define FPV_OBS_AOS_DIM 16
 
 /* Host-side description of one drone type; doubles, narrowed to fp32 by fpv_create.
  * Field sources: components.py:92-100 (dt, gravity, mass, drag, areas), :120-125 (motor_xy),
@@ -121,6 +122,9 @@ typedef struct fpv_buffers {
     float wind[3];           /* wind_velocity_vector of this step (kinematics.py:35: ADDED to v) */
     uint32_t rounding_seed;  /* FPV_FLAG_FP16_STATE: mixed with the handle's launch counter for the stochastic rounding */
     uint16_t* state_h;       /* FPV_FLAG_FP16_STATE: [FPV_HALF_ROWS][ld] binary16, 8-byte aligned; else unused */
+    float* obs_aos;          /* [n][FPV_OBS_AOS_DIM] row-major observation per drone, 16-byte aligned, or NULL:
+                                p3, v3, q4 (wxyz), prev_rates3, R_new@acc 3 - the values Drone.step returns
+                                (components.py:247-248) gathered in one row; drone mode, fp32 state only */
 } fpv_buffers_t;
 
 typedef struct fpv_env* fpv_handle_t;

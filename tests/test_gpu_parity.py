@@ -434,3 +434,28 @@ def test_fp16_state_full_size_vs_fp32_run():
     assert float(dp.max()) < 2e-2 and float(dp.mean()) < 2e-3, (float(dp.max()), float(dp.mean()))
     assert float(dq.max()) < 3e-2 and float(dq.mean()) < 3e-3, (float(dq.max()), float(dq.mean()))
     assert bool(torch.isfinite(e16.state_h.float()).all())
+
+
+@pytest.mark.parametrize("n,block", [(1, 128), (63, 128), (1000, 128), (4096 + 5, 256), (1 << 16, 128)])
+def test_obs_aos_rows_equal_soa_state(params_1k, n, block):
+    """The LDS-transposed [n, 16] observation must be exactly the SoA state + the accelerometer
+    triple of the same step (p3 v3 q4 rates3 R_new@acc 3), for ragged sizes and both block widths."""
+    steps = 20
+    acts = torch.from_numpy(sticks.ema_noise(steps, range(min(n, 2048)), seed=2)).to(DEV)
+    if n > 2048:
+        acts = acts.repeat(1, (n + 2047) // 2048, 1)[:, :n].contiguous()
+    env = _drone_batch(params_1k.replace(ceiling=10.4), n, with_obs_aos=True, auto_reset=True)
+    plain = _drone_batch(params_1k.replace(ceiling=10.4), n, auto_reset=True)
+    env.set_tuning(1, block)
+    env.reset(); plain.reset()
+    env.obs_aos.fill_(float("nan"))
+    for t in range(steps):
+        env.step(acts[t], return_imu=False)
+        plain.step(acts[t], return_imu=False)
+    torch.cuda.synchronize()
+    assert torch.equal(env.state, plain.state), "the AoS head must not change the physics"
+    obs = env.obs_aos
+    assert obs.shape == (n, 16)
+    assert torch.equal(obs[:, 0:13], env.state[0:13, :n].t())
+    assert torch.equal(obs[:, 13:16], env.accel[:, :n].t())
+    assert torch.equal(env.reward, plain.reward) and torch.equal(env.done_u8, plain.done_u8)

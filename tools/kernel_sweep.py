@@ -24,6 +24,7 @@ def main():
     ap.add_argument("--geom", type=str, nargs="*", default=["1x128", "1x256", "2x128", "4x128"],
                     help="<drones per lane>x<threads per workgroup>")
     ap.add_argument("--fp16", action="store_true", help="also time the fp16-storage kernel (config 4, 89 B/env-step)")
+    ap.add_argument("--aos", action="store_true", help="also time the step with the [n,16] AoS observation head")
     ap.add_argument("--out", default=None)
     a = ap.parse_args()
     dev = torch.device("cuda:0")
@@ -41,6 +42,11 @@ def main():
         for g in ("h2x128", "h4x128", "h2x256", "h4x256"):      # fp16 storage: V drones per lane x block
             envs[g] = e16
         a.geom = list(a.geom) + ["h2x128", "h4x128", "h2x256", "h4x256"]
+    if a.aos:
+        ea = DroneBatch(p, a.n, device=dev, with_accel=False, with_obs_aos=True)
+        ea.reset()
+        envs["aos1x128"] = envs["aos1x256"] = ea
+        a.geom = list(a.geom) + ["aos1x128", "aos1x256"]
     variants = [(g, api) for g in a.geom for api in ("rollout", "step")]
     times = {v: [] for v in variants}
     ev0, ev1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
@@ -48,7 +54,7 @@ def main():
         for v in variants:
             d, api = v
             e = envs[d]
-            e.set_tuning(*[int(x) for x in d.lstrip("h").split("x")])
+            e.set_tuning(*[int(x) for x in d.replace("aos", "").lstrip("h").split("x")])
             torch.cuda.synchronize()
             ev0.record()
             done = 0
@@ -66,7 +72,7 @@ def main():
                 times[v].append(ev0.elapsed_time(ev1) * 1e3 / a.launches)
     res = []
     for v in variants:
-        B = envs[v[0]].algorithmic_bytes()
+        B = envs[v[0]].algorithmic_bytes() + (64 if v[0].startswith("aos") else 0)
         med, mn = statistics.median(times[v]), min(times[v])
         res.append({"geom": v[0], "api": v[1], "median_us": med, "min_us": mn,
                     "GBps_alg_median": B * a.n / med / 1e3, "env_steps_per_s_median": a.n / med * 1e6})
