@@ -21,6 +21,7 @@ FPV_DRONE_ROWS, FPV_RACER_ROWS = 14, 20
 FPV_FLAG_AUTO_RESET = 1
 FPV_FLAG_GROUND = 2
 FPV_FLAG_FP16_STATE = 4
+FPV_FLAG_STICK_NOISE = 8
 FPV_HALF_ROWS = 11
 FPV_OBS_AOS_DIM = 16
 
@@ -30,7 +31,7 @@ R_OMEGA, R_IERR, R_LERR, R_FIRST = 10, 13, 16, 19
 
 # every symbol include/fpv_abi.h declares
 EXPORTS = ("fpv_abi_version", "fpv_state_rows", "fpv_algorithmic_bytes", "fpv_handle_algorithmic_bytes", "fpv_create", "fpv_destroy",
-           "fpv_reset", "fpv_step", "fpv_rollout", "fpv_set_params", "fpv_set_tuning", "fpv_recommended_ld",
+           "fpv_reset", "fpv_step", "fpv_rollout", "fpv_set_params", "fpv_set_step_counter", "fpv_set_tuning", "fpv_recommended_ld",
            "fpv_diag_stream_copy", "fpv_last_error",
            "fpv_error_name")
 
@@ -49,6 +50,8 @@ class FpvParams(C.Structure):
         ("racer_mass", C.c_double), ("racer_inertia", C.c_double * 3), ("racer_pid", (C.c_double * 3) * 3),
         ("racer_velocity_damping", C.c_double),
         ("motor_radius", C.c_double), ("ground_spring", C.c_double), ("ground_damping", C.c_double),
+        ("noise_transition", C.c_double), ("noise_gain", C.c_double),
+        ("noise_seed", C.c_uint64), ("drone_id_offset", C.c_uint64),
     ]
 
 
@@ -58,17 +61,21 @@ class FpvBuffers(C.Structure):
         ("done", C.c_void_p), ("done_bits", C.c_void_p), ("accel", C.c_void_p), ("ep_return", C.c_void_p),
         ("ep_length", C.c_void_p), ("last_return", C.c_void_p), ("last_length", C.c_void_p),
         ("wind", C.c_float * 3), ("rounding_seed", C.c_uint32), ("state_h", C.c_void_p),
-        ("obs_aos", C.c_void_p),
+        ("noise_state", C.c_void_p), ("action_out", C.c_void_p), ("obs_aos", C.c_void_p),
     ]
 
 
-def pack_params(p, auto_reset: bool = False, fp16_state: bool = False) -> FpvParams:
+def pack_params(p, auto_reset: bool = False, fp16_state: bool = False, stick_noise: bool = False,
+                noise_seed: int = 0, drone_id_offset: int = 0) -> FpvParams:
     """DroneParams -> fpv_params_t."""
     s = FpvParams()
     s.struct_size = C.sizeof(FpvParams)
     s.mode = int(p.mode)
     s.flags = ((FPV_FLAG_AUTO_RESET if auto_reset else 0) | (FPV_FLAG_GROUND if getattr(p, "ground", False) else 0)
-               | (FPV_FLAG_FP16_STATE if fp16_state else 0))
+               | (FPV_FLAG_FP16_STATE if fp16_state else 0) | (FPV_FLAG_STICK_NOISE if stick_noise else 0))
+    s.noise_transition = float(getattr(p, "noise_transition", 0.1))
+    s.noise_gain = float(getattr(p, "noise_gain", 1.0))
+    s.noise_seed, s.drone_id_offset = int(noise_seed) & (2 ** 64 - 1), int(drone_id_offset)
     s.racer_omega_dt = int(bool(p.racer_omega_dt))
     s.dt, s.gravity, s.mass, s.max_rates = float(p.dt), float(p.gravity), float(p.mass), float(p.max_rates)
     s.rates_transition_rate = float(p.rates_transition_rate)
@@ -128,6 +135,7 @@ def lib() -> C.CDLL:
     L.fpv_rollout.argtypes = [vp, pb, C.c_int, i64, i64, vp]
     L.fpv_set_params.argtypes = [vp, pp]
     L.fpv_set_tuning.argtypes = [vp, C.c_int, C.c_int]
+    L.fpv_set_step_counter.argtypes = [vp, C.c_uint32]
     L.fpv_recommended_ld.argtypes = [i64]
     L.fpv_recommended_ld.restype = i64
     L.fpv_diag_stream_copy.argtypes = [vp, vp, i64, vp]

@@ -23,6 +23,8 @@ static inline int fpv_derive_constants(const fpv_params_t* P, FpvK* K, bool* big
     if (P->struct_size != sizeof(fpv_params_t)) { *why = "fpv_params_t.struct_size does not match this library"; return FPV_EINVAL; }
     if (P->mode != FPV_MODE_DRONE && P->mode != FPV_MODE_RACER) { *why = "unknown mode"; return FPV_EINVAL; }
     if ((P->flags & FPV_FLAG_FP16_STATE) && P->mode != FPV_MODE_DRONE) { *why = "FPV_FLAG_FP16_STATE is a drone-mode layout"; return FPV_EINVAL; }
+    if ((P->flags & FPV_FLAG_STICK_NOISE) && (P->mode != FPV_MODE_DRONE || (P->flags & FPV_FLAG_FP16_STATE))) { *why = "FPV_FLAG_STICK_NOISE needs drone mode with fp32 state"; return FPV_EINVAL; }
+    if ((P->flags & FPV_FLAG_STICK_NOISE) && !(P->noise_transition > 0 && P->noise_transition <= 1)) { *why = "noise_transition must be in (0, 1]"; return FPV_EPARAM; }
     if (!(P->dt > 0) || !isfinite(P->dt)) { *why = "dt must be positive and finite"; return FPV_EPARAM; }
     if (!(P->mass > 0)) { *why = "mass must be positive"; return FPV_EPARAM; }
     if (!(P->max_rates >= 0) || !isfinite(P->max_rates)) { *why = "max_rates must be finite and >= 0"; return FPV_EPARAM; }
@@ -69,6 +71,11 @@ static inline int fpv_derive_constants(const fpv_params_t* P, FpvK* K, bool* big
     K->motor_radius = (float)P->motor_radius;
     K->ground_k_m = (float)(P->ground_spring / P->mass);
     K->ground_c_m = (float)(P->ground_damping / P->mass);
+    K->noise.tau = (float)P->noise_transition;
+    K->noise.omtau = (float)(1.0 - P->noise_transition);
+    K->noise.gain = (float)P->noise_gain;
+    K->noise.seed_lo = (uint32_t)P->noise_seed; K->noise.seed_hi = (uint32_t)(P->noise_seed >> 32);
+    K->noise.id_lo = (uint32_t)P->drone_id_offset; K->noise.id_hi = (uint32_t)(P->drone_id_offset >> 32);
     K->flags = P->flags;
     // |rates| <= max_rates always (clip + convex low-pass from 0), so the largest half-angle of one
     // step is known here; beyond pi/4 the short polynomial is no longer exact to fp32.

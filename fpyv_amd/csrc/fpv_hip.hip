@@ -46,6 +46,9 @@ struct FpvBufD {
     int32_t* last_length;
     float wx, wy, wz;
     float* obs_aos;        // [n][16] row-major observation (p3 v3 q4 rates3 accel3) or null
+    float* noise_state;    // FPV_FLAG_STICK_NOISE: [4][ld] EMA stick-noise state
+    float4* action_out;    // [n] applied action or null
+    uint32_t step;         // launch index of the handle: Philox counter word
     uint16_t* state_h;     // FPV_FLAG_FP16_STATE: [11][ld] binary16 rows (v, q, rates, thrust)
     uint32_t seed;         // stochastic-rounding seed of this launch
 };
@@ -106,7 +109,22 @@ __device__ __forceinline__ void emit_lane_outputs(const FpvBufD& B, int64_t i, f
     }
 }
 
-template <int BS, int DPL, bool BIG>
+// EMA stick noise: read 4 state floats, one Philox4x32-10 block -> 4 normals, write them back,
+// perturb the action.  With no caller action (B.action null) the sticks are the pure noise profile.
+__device__ __forceinline__ float4 apply_stick_noise(const FpvK& K, const FpvBufD& B, int64_t i, float4 a)
+{
+    float ns[4], av[4] = {a.x, a.y, a.z, a.w};
+#pragma unroll
+    for (int k = 0; k < 4; ++k) ns[k] = B.noise_state[(int64_t)k * B.ld + i];
+    fpv_stick_noise(K.noise, B.step, (uint64_t)i, ns, av);
+#pragma unroll
+    for (int k = 0; k < 4; ++k) B.noise_state[(int64_t)k * B.ld + i] = ns[k];
+    const float4 r = make_float4(av[0], av[1], av[2], av[3]);
+    if (B.action_out) B.action_out[i] = r;
+    return r;
+}
+
+template <int BS, int DPL, bool BIG, bool NOISE = false>
 __global__ __launch_bounds__(BS) void fpv_drone_step_kernel(const FpvK K, const FpvBufD B, const int64_t n)
 {
     const int64_t base = (int64_t)blockIdx.x * (BS * DPL) + threadIdx.x;
@@ -119,8 +137,9 @@ __global__ __launch_bounds__(BS) void fpv_drone_step_kernel(const FpvK K, const 
         const int64_t i = base + (int64_t)j * BS;
         live[j] = i < n;
         if (live[j]) {
-            a[j] = ld_action(B.action, i);
+            a[j] = (!NOISE || B.action) ? ld_action(B.action, i) : make_float4(0.f, 0.f, 0.f, 0.f);
             ld_drone(B.state, B.ld, i, s[j]);
+            if (NOISE) a[j] = apply_stick_noise(K, B, i, a[j]);
         }
     }
 #pragma unroll
@@ -378,6 +397,10 @@ __global__ __launch_bounds__(kBlock) void fpv_reset_kernel(const FpvK K, const F
     }
     if (B.done) B.done[i] = 0;
     if (B.ep_return) { B.ep_return[i] = 0.0f; B.ep_length[i] = 0; }
+    if (B.noise_state) {
+#pragma unroll
+        for (int k = 0; k < 4; ++k) B.noise_state[(int64_t)k * B.ld + i] = 0.0f;      // x_s(0) = 0
+    }
 }
 
 // Counter calibration: a copy with the step kernel's access shape (one dword per lane per
@@ -425,7 +448,13 @@ int check_buffers(const fpv_env* h, const fpv_buffers_t* b, bool need_action)  /
     if (!h) return fail(FPV_EINVAL, "null handle");
     if (!b) return fail(FPV_EINVAL, "null fpv_buffers_t");
     if (!b->state) return fail(FPV_EINVAL, "fpv_buffers_t.state is null");
-    if (need_action && !b->action) return fail(FPV_EINVAL, "fpv_buffers_t.action is null");
+    const bool noise = (h->K.flags & FPV_FLAG_STICK_NOISE) != 0;
+    if (need_action && !b->action && !noise) return fail(FPV_EINVAL, "fpv_buffers_t.action is null");
+    if (noise) {
+        if (!b->noise_state) return fail(FPV_EINVAL, "FPV_FLAG_STICK_NOISE needs fpv_buffers_t.noise_state");
+        if (b->obs_aos) return fail(FPV_EINVAL, "obs_aos and FPV_FLAG_STICK_NOISE cannot be combined yet");
+    }
+    if ((uintptr_t)b->action_out & 15) return fail(FPV_EALIGN, "action_out must be 16-byte aligned");
     if (b->ld < h->n) return fail(FPV_EALIGN, "fpv_buffers_t.ld is smaller than the number of drones");
     if (b->ld % 4) return fail(FPV_EALIGN, "fpv_buffers_t.ld must be a multiple of 4 floats");
     if (((uintptr_t)b->state & 15) || ((uintptr_t)b->action & 15))
@@ -456,6 +485,7 @@ FpvBufD to_device_view(const fpv_buffers_t* b)
     d.last_return = b->last_return; d.last_length = b->last_length;
     d.wx = b->wind[0]; d.wy = b->wind[1]; d.wz = b->wind[2];
     d.state_h = b->state_h; d.seed = b->rounding_seed; d.obs_aos = b->obs_aos;
+    d.noise_state = b->noise_state; d.action_out = reinterpret_cast<float4*>(b->action_out); d.step = 0;
     return d;
 }
 
@@ -495,6 +525,7 @@ void launch_drone_bs(const fpv_env* h, const FpvBufD& d, hipStream_t s)
 int launch_step(fpv_env* h, const FpvBufD& d_in, hipStream_t s)
 {
     FpvBufD d = d_in;
+    d.step = h->launches;
     d.seed = d_in.seed + h->launches++;
     if (h->mode == FPV_MODE_DRONE && (h->K.flags & FPV_FLAG_FP16_STATE)) {
         const int v = h->dpl == 4 ? 4 : 2;
@@ -509,6 +540,16 @@ int launch_step(fpv_env* h, const FpvBufD& d_in, hipStream_t s)
             else { if (h->big_angle) FPV_LAUNCH_H(2, 128, true); else FPV_LAUNCH_H(2, 128, false); }
         }
 #undef FPV_LAUNCH_H
+    } else if (h->mode == FPV_MODE_DRONE && (h->K.flags & FPV_FLAG_STICK_NOISE)) {
+        const int bs = h->block;
+        const dim3 grid((unsigned)((h->n + bs - 1) / bs));
+        if (bs == 256) {
+            if (h->big_angle) hipLaunchKernelGGL((fpv_drone_step_kernel<256, 1, true, true>), grid, dim3(256), 0, s, h->K, d, h->n);
+            else hipLaunchKernelGGL((fpv_drone_step_kernel<256, 1, false, true>), grid, dim3(256), 0, s, h->K, d, h->n);
+        } else {
+            if (h->big_angle) hipLaunchKernelGGL((fpv_drone_step_kernel<128, 1, true, true>), grid, dim3(128), 0, s, h->K, d, h->n);
+            else hipLaunchKernelGGL((fpv_drone_step_kernel<128, 1, false, true>), grid, dim3(128), 0, s, h->K, d, h->n);
+        }
     } else if (h->mode == FPV_MODE_DRONE && d.obs_aos) {
         const dim3 grid((unsigned)((h->n + h->block - 1) / h->block));
         if (h->block == 256) {
@@ -588,7 +629,7 @@ int fpv_set_params(fpv_handle_t h, const fpv_params_t* params)
 {
     if (!h || !params) return fail(FPV_EINVAL, "null argument");
     if ((int)params->mode != h->mode) return fail(FPV_EINVAL, "mode cannot change on a live handle (state layout differs)");
-    if ((params->flags ^ h->P.flags) & FPV_FLAG_FP16_STATE)
+    if ((params->flags ^ h->P.flags) & (FPV_FLAG_FP16_STATE | FPV_FLAG_STICK_NOISE))
         return fail(FPV_EINVAL, "FPV_FLAG_FP16_STATE cannot change on a live handle (state layout differs)");
     FpvK K;
     bool big = false;
@@ -596,6 +637,13 @@ int fpv_set_params(fpv_handle_t h, const fpv_params_t* params)
     const int rc = fpv_derive_constants(params, &K, &big, &why);
     if (rc != FPV_OK) return fail(rc, why);
     h->K = K; h->P = *params; h->big_angle = big;
+    return FPV_OK;
+}
+
+int fpv_set_step_counter(fpv_handle_t h, uint32_t step)
+{
+    if (!h) return fail(FPV_EINVAL, "null handle");
+    h->launches = step;
     return FPV_OK;
 }
 
@@ -656,7 +704,7 @@ int fpv_rollout(fpv_handle_t h, const fpv_buffers_t* b, int k, int64_t action_st
     FpvBufD d = to_device_view(b);
     const float* a0 = b->action;
     for (int t = 0; t < k; ++t) {
-        d.action = reinterpret_cast<const float4*>(a0 + (int64_t)t * action_stride);
+        d.action = a0 ? reinterpret_cast<const float4*>(a0 + (int64_t)t * action_stride) : nullptr;
         if (out_stride) {
             if (b->reward) d.reward = b->reward + (int64_t)t * out_stride;
             if (b->done) d.done = b->done + (int64_t)t * out_stride;

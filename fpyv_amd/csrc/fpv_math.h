@@ -30,6 +30,14 @@
 
 #define FPV_MATH_FLAG_AUTO_RESET 1u   // = FPV_FLAG_AUTO_RESET (include/fpv_abi.h)
 #define FPV_MATH_FLAG_GROUND 2u       // = FPV_FLAG_GROUND
+#define FPV_MATH_FLAG_STICK_NOISE 8u  // = FPV_FLAG_STICK_NOISE
+
+struct FpvNoiseK {           // uniform constants of the stick-noise generator
+    float tau, omtau;        // transition, 1 - transition   (noise_smooth_test.py:5: 0.1)
+    float gain;              // sticks += gain * x_s, then clipped to [-1, 1]
+    uint32_t seed_lo, seed_hi;
+    uint32_t id_lo, id_hi;   // global id of this shard's drone 0
+};
 
 // Uniform per-launch constants (kernel argument -> SGPRs).  Derived in double on the host.
 struct FpvK {
@@ -51,6 +59,7 @@ struct FpvK {
     float r_dt_over_I[3];
     float r_pid[3][3];
     float motor_radius, ground_k_m, ground_c_m;   // contact distance; spring and damping already divided by m
+    FpvNoiseK noise;
     uint32_t flags;
 };
 
@@ -229,6 +238,56 @@ FPV_HD void fpv_pack_half(const FpvDroneState& s, uint32_t seed, uint32_t drone,
     h.q[3] = fpv_f32_to_f16_sr(s.q.z, ((r0 >> 26) | ((r1 >> 26) << 6) | ((r2 >> 26) << 12)) & 0x1fffu);
     h.r[0] = fpv_f32_to_f16_rn(s.rx); h.r[1] = fpv_f32_to_f16_rn(s.ry); h.r[2] = fpv_f32_to_f16_rn(s.rz);
     h.t = fpv_f32_to_f16_rn(s.thrust);
+}
+
+// ------------------------------------------------------------------------------------------------
+// In-kernel stick noise: the profile of tests/noise_smooth_test.py:6-12,
+//   x ~ N(0,1);  x_s <- (1 - tau) x_s + tau x,
+// generated per drone and channel from Philox4x32-10 (Salmon et al., SC'11; counter-based, so a
+// drone's stream depends only on (seed, GLOBAL drone id, step) - not on the batch, lane or shard).
+// ------------------------------------------------------------------------------------------------
+FPV_HD void fpv_philox4x32_10(uint32_t c0, uint32_t c1, uint32_t c2, uint32_t c3, uint32_t k0, uint32_t k1,
+                              uint32_t out[4])
+{
+#pragma unroll
+    for (int r = 0; r < 10; ++r) {
+        const uint64_t p0 = (uint64_t)0xD2511F53u * c0, p1 = (uint64_t)0xCD9E8D57u * c2;
+        const uint32_t n0 = (uint32_t)(p1 >> 32) ^ c1 ^ k0, n2 = (uint32_t)(p0 >> 32) ^ c3 ^ k1;
+        c1 = (uint32_t)p1; c3 = (uint32_t)p0; c0 = n0; c2 = n2;
+        k0 += 0x9E3779B9u; k1 += 0xBB67AE85u;
+    }
+    out[0] = c0; out[1] = c1; out[2] = c2; out[3] = c3;
+}
+
+// four standard normals from one Philox block (Box-Muller on two uniform pairs in (0,1))
+FPV_HD void fpv_normal4(uint32_t seed_lo, uint32_t seed_hi, uint32_t drone_lo, uint32_t drone_hi, uint32_t step,
+                        float z[4])
+{
+    uint32_t r[4];
+    fpv_philox4x32_10(drone_lo, drone_hi, step, 0u, seed_lo, seed_hi, r);
+    const float u0 = ((float)(r[0] >> 8) + 0.5f) * 5.9604644775390625e-08f;    // 2^-24, in (0,1)
+    const float u1 = ((float)(r[1] >> 8) + 0.5f) * 5.9604644775390625e-08f;
+    const float u2 = ((float)(r[2] >> 8) + 0.5f) * 5.9604644775390625e-08f;
+    const float u3 = ((float)(r[3] >> 8) + 0.5f) * 5.9604644775390625e-08f;
+    const float ra = sqrtf(-2.0f * logf(u0)), rb = sqrtf(-2.0f * logf(u2));
+    float s, c;
+    fpv_sincos_full(6.283185307179586f * u1, &s, &c);
+    z[0] = ra * c; z[1] = ra * s;
+    fpv_sincos_full(6.283185307179586f * u3, &s, &c);
+    z[2] = rb * c; z[3] = rb * s;
+}
+
+// advance the EMA state ns[4] and perturb the action in place
+FPV_HD void fpv_stick_noise(const FpvNoiseK& N, uint32_t step, uint64_t local_id, float ns[4], float a[4])
+{
+    const uint64_t gid = (((uint64_t)N.id_hi << 32) | N.id_lo) + local_id;
+    float z[4];
+    fpv_normal4(N.seed_lo, N.seed_hi, (uint32_t)gid, (uint32_t)(gid >> 32), step, z);
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+        ns[k] = fmaf(z[k], N.tau, ns[k] * N.omtau);
+        a[k] = fminf(fmaxf(fmaf(N.gain, ns[k], a[k]), -1.0f), 1.0f);
+    }
 }
 
 struct FpvStepOut {

@@ -36,7 +36,9 @@ class _Batch:
 
     def __init__(self, params: DroneParams, num_envs: int, device: Any = "cuda:0", auto_reset: bool = False,
                  track_episodes: bool = False, with_accel: bool = False, with_done_bits: bool = False,
-                 fp16_state: bool = False, rounding_seed: int = 0, with_obs_aos: bool = False):
+                 fp16_state: bool = False, rounding_seed: int = 0, with_obs_aos: bool = False,
+                 stick_noise: bool = False, noise_seed: int = 0, drone_id_offset: int = 0,
+                 with_action_out: bool = False):
         if num_envs <= 0:
             raise ValueError("num_envs must be positive")
         self.params = params
@@ -52,7 +54,10 @@ class _Batch:
         self._handle = C.c_void_p()
         self.fp16_state = bool(fp16_state)
         self.rounding_seed = int(rounding_seed) & 0xFFFFFFFF
-        self._cparams = _lib.pack_params(params, auto_reset=auto_reset, fp16_state=self.fp16_state)
+        self.stick_noise = bool(stick_noise)
+        self._pack_kw = dict(fp16_state=self.fp16_state, stick_noise=self.stick_noise, noise_seed=noise_seed,
+                             drone_id_offset=drone_id_offset)
+        self._cparams = _lib.pack_params(params, auto_reset=auto_reset, **self._pack_kw)
         _lib.check(self._L.fpv_create(C.byref(self._cparams), self.n, dev_index, C.byref(self._handle)))
         f32 = dict(dtype=torch.float32, device=self.device)
         if self.fp16_state:
@@ -74,6 +79,9 @@ class _Batch:
             self.last_length = torch.zeros(self.n, dtype=torch.int32, device=self.device)
         else:
             self.ep_return = self.ep_length = self.last_return = self.last_length = None
+        # in-kernel EMA stick noise state (x_s per channel) and the action actually applied
+        self.noise_state = torch.zeros((4, self.ld), **f32) if self.stick_noise else None
+        self.action_out = torch.zeros((self.n, 4), **f32) if with_action_out else None
         # optional row-major [num_envs, 16] observation written by the kernel through an LDS transpose
         self.obs_aos = (torch.zeros((self.n, _lib.FPV_OBS_AOS_DIM), **f32) if with_obs_aos else None)
         self._bcast_action = None
@@ -92,6 +100,7 @@ class _Batch:
         b.wind[0] = b.wind[1] = b.wind[2] = 0.0
         b.state_h, b.rounding_seed = ptr(self.state_h), self.rounding_seed
         b.obs_aos = ptr(self.obs_aos)
+        b.noise_state, b.action_out = ptr(self.noise_state), ptr(self.action_out)
 
     def rows_f32(self, r0: int, r1: int) -> torch.Tensor:
         """[num_envs, r1-r0] fp32 values of state rows r0..r1-1 (fpv_abi.h row numbering), whatever the
@@ -111,7 +120,11 @@ class _Batch:
     def _stream(self) -> int:
         return torch.cuda.current_stream(self.device).cuda_stream
 
-    def _action_ptr(self, action: Any) -> int:
+    def _action_ptr(self, action: Any) -> Optional[int]:
+        if action is None:
+            if not self.stick_noise:
+                raise ValueError("action=None is only meaningful with stick_noise=True (pure noise sticks)")
+            return None
         if not torch.is_tensor(action):
             action = torch.as_tensor(np.asarray(action, dtype=np.float32), device=self.device)
         if action.dim() == 1:
@@ -128,12 +141,16 @@ class _Batch:
         self._keepalive = action
         return action.data_ptr()
 
+    def set_step_counter(self, step: int) -> None:
+        """Step index keying the stick-noise stream / stochastic rounding (counts launches from 0)."""
+        _lib.check(self._L.fpv_set_step_counter(self._handle, int(step) & 0xFFFFFFFF))
+
     def set_tuning(self, drones_per_lane: int = 0, block_threads: int = 0) -> None:
         _lib.check(self._L.fpv_set_tuning(self._handle, int(drones_per_lane), int(block_threads)))
 
     def set_params(self, params: DroneParams, auto_reset: Optional[bool] = None) -> None:
         flags_auto = bool(self._cparams.flags & _lib.FPV_FLAG_AUTO_RESET) if auto_reset is None else auto_reset
-        cp = _lib.pack_params(params, auto_reset=flags_auto, fp16_state=self.fp16_state)
+        cp = _lib.pack_params(params, auto_reset=flags_auto, **self._pack_kw)
         _lib.check(self._L.fpv_set_params(self._handle, C.byref(cp)))
         self.params, self._cparams = params, cp
 
@@ -174,22 +191,29 @@ class _Batch:
             b.wind[0], b.wind[1], b.wind[2] = float(wind[0]), float(wind[1]), float(wind[2])
         _lib.check(self._L.fpv_step(self._handle, C.byref(b), self._stream()))
 
-    def rollout(self, actions: torch.Tensor, wind: Optional[Sequence[float]] = None,
-                rewards: Optional[torch.Tensor] = None, dones: Optional[torch.Tensor] = None) -> None:
+    def rollout(self, actions: Optional[torch.Tensor], wind: Optional[Sequence[float]] = None,
+                rewards: Optional[torch.Tensor] = None, dones: Optional[torch.Tensor] = None,
+                steps: Optional[int] = None) -> None:
         """k steps back to back without returning to Python: actions [k, num_envs, 4] (one batch
-        per step) or [num_envs, 4] with `rewards`/`dones` of shape [k, num_envs] giving k."""
+        per step) or [num_envs, 4] with `rewards`/`dones` of shape [k, num_envs] (or `steps`) giving
+        k; actions=None with stick_noise=True runs `steps` steps of pure in-kernel noise sticks."""
         b = self._buf
-        if actions.dim() == 3:
+        if actions is None:
+            if not self.stick_noise or steps is None:
+                raise ValueError("actions=None needs stick_noise=True and steps=k")
+            k, stride = int(steps), 0
+        elif actions.dim() == 3:
             k, stride = actions.shape[0], self.n * 4
             if actions.shape[1:] != (self.n, 4):
                 raise ValueError(f"actions must be [k, {self.n}, 4]")
         else:
-            if rewards is None and dones is None:
-                raise ValueError("held-action rollouts need rewards/dones [k, num_envs] to define k")
-            k, stride = (rewards if rewards is not None else dones).shape[0], 0
-        if actions.dtype != torch.float32 or not actions.is_contiguous() or actions.device != self.state.device:
+            if rewards is None and dones is None and steps is None:
+                raise ValueError("held-action rollouts need rewards/dones [k, num_envs] or steps=k to define k")
+            k, stride = (int(steps) if steps is not None else (rewards if rewards is not None else dones).shape[0]), 0
+        if actions is not None and (actions.dtype != torch.float32 or not actions.is_contiguous()
+                                    or actions.device != self.state.device):
             raise ValueError("actions must be a contiguous float32 tensor on the env's device")
-        b.action = actions.data_ptr()
+        b.action = actions.data_ptr() if actions is not None else None
         if wind is not None:
             b.wind[0], b.wind[1], b.wind[2] = float(wind[0]), float(wind[1]), float(wind[2])
         out_stride = 0
@@ -273,7 +297,7 @@ class DroneBatch(_Batch):
         """Drone.step for every drone.  `object_list` must be empty (collision objects are outside
         the batched step) and the guidance overrides `rotation_matrix` / `thrust_force`
         (components.py:230-232) are not supported."""
-        if action is None:
+        if action is None and not self.stick_noise:
             raise ValueError("action=None reads a physical joystick in the reference; pass stick values")
         if len(object_list):
             raise NotImplementedError("collision objects are not part of the batched step (object_list must be empty)")

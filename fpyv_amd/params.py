@@ -130,6 +130,9 @@ class DroneParams:
     motor_radius: float = 0.1
     ground_spring: float = 100.0
     ground_damping: float = 0.0
+    # in-kernel stick noise (tests/noise_smooth_test.py:5-11): x_s <- (1 - tau) x_s + tau N(0,1)
+    noise_transition: float = 0.1
+    noise_gain: float = 1.0
 
     @property
     def init_quat(self) -> np.ndarray:

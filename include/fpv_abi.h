@@ -63,6 +63,10 @@ enum {
     FPV_FLAG_AUTO_RESET = 1u,   /* re-initialise a lane in-kernel when it reports done */
     FPV_FLAG_GROUND = 2u,       /* ground plane z = 0 in object_list: per-motor spring contact,
                                    Drone.handle_collisions with a Ground object (components.py:198-214) */
+    FPV_FLAG_STICK_NOISE = 8u,  /* drone mode, fp32 state: the kernel advances an EMA-smoothed Gaussian stick noise
+                                   per drone and channel (the profile of tests/noise_smooth_test.py:6-12, Philox4x32-10
+                                   keyed by seed / global drone id / step) and ADDS gain * noise to the action
+                                   (clipped to [-1,1]); fpv_buffers_t.action may then be NULL (pure noise sticks) */
     FPV_FLAG_FP16_STATE = 4u    /* drone mode only: v, q, prev_rates, prev_thrust stored as IEEE binary16 in
                                    fpv_buffers_t.state_h[11][ld]; fpv_buffers_t.state holds only the 3 position
                                    rows in fp32; arithmetic stays fp32 (BASELINE config 4) */
@@ -103,6 +107,10 @@ typedef struct fpv_params {
     double motor_radius;              /* contact starts at distance < motor_radius (components.py:121), m */
     double ground_spring;             /* N/m   (handle_collisions default 100, components.py:198) */
     double ground_damping;            /* N s/m (handle_collisions default 0) */
+    double noise_transition;          /* FPV_FLAG_STICK_NOISE: x_s <- (1-tau) x_s + tau N(0,1); noise_smooth_test.py:5 uses 0.1 */
+    double noise_gain;                /* sticks += noise_gain * x_s */
+    uint64_t noise_seed;              /* Philox key */
+    uint64_t drone_id_offset;         /* global id of this handle's drone 0 (shard offset): streams are keyed by global id */
 } fpv_params_t;
 
 /* Device buffers of one batch.  Only `state` is mandatory for fpv_reset; `state` and `action`
@@ -122,6 +130,8 @@ typedef struct fpv_buffers {
     float wind[3];           /* wind_velocity_vector of this step (kinematics.py:35: ADDED to v) */
     uint32_t rounding_seed;  /* FPV_FLAG_FP16_STATE: mixed with the handle's launch counter for the stochastic rounding */
     uint16_t* state_h;       /* FPV_FLAG_FP16_STATE: [FPV_HALF_ROWS][ld] binary16, 8-byte aligned; else unused */
+    float* noise_state;      /* FPV_FLAG_STICK_NOISE: [4][ld] EMA stick-noise state (read-modify-write); else unused */
+    float* action_out;       /* [n][4] the action actually applied (after noise and clipping), 16-byte aligned, or NULL */
     float* obs_aos;          /* [n][FPV_OBS_AOS_DIM] row-major observation per drone, 16-byte aligned, or NULL:
                                 p3, v3, q4 (wxyz), prev_rates3, R_new@acc 3 - the values Drone.step returns
                                 (components.py:247-248) gathered in one row; drone mode, fp32 state only */
@@ -157,6 +167,10 @@ int fpv_step(fpv_handle_t h, const fpv_buffers_t* b, void* stream);
  * non-zero, writes reward/done at + t*out_stride elements. */
 int fpv_rollout(fpv_handle_t h, const fpv_buffers_t* b, int k, int64_t action_stride,
                 int64_t out_stride, void* stream);
+
+/* The step index that keys the stick-noise stream (and the stochastic rounding) counts launches of a
+ * handle from 0; set it to resume / replay a run. */
+int fpv_set_step_counter(fpv_handle_t h, uint32_t step);
 
 /* Replace the drone type of a live handle (e.g. domain randomisation between episodes). */
 int fpv_set_params(fpv_handle_t h, const fpv_params_t* params);

@@ -123,3 +123,28 @@ extern "C" int fpvl_run_h(const fpv_params_t* P, int64_t n, int steps, float* po
 // conversion helpers exposed for the unit tests
 extern "C" uint16_t fpvl_f32_to_f16(float x, uint32_t rnd13, int stochastic) { return stochastic ? fpv_f32_to_f16_sr(x, rnd13) : fpv_f32_to_f16_rn(x); }
 extern "C" float fpvl_f16_to_f32(uint16_t h) { return fpv_f16_to_f32(h); }
+
+// stick-noise generator on the host: ns [4][ld] EMA state advanced `steps` times from step index
+// step0; applied [steps][n][4] receives clip(base + gain * x_s) (base = 0 when base_actions is NULL)
+extern "C" int fpvl_stick_noise(const fpv_params_t* P, int64_t n, int steps, float* ns, int64_t ld,
+                                const float* base_actions, float* applied, uint32_t step0)
+{
+    FpvK K;
+    bool big = false;
+    const char* why = "";
+    const int rc = fpv_derive_constants(P, &K, &big, &why);
+    if (rc != FPV_OK) return rc;
+    for (int t = 0; t < steps; ++t)
+        for (int64_t i = 0; i < n; ++i) {
+            float s[4], a[4];
+            for (int k = 0; k < 4; ++k) { s[k] = ns[k * ld + i]; a[k] = base_actions ? base_actions[((int64_t)t * n + i) * 4 + k] : 0.0f; }
+            fpv_stick_noise(K.noise, step0 + (uint32_t)t, (uint64_t)i, s, a);
+            for (int k = 0; k < 4; ++k) { ns[k * ld + i] = s[k]; if (applied) applied[((int64_t)t * n + i) * 4 + k] = a[k]; }
+        }
+    return FPV_OK;
+}
+
+extern "C" void fpvl_philox(const uint32_t ctr[4], const uint32_t key[2], uint32_t out[4])
+{
+    fpv_philox4x32_10(ctr[0], ctr[1], ctr[2], ctr[3], key[0], key[1], out);
+}

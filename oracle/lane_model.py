@@ -117,3 +117,29 @@ def split_half(state: np.ndarray):
 
 def join_half(pos: np.ndarray, sh: np.ndarray) -> np.ndarray:
     return np.concatenate([pos, sh.view(np.float16).astype(np.float32)], axis=0)
+
+
+def stick_noise(p, n: int, steps: int, noise_seed: int = 0, drone_id_offset: int = 0, base_actions=None,
+                step0: int = 0, ns: Optional[np.ndarray] = None):
+    """Host build of the in-kernel generator.  Returns (applied [steps, n, 4] fp32, ns [4, ld] fp32)."""
+    L = lib()
+    L.fpvl_stick_noise.argtypes = [C.POINTER(abi.FpvParams), C.c_int64, C.c_int, C.POINTER(C.c_float), C.c_int64,
+                                   C.c_void_p, C.POINTER(C.c_float), C.c_uint32]
+    L.fpvl_stick_noise.restype = C.c_int
+    ld = (n + 63) // 64 * 64 if ns is None else ns.shape[1]
+    ns = np.zeros((4, ld), dtype=np.float32) if ns is None else ns
+    applied = np.zeros((steps, n, 4), dtype=np.float32)
+    base = None if base_actions is None else np.ascontiguousarray(base_actions, dtype=np.float32)
+    cp = abi.pack_params(p, stick_noise=True, noise_seed=noise_seed, drone_id_offset=drone_id_offset)
+    fp = lambda a: a.ctypes.data_as(C.POINTER(C.c_float))  # noqa: E731
+    rc = L.fpvl_stick_noise(C.byref(cp), n, steps, fp(ns), ld, None if base is None else base.ctypes.data, fp(applied), step0)
+    if rc != 0:
+        raise RuntimeError(f"fpvl_stick_noise failed with {rc}")
+    return applied, ns
+
+
+def philox(ctr, key):
+    L = lib()
+    out = (C.c_uint32 * 4)()
+    L.fpvl_philox((C.c_uint32 * 4)(*ctr), (C.c_uint32 * 2)(*key), out)
+    return [int(x) for x in out]

@@ -1,0 +1,53 @@
+"""Philox4x32-10 (Salmon, Moraes, Dror, Shaw - "Parallel random numbers: as easy as 1, 2, 3", SC'11)
+in NumPy, and the EMA stick-noise profile built on it, as a float64 checker of the in-kernel
+generator (fpyv_amd/csrc/fpv_math.h: fpv_philox4x32_10 / fpv_normal4 / fpv_stick_noise).
+
+TEST INFRASTRUCTURE ONLY.  The integer generator is pinned by the known-answer vectors of the
+Random123 distribution (tests/test_stick_noise.py); the float part follows
+/root/reference/tests/noise_smooth_test.py:6-12 (x ~ N(0,1); x_s <- (1-tau) x_s + tau x).
+"""
+import numpy as np
+
+M0, M1 = np.uint64(0xD2511F53), np.uint64(0xCD9E8D57)
+W0, W1 = np.uint32(0x9E3779B9), np.uint32(0xBB67AE85)
+
+
+def philox4x32_10(ctr, key):
+    """ctr: [..., 4] uint32, key: [..., 2] uint32 -> [..., 4] uint32"""
+    c = [np.asarray(ctr[..., i], dtype=np.uint32).copy() for i in range(4)]
+    k0, k1 = np.asarray(key[..., 0], dtype=np.uint32).copy(), np.asarray(key[..., 1], dtype=np.uint32).copy()
+    for _ in range(10):
+        p0 = M0 * c[0].astype(np.uint64)
+        p1 = M1 * c[2].astype(np.uint64)
+        n0 = (p1 >> np.uint64(32)).astype(np.uint32) ^ c[1] ^ k0
+        n2 = (p0 >> np.uint64(32)).astype(np.uint32) ^ c[3] ^ k1
+        c = [n0, p1.astype(np.uint32), n2, p0.astype(np.uint32)]
+        k0 = (k0 + W0).astype(np.uint32)
+        k1 = (k1 + W1).astype(np.uint32)
+    return np.stack(c, axis=-1)
+
+
+def normal4(seed, drone_ids, step):
+    """[n, 4] float64 standard normals for global drone ids `drone_ids` at step index `step`."""
+    ids = np.asarray(drone_ids, dtype=np.uint64)
+    n = ids.shape[0]
+    ctr = np.stack([(ids & np.uint64(0xFFFFFFFF)).astype(np.uint32), (ids >> np.uint64(32)).astype(np.uint32),
+                    np.full(n, step, dtype=np.uint32), np.zeros(n, dtype=np.uint32)], axis=-1)
+    key = np.broadcast_to(np.array([seed & 0xFFFFFFFF, (seed >> 32) & 0xFFFFFFFF], dtype=np.uint32), (n, 2))
+    r = philox4x32_10(ctr, key)
+    u = ((r >> np.uint32(8)).astype(np.float64) + 0.5) * 2.0 ** -24
+    ra, rb = np.sqrt(-2 * np.log(u[:, 0])), np.sqrt(-2 * np.log(u[:, 2]))
+    return np.stack([ra * np.cos(2 * np.pi * u[:, 1]), ra * np.sin(2 * np.pi * u[:, 1]),
+                     rb * np.cos(2 * np.pi * u[:, 3]), rb * np.sin(2 * np.pi * u[:, 3])], axis=-1)
+
+
+def ema_sticks(seed, drone_ids, steps, tau=0.1, gain=1.0, base_action=None, step0=0):
+    """[steps, n, 4] applied sticks and the final EMA state [n, 4] (float64)."""
+    n = len(drone_ids)
+    s = np.zeros((n, 4))
+    out = np.empty((steps, n, 4))
+    for t in range(steps):
+        s = s * (1 - tau) + normal4(seed, drone_ids, step0 + t) * tau
+        a = 0.0 if base_action is None else base_action[t]
+        out[t] = np.clip(a + gain * s, -1.0, 1.0)
+    return out, s

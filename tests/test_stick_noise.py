@@ -1,0 +1,101 @@
+"""In-kernel stick-noise generator: Philox4x32-10 pinned by the Random123
+known-answer vectors, the EMA profile of /root/reference/tests/noise_smooth_test.py:6-12 checked
+against a float64 NumPy restatement (oracle/philox.py), shard / batch invariance, and - on the GPU -
+the kernel against both."""
+import numpy as np
+import pytest
+
+from fpyv_amd import load_params
+from oracle import lane_model, philox
+
+KAT = [  # Random123 kat_vectors, philox4x32-10: counter, key, expected
+    ([0, 0, 0, 0], [0, 0], [0x6627e8d5, 0xe169c58d, 0xbc57ac4c, 0x9b00dbd8]),
+    ([0xffffffff] * 4, [0xffffffff] * 2, [0x408f276d, 0x41c83b0e, 0xa20bc7c6, 0x6d5451fd]),
+    ([0x243f6a88, 0x85a308d3, 0x13198a2e, 0x03707344], [0xa4093822, 0x299f31d0],
+     [0xd16cfe09, 0x94fdcceb, 0x5001e420, 0x24126ea1]),
+]
+
+
+@pytest.mark.parametrize("ctr,key,want", KAT)
+def test_philox_known_answers(ctr, key, want):
+    got_np = philox.philox4x32_10(np.array([ctr], dtype=np.uint32), np.array([key], dtype=np.uint32))[0]
+    assert [int(x) for x in got_np] == want
+    assert lane_model.philox(ctr, key) == want          # the header the kernel compiles
+
+
+def test_ema_profile_matches_float64_restatement():
+    p = load_params(fps=1000)
+    n, steps, seed, off = 300, 400, 0x1234_5678_9abc_def0, (1 << 33) + 17
+    applied, ns = lane_model.stick_noise(p, n, steps, noise_seed=seed, drone_id_offset=off)
+    ref, ref_s = philox.ema_sticks(seed, off + np.arange(n, dtype=np.uint64), steps)
+    assert np.abs(applied - ref).max() < 3e-6
+    assert np.abs(ns[:, :n].T - ref_s).max() < 3e-6
+    # the profile itself: zero mean, stationary sigma = sqrt(tau / (2 - tau)) = 0.2294 (noise_smooth_test.py)
+    tail = applied[200:].reshape(-1)
+    assert abs(tail.mean()) < 5e-3 and abs(tail.std() - np.sqrt(0.1 / 1.9)) < 5e-3
+    assert np.abs(applied).max() <= 1.0
+
+
+def test_streams_depend_only_on_global_id_and_step():
+    p = load_params(fps=1000)
+    whole, _ = lane_model.stick_noise(p, 256, 50, noise_seed=9)
+    shard, _ = lane_model.stick_noise(p, 128, 50, noise_seed=9, drone_id_offset=128)
+    assert np.array_equal(whole[:, 128:], shard), "a shard must reproduce its slice of the global batch"
+    # resuming at step 20 with the saved EMA state continues the same stream
+    first, ns = lane_model.stick_noise(p, 64, 20, noise_seed=9)
+    rest, _ = lane_model.stick_noise(p, 64, 30, noise_seed=9, step0=20, ns=ns)
+    assert np.array_equal(np.concatenate([first, rest]), whole[:, :64])
+    other, _ = lane_model.stick_noise(p, 64, 50, noise_seed=10)
+    assert not np.array_equal(other, whole[:, :64])
+
+
+def test_noise_added_to_policy_action_and_clipped():
+    p = load_params(fps=1000).replace(noise_gain=2.0)
+    base = np.full((30, 16, 4), 0.9, dtype=np.float32)
+    applied, _ = lane_model.stick_noise(p, 16, 30, noise_seed=1, base_actions=base)
+    ref, _ = philox.ema_sticks(1, np.arange(16, dtype=np.uint64), 30, gain=2.0, base_action=base.astype(np.float64))
+    assert np.abs(applied - ref).max() < 5e-6 and applied.max() == 1.0
+
+
+@pytest.mark.gpu
+def test_kernel_stick_noise_vs_references():
+    import torch
+    from fpyv_amd.env import DroneBatch
+    from oracle import oracle
+    from parity import assert_parity, soa_vs_oracle
+    p = load_params(fps=1000)
+    n, steps, seed, off = 1000, 200, 77, 5000
+    env = DroneBatch(p, n, device="cuda:0", stick_noise=True, noise_seed=seed, drone_id_offset=off,
+                     with_action_out=True, with_accel=False)
+    env.reset()
+    applied = np.zeros((steps, n, 4), dtype=np.float32)
+    for t in range(steps):
+        env.step(None, return_imu=False)                  # pure noise sticks
+        applied[t] = env.action_out.cpu().numpy()
+    ref, ref_s = philox.ema_sticks(seed, off + np.arange(n, dtype=np.uint64), steps)
+    assert np.abs(applied - ref).max() < 5e-6
+    assert np.abs(env.noise_state[:, :n].t().cpu().numpy() - ref_s).max() < 5e-6
+    host, _ = lane_model.stick_noise(p, n, steps, noise_seed=seed, drone_id_offset=off)
+    assert np.abs(applied - host).max() < 2e-6            # device libm vs host libm in log/sincos only
+    # physics driven by those sticks == oracle driven by the recorded applied actions
+    st = oracle.drone_initial_state(n, p.init_position, p.init_velocity, [0, 0, 0])
+    oracle.drone_run(p, st, applied.astype(np.float64), threads=0)
+    assert_parity(soa_vs_oracle(env.state.cpu().numpy(), st, n), 1e-5, "noise-driven flight")
+    # policy action + noise, via rollout; and reset clears the EMA state of the masked lanes
+    env2 = DroneBatch(p.replace(noise_gain=0.5), n, device="cuda:0", stick_noise=True, noise_seed=seed,
+                      with_action_out=True, with_accel=False)
+    env2.reset()
+    base = torch.full((10, n, 4), 0.2, device="cuda:0")
+    env2.rollout(base)
+    ref2, _ = philox.ema_sticks(seed, np.arange(n, dtype=np.uint64), 10, gain=0.5,
+                                base_action=np.full((10, n, 4), 0.2))
+    assert np.abs(env2.action_out.cpu().numpy() - ref2[-1]).max() < 5e-6
+    mask = np.zeros(n, dtype=np.uint8); mask[::3] = 1
+    env2.reset(mask=mask)
+    ns = env2.noise_state[:, :n].cpu().numpy()
+    assert np.all(ns[:, ::3] == 0) and np.all(ns[:, 1::3] != 0)
+    env3 = DroneBatch(p, n, device="cuda:0", stick_noise=True, noise_seed=seed, with_accel=False)
+    env3.reset()
+    env3.rollout(None, steps=5)
+    with pytest.raises(ValueError):
+        DroneBatch(p, 8, device="cuda:0").step(None)

@@ -25,6 +25,7 @@ def main():
                     help="<drones per lane>x<threads per workgroup>")
     ap.add_argument("--fp16", action="store_true", help="also time the fp16-storage kernel (config 4, 89 B/env-step)")
     ap.add_argument("--aos", action="store_true", help="also time the step with the [n,16] AoS observation head")
+    ap.add_argument("--noise", action="store_true", help="also time pure in-kernel noise sticks (no action read)")
     ap.add_argument("--out", default=None)
     a = ap.parse_args()
     dev = torch.device("cuda:0")
@@ -47,6 +48,11 @@ def main():
         ea.reset()
         envs["aos1x128"] = envs["aos1x256"] = ea
         a.geom = list(a.geom) + ["aos1x128", "aos1x256"]
+    if a.noise:
+        en = DroneBatch(p, a.n, device=dev, with_accel=False, stick_noise=True, noise_seed=1)
+        en.reset()
+        envs["noise1x128"] = en
+        a.geom = list(a.geom) + ["noise1x128"]
     variants = [(g, api) for g in a.geom for api in ("rollout", "step")]
     times = {v: [] for v in variants}
     ev0, ev1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
@@ -54,13 +60,19 @@ def main():
         for v in variants:
             d, api = v
             e = envs[d]
-            e.set_tuning(*[int(x) for x in d.replace("aos", "").lstrip("h").split("x")])
+            e.set_tuning(*[int(x) for x in d.replace("aos", "").replace("noise", "").lstrip("h").split("x")])
             torch.cuda.synchronize()
             ev0.record()
             done = 0
             while done < a.launches:
                 span = min(a.ring, a.launches - done)
-                if api == "rollout":
+                if d.startswith("noise"):
+                    if api == "rollout":
+                        e.rollout(None, steps=span)
+                    else:
+                        for t in range(span):
+                            e.step(None, return_imu=False)
+                elif api == "rollout":
                     e.rollout(acts[:span])
                 else:
                     for t in range(span):
@@ -72,7 +84,7 @@ def main():
                 times[v].append(ev0.elapsed_time(ev1) * 1e3 / a.launches)
     res = []
     for v in variants:
-        B = envs[v[0]].algorithmic_bytes() + (64 if v[0].startswith("aos") else 0)
+        B = envs[v[0]].algorithmic_bytes() + (64 if v[0].startswith("aos") else 0) + (16 if v[0].startswith("noise") else 0)
         med, mn = statistics.median(times[v]), min(times[v])
         res.append({"geom": v[0], "api": v[1], "median_us": med, "min_us": mn,
                     "GBps_alg_median": B * a.n / med / 1e3, "env_steps_per_s_median": a.n / med * 1e6})
