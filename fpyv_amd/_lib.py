@@ -55,13 +55,40 @@ class FpvParams(C.Structure):
     ]
 
 
+FPV_MAX_OBJECTS = 8
+OBJ_GROUND, OBJ_CYLINDER, OBJ_SPHERE = 0, 1, 2
+
+
+class FpvObject(C.Structure):
+    _fields_ = [("type", C.c_int32), ("x", C.c_float), ("y", C.c_float), ("z", C.c_float),
+                ("radius", C.c_float), ("height", C.c_float)]
+
+
+class FpvObjects(C.Structure):
+    _fields_ = [("count", C.c_int32), ("obj", FpvObject * FPV_MAX_OBJECTS)]
+
+
+def pack_objects(objects) -> FpvObjects:
+    """sequence of (type, x, y, z, radius, height) in object_list order -> fpv_objects_t"""
+    objs = list(objects)
+    if len(objs) > FPV_MAX_OBJECTS:
+        raise ValueError(f"at most {FPV_MAX_OBJECTS} collision objects")
+    t = FpvObjects()
+    t.count = len(objs)
+    for k, o in enumerate(objs):
+        t.obj[k].type = int(o[0])
+        t.obj[k].x, t.obj[k].y, t.obj[k].z = float(o[1]), float(o[2]), float(o[3])
+        t.obj[k].radius, t.obj[k].height = float(o[4]), float(o[5])
+    return t
+
+
 class FpvBuffers(C.Structure):
     _fields_ = [
         ("state", C.c_void_p), ("ld", C.c_int64), ("action", C.c_void_p), ("reward", C.c_void_p),
         ("done", C.c_void_p), ("done_bits", C.c_void_p), ("accel", C.c_void_p), ("ep_return", C.c_void_p),
         ("ep_length", C.c_void_p), ("last_return", C.c_void_p), ("last_length", C.c_void_p),
         ("wind", C.c_float * 3), ("rounding_seed", C.c_uint32), ("state_h", C.c_void_p),
-        ("noise_state", C.c_void_p), ("action_out", C.c_void_p), ("obs_aos", C.c_void_p),
+        ("noise_state", C.c_void_p), ("action_out", C.c_void_p), ("objects", C.c_void_p), ("obs_aos", C.c_void_p),
     ]
 
 

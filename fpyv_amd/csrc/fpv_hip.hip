@@ -49,6 +49,7 @@ struct FpvBufD {
     float* noise_state;    // FPV_FLAG_STICK_NOISE: [4][ld] EMA stick-noise state
     float4* action_out;    // [n] applied action or null
     uint32_t step;         // launch index of the handle: Philox counter word
+    FpvObjects objs;       // the step's object_list (count 0 = none); only the OBJ instantiation reads it
     uint16_t* state_h;     // FPV_FLAG_FP16_STATE: [11][ld] binary16 rows (v, q, rates, thrust)
     uint32_t seed;         // stochastic-rounding seed of this launch
 };
@@ -124,7 +125,7 @@ __device__ __forceinline__ float4 apply_stick_noise(const FpvK& K, const FpvBufD
     return r;
 }
 
-template <int BS, int DPL, bool BIG, bool NOISE = false>
+template <int BS, int DPL, bool BIG, bool NOISE = false, bool OBJ = false>
 __global__ __launch_bounds__(BS) void fpv_drone_step_kernel(const FpvK K, const FpvBufD B, const int64_t n)
 {
     const int64_t base = (int64_t)blockIdx.x * (BS * DPL) + threadIdx.x;
@@ -148,7 +149,7 @@ __global__ __launch_bounds__(BS) void fpv_drone_step_kernel(const FpvK K, const 
         FpvStepOut o;
         o.done = false; o.reward = 0.0f; o.ax = o.ay = o.az = 0.0f;
         if (live[j]) {
-            o = fpv_drone_step_lane<BIG>(K, s[j], a[j].x, a[j].y, a[j].z, a[j].w, B.wx, B.wy, B.wz);
+            o = fpv_drone_step_lane<BIG, OBJ>(K, s[j], a[j].x, a[j].y, a[j].z, a[j].w, B.wx, B.wy, B.wz, &B.objs);
             if (B.accel) {
                 B.accel[0 * B.ld + i] = o.ax; B.accel[1 * B.ld + i] = o.ay; B.accel[2 * B.ld + i] = o.az;
             }
@@ -208,18 +209,6 @@ __global__ __launch_bounds__(BS) void fpv_drone_step_aos_kernel(const FpvK K, co
 
 // fp16-storage variant (BASELINE config 4): position rows fp32, the other 11 rows binary16.
 // 89 algorithmic bytes per env-step instead of 133; arithmetic and the lane function are unchanged.
-__device__ __forceinline__ void ld_drone_h(const FpvBufD& B, int64_t i, FpvDroneState& s)
-{
-    s.px = B.state[0 * B.ld + i]; s.py = B.state[1 * B.ld + i]; s.pz = B.state[2 * B.ld + i];
-    FpvHalfState h;
-    const uint16_t* __restrict__ sh = B.state_h;
-    h.v[0] = sh[0 * B.ld + i]; h.v[1] = sh[1 * B.ld + i]; h.v[2] = sh[2 * B.ld + i];
-    h.q[0] = sh[3 * B.ld + i]; h.q[1] = sh[4 * B.ld + i]; h.q[2] = sh[5 * B.ld + i]; h.q[3] = sh[6 * B.ld + i];
-    h.r[0] = sh[7 * B.ld + i]; h.r[1] = sh[8 * B.ld + i]; h.r[2] = sh[9 * B.ld + i];
-    h.t = sh[10 * B.ld + i];
-    fpv_unpack_half(h, s);
-}
-
 __device__ __forceinline__ void st_drone_h(const FpvBufD& B, int64_t i, const FpvDroneState& s)
 {
     B.state[0 * B.ld + i] = s.px; B.state[1 * B.ld + i] = s.py; B.state[2 * B.ld + i] = s.pz;
@@ -460,6 +449,15 @@ int check_buffers(const fpv_env* h, const fpv_buffers_t* b, bool need_action)  /
     if (((uintptr_t)b->state & 15) || ((uintptr_t)b->action & 15))
         return fail(FPV_EALIGN, "state and action must be 16-byte aligned");
     if ((uintptr_t)b->done_bits & 7) return fail(FPV_EALIGN, "done_bits must be 8-byte aligned");
+    if (b->objects && b->objects->count != 0) {
+        if (b->objects->count < 0 || b->objects->count > FPV_MAX_OBJECTS) return fail(FPV_EINVAL, "objects.count out of range");
+        if (h->mode != FPV_MODE_DRONE || (h->K.flags & (FPV_FLAG_FP16_STATE | FPV_FLAG_STICK_NOISE | FPV_FLAG_GROUND)) || b->obs_aos)
+            return fail(FPV_EINVAL, "objects need drone mode with fp32 state and cannot be combined with "
+                                    "FPV_FLAG_GROUND (use a Ground entry), stick noise or obs_aos");
+        for (int k = 0; k < b->objects->count; ++k)
+            if (b->objects->obj[k].type < FPV_OBJ_GROUND || b->objects->obj[k].type > FPV_OBJ_SPHERE)
+                return fail(FPV_EINVAL, "unknown object type");
+    }
     if (b->obs_aos) {
         if (h->mode != FPV_MODE_DRONE || (h->K.flags & FPV_FLAG_FP16_STATE))
             return fail(FPV_EINVAL, "obs_aos is available in drone mode with fp32 state only");
@@ -486,6 +484,15 @@ FpvBufD to_device_view(const fpv_buffers_t* b)
     d.wx = b->wind[0]; d.wy = b->wind[1]; d.wz = b->wind[2];
     d.state_h = b->state_h; d.seed = b->rounding_seed; d.obs_aos = b->obs_aos;
     d.noise_state = b->noise_state; d.action_out = reinterpret_cast<float4*>(b->action_out); d.step = 0;
+    d.objs.count = 0;
+    if (b->objects) {
+        d.objs.count = b->objects->count;
+        for (int k = 0; k < d.objs.count && k < FPV_MAX_OBJECTS; ++k) {
+            const fpv_object_t& o = b->objects->obj[k];
+            d.objs.o[k].type = o.type; d.objs.o[k].x = o.x; d.objs.o[k].y = o.y; d.objs.o[k].z = o.z;
+            d.objs.o[k].radius = o.radius; d.objs.o[k].height = o.height;
+        }
+    }
     return d;
 }
 
@@ -549,6 +556,16 @@ int launch_step(fpv_env* h, const FpvBufD& d_in, hipStream_t s)
         } else {
             if (h->big_angle) hipLaunchKernelGGL((fpv_drone_step_kernel<128, 1, true, true>), grid, dim3(128), 0, s, h->K, d, h->n);
             else hipLaunchKernelGGL((fpv_drone_step_kernel<128, 1, false, true>), grid, dim3(128), 0, s, h->K, d, h->n);
+        }
+    } else if (h->mode == FPV_MODE_DRONE && d.objs.count > 0) {
+        const int bs = h->block;
+        const dim3 grid((unsigned)((h->n + bs - 1) / bs));
+        if (bs == 256) {
+            if (h->big_angle) hipLaunchKernelGGL((fpv_drone_step_kernel<256, 1, true, false, true>), grid, dim3(256), 0, s, h->K, d, h->n);
+            else hipLaunchKernelGGL((fpv_drone_step_kernel<256, 1, false, false, true>), grid, dim3(256), 0, s, h->K, d, h->n);
+        } else {
+            if (h->big_angle) hipLaunchKernelGGL((fpv_drone_step_kernel<128, 1, true, false, true>), grid, dim3(128), 0, s, h->K, d, h->n);
+            else hipLaunchKernelGGL((fpv_drone_step_kernel<128, 1, false, false, true>), grid, dim3(128), 0, s, h->K, d, h->n);
         }
     } else if (h->mode == FPV_MODE_DRONE && d.obs_aos) {
         const dim3 grid((unsigned)((h->n + h->block - 1) / h->block));

@@ -296,9 +296,72 @@ struct FpvStepOut {
     bool done;          // ground flag (reference) OR ceiling (build), before any auto-reset
 };
 
-template <bool BIG>
+// ------------------------------------------------------------------------------------------------
+// object_list collisions (components.py:198-214) for a short ordered table of analytic objects:
+// Ground plane z = 0 (:674-680), Cylinder (:710-729, as written) and Target sphere (:774-778).
+// Per object: distances of the four motors; if any is negative the drone has crashed and the pass
+// stops, keeping the forces of EARLIER objects; otherwise every motor closer than motor_radius adds
+// the spring force (-k (d - r_m) - c v.n) n (kinematics.py:56-59).  Forces come back divided by m.
+// ------------------------------------------------------------------------------------------------
+#ifndef FPV_MAX_OBJECTS
+#define FPV_MAX_OBJECTS 8
+#endif
+struct FpvObject { int32_t type; float x, y, z, radius, height; };      // type: 0 Ground, 1 Cylinder, 2 Target
+struct FpvObjects { int32_t count; FpvObject o[FPV_MAX_OBJECTS]; };
+
+FPV_HD bool fpv_collide_objects(const FpvK& K, const FpvObjects& T, const float mx[4], const float my[4],
+                                const float mz[4], float vx, float vy, float vz, float acc[3])
+{
+    bool crashed = false;
+    acc[0] = acc[1] = acc[2] = 0.0f;
+    for (int o = 0; o < T.count && !crashed; ++o) {
+        const FpvObject& ob = T.o[o];
+        float dist[4], nx[4], ny[4], nz[4];
+#pragma unroll
+        for (int m = 0; m < 4; ++m) {
+            const float rx = mx[m] - ob.x, ry = my[m] - ob.y, rz = mz[m] - ob.z;
+            if (ob.type == 0) {
+                dist[m] = mz[m]; nx[m] = 0.0f; ny[m] = 0.0f; nz[m] = 1.0f;
+            } else if (ob.type == 1) {
+                const float rr = sqrtf(fmaf(rx, rx, ry * ry));
+                const float d2 = rr - ob.radius;
+                const float top = ob.z + ob.height;
+                if (ob.z < mz[m] && mz[m] < top) dist[m] = d2;
+                else {
+                    const float dh = fminf(fabsf(mz[m] - ob.z), fabsf(mz[m] - top));
+                    dist[m] = sqrtf(fmaf(d2, d2, dh * dh));
+                }
+                if (ob.z < rz && rz < top) {                       // relative z against absolute bounds, as written
+                    const float inv = 1.0f / rr;
+                    nx[m] = rx * inv; ny[m] = ry * inv; nz[m] = 0.0f;
+                } else {
+                    nx[m] = 0.0f; ny[m] = 0.0f;
+                    nz[m] = (fabsf(rz - ob.z) < fabsf(rz - top)) ? -1.0f : 1.0f;
+                }
+            } else {
+                const float rr = sqrtf(fmaf(rx, rx, fmaf(ry, ry, rz * rz)));
+                const float inv = 1.0f / rr;
+                dist[m] = rr - ob.radius;
+                nx[m] = rx * inv; ny[m] = ry * inv; nz[m] = rz * inv;
+            }
+        }
+        if (dist[0] < 0.0f || dist[1] < 0.0f || dist[2] < 0.0f || dist[3] < 0.0f) { crashed = true; break; }
+#pragma unroll
+        for (int m = 0; m < 4; ++m) {
+            const float d = dist[m] - K.motor_radius;
+            if (d < 0.0f) {
+                const float vn = fmaf(vx, nx[m], fmaf(vy, ny[m], vz * nz[m]));
+                const float f = fmaf(-K.ground_k_m, d, -K.ground_c_m * vn);
+                acc[0] = fmaf(f, nx[m], acc[0]); acc[1] = fmaf(f, ny[m], acc[1]); acc[2] = fmaf(f, nz[m], acc[2]);
+            }
+        }
+    }
+    return crashed;
+}
+
+template <bool BIG, bool OBJ = false>
 FPV_HD FpvStepOut fpv_drone_step_lane(const FpvK& K, FpvDroneState& s, float a0, float a1, float a2, float a3,
-                                      float wx, float wy, float wz)
+                                      float wx, float wy, float wz, const FpvObjects* objs = nullptr)
 {
     // (1)-(2) stick -> rate command (deg/s), clipped, low-passed          components.py:185-189
     const float c0 = fminf(fmaxf(-a0 * K.max_rates, -K.max_rates), K.max_rates);
@@ -324,8 +387,8 @@ FPV_HD FpvStepOut fpv_drone_step_lane(const FpvK& K, FpvDroneState& s, float a0,
     const float fz = -K.kdrag_m[2] * bz * speed;
     // (4) thrust along body z (third column), gravity; everything already divided by m
     const float tm = s.thrust * K.inv_mass;
-    const float accx = fmaf(R.r00, fx, fmaf(R.r01, fy, fmaf(R.r02, fz, tm * R.r02)));
-    const float accy = fmaf(R.r10, fx, fmaf(R.r11, fy, fmaf(R.r12, fz, tm * R.r12)));
+    float accx = fmaf(R.r00, fx, fmaf(R.r01, fy, fmaf(R.r02, fz, tm * R.r02)));
+    float accy = fmaf(R.r10, fx, fmaf(R.r11, fy, fmaf(R.r12, fz, tm * R.r12)));
     float accz = fmaf(R.r20, fx, fmaf(R.r21, fy, fmaf(R.r22, fz, fmaf(tm, R.r22, -K.g))));
 
     // ground flag: any motor below z = 0 on the PRE-update pose             components.py:235-240
@@ -342,6 +405,18 @@ FPV_HD FpvStepOut fpv_drone_step_lane(const FpvK& K, FpvDroneState& s, float a0,
         if (d < 0.0f) contact += fmaf(-K.ground_k_m, d, -K.ground_c_m * s.vz);   // kinematics.py:56-59, normal = +z
     }
     if ((K.flags & FPV_MATH_FLAG_GROUND) && !done) accz += contact;
+    if (OBJ) {                                               // general object_list replaces the ground-only pass
+        float mxw[4], myw[4], mzw[4], ca[3];
+#pragma unroll
+        for (int m = 0; m < 4; ++m) {
+            mxw[m] = s.px + fmaf(K.motor_x[m], R.r00, K.motor_y[m] * R.r01);
+            myw[m] = s.py + fmaf(K.motor_x[m], R.r10, K.motor_y[m] * R.r11);
+            mzw[m] = s.pz + fmaf(K.motor_x[m], R.r20, K.motor_y[m] * R.r21);
+        }
+        const bool crashed = fpv_collide_objects(K, *objs, mxw, myw, mzw, s.vx, s.vy, s.vz, ca);
+        accx += ca[0]; accy += ca[1]; accz += ca[2];
+        done = done || crashed;
+    }
 
     // (6) explicit Euler: p with the OLD v, then v                          kinematics.py:21-22
     s.px = fmaf(s.vx, K.dt, s.px); s.py = fmaf(s.vy, K.dt, s.py); s.pz = fmaf(s.vz, K.dt, s.pz);

@@ -184,6 +184,17 @@ class _Batch:
                                      self._stream()))
         self._keepalive_reset = (pos, vel, ang, m)
 
+    def _set_objects(self, object_list) -> None:
+        """Bind the step's object_list (host-side table, read by fpv_step during the call)."""
+        from .objects import to_rows
+        rows = to_rows(object_list) if object_list is not None and len(object_list) else ()
+        if rows:
+            self._objects = _lib.pack_objects(rows)
+            self._buf.objects = C.addressof(self._objects)
+        else:
+            self._objects = None
+            self._buf.objects = None
+
     def _step_raw(self, action: Any, wind: Optional[Sequence[float]] = None) -> None:
         b = self._buf
         b.action = self._action_ptr(action)
@@ -294,15 +305,15 @@ class DroneBatch(_Batch):
 
     def step(self, action, wind_velocity_vector=None, object_list=(), rotation_matrix=None, thrust_force=None,
              return_imu: bool = True):
-        """Drone.step for every drone.  `object_list` must be empty (collision objects are outside
-        the batched step) and the guidance overrides `rotation_matrix` / `thrust_force`
+        """Drone.step for every drone.  `object_list` holds up to 8 analytic collision objects
+        (fpyv_amd.objects.Ground / Cylinder / Target, or raw (type, x, y, z, radius, height) rows) in
+        the reference's list order; the guidance overrides `rotation_matrix` / `thrust_force`
         (components.py:230-232) are not supported."""
         if action is None and not self.stick_noise:
             raise ValueError("action=None reads a physical joystick in the reference; pass stick values")
-        if len(object_list):
-            raise NotImplementedError("collision objects are not part of the batched step (object_list must be empty)")
         if rotation_matrix is not None or thrust_force is not None:
             raise NotImplementedError("guidance overrides (rotation_matrix=, thrust_force=) are not supported")
+        self._set_objects(object_list)
         self._step_raw(action, wind_velocity_vector)
         if not return_imu:
             return None

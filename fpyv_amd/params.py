@@ -133,6 +133,9 @@ class DroneParams:
     # in-kernel stick noise (tests/noise_smooth_test.py:5-11): x_s <- (1 - tau) x_s + tau N(0,1)
     noise_transition: float = 0.1
     noise_gain: float = 1.0
+    # ordered object_list for the collision pass (components.py:198-214): tuples
+    # (type, x, y, z, radius, height) with type 0 = Ground, 1 = Cylinder, 2 = Target sphere; max 8
+    objects: tuple = ()
 
     @property
     def init_quat(self) -> np.ndarray:

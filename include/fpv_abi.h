@@ -113,6 +113,17 @@ typedef struct fpv_params {
     uint64_t drone_id_offset;         /* global id of this handle's drone 0 (shard offset): streams are keyed by global id */
 } fpv_params_t;
 
+/* Analytic collision objects = the reference's object_list (components.py:198-214) in list order.
+ * Ground: plane z = 0 (components.py:646-680); Cylinder: axis along +z from (x,y,z), radius, height
+ * (:685-729); Sphere: a Target (:753-778) - update x,y,z before each step for a moving target
+ * (simulator.py:87).  Gates and the Trail never collide in the reference (:202) and have no entry. */
+#ifndef FPV_MAX_OBJECTS
+#define FPV_MAX_OBJECTS 8
+#endif
+enum { FPV_OBJ_GROUND = 0, FPV_OBJ_CYLINDER = 1, FPV_OBJ_SPHERE = 2 };
+typedef struct fpv_object { int32_t type; float x, y, z, radius, height; } fpv_object_t;
+typedef struct fpv_objects { int32_t count; fpv_object_t obj[FPV_MAX_OBJECTS]; } fpv_objects_t;
+
 /* Device buffers of one batch.  Only `state` is mandatory for fpv_reset; `state` and `action`
  * for fpv_step.  NULL optional pointers skip that output. */
 typedef struct fpv_buffers {
@@ -132,6 +143,8 @@ typedef struct fpv_buffers {
     uint16_t* state_h;       /* FPV_FLAG_FP16_STATE: [FPV_HALF_ROWS][ld] binary16, 8-byte aligned; else unused */
     float* noise_state;      /* FPV_FLAG_STICK_NOISE: [4][ld] EMA stick-noise state (read-modify-write); else unused */
     float* action_out;       /* [n][4] the action actually applied (after noise and clipping), 16-byte aligned, or NULL */
+    const struct fpv_objects* objects; /* HOST pointer, read during the call: the step's object_list, or NULL.
+                                Drone mode, fp32 state; not combinable with FPV_FLAG_GROUND (put a Ground entry in the list) */
     float* obs_aos;          /* [n][FPV_OBS_AOS_DIM] row-major observation per drone, 16-byte aligned, or NULL:
                                 p3, v3, q4 (wxyz), prev_rates3, R_new@acc 3 - the values Drone.step returns
                                 (components.py:247-248) gathered in one row; drone mode, fp32 state only */

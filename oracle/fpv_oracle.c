@@ -122,6 +122,57 @@ void fpvo_drone_step(const fpvo_params* P, double* s, const double action[4], co
             }
         }
     }
+    /* general object_list: objects in list order; per object distances of all four motors first
+     * (components.py:203-204), then the per-motor loop whose first iteration returns on a crash,
+     * keeping the forces of EARLIER objects (:205-212).
+     *   Ground   distance = z, normal +z                         components.py:674-680
+     *   Cylinder distance/normal as written, incl. the relative-vs-absolute z test in
+     *            calculate_normal                                 components.py:710-729
+     *   Target   |p - c| - radius, radial normal                  components.py:774-778 */
+    if (P->n_objects > 0) {
+        coll[0] = coll[1] = coll[2] = 0;
+        done = 0;
+        for (int o = 0; o < P->n_objects && !done; ++o) {
+            const double cx = P->objects[o].x, cy = P->objects[o].y, cz = P->objects[o].z;
+            const double rad = P->objects[o].radius, hgt = P->objects[o].height;
+            double dist[4], nrm[4][3];
+            for (int m = 0; m < 4; ++m) {
+                const double* q = mpos[m];
+                if (P->objects[o].type == 0) {
+                    dist[m] = q[2]; nrm[m][0] = 0; nrm[m][1] = 0; nrm[m][2] = 1;
+                } else if (P->objects[o].type == 1) {
+                    const double d2 = sqrt((q[0] - cx) * (q[0] - cx) + (q[1] - cy) * (q[1] - cy)) - rad;
+                    if (cz < q[2] && q[2] < cz + hgt) dist[m] = d2;
+                    else {
+                        const double dh = fmin(fabs(q[2] - cz), fabs(q[2] - (cz + hgt)));
+                        dist[m] = sqrt(d2 * d2 + dh * dh);
+                    }
+                    const double rx = q[0] - cx, ry = q[1] - cy, rz = q[2] - cz;
+                    if (cz < rz && rz < cz + hgt) {
+                        const double nn = sqrt(rx * rx + ry * ry);
+                        nrm[m][0] = rx / nn; nrm[m][1] = ry / nn; nrm[m][2] = 0;
+                    } else {
+                        nrm[m][0] = 0; nrm[m][1] = 0;
+                        nrm[m][2] = (fabs(rz - cz) < fabs(rz - (cz + hgt))) ? -1 : 1;
+                    }
+                } else {
+                    const double rx = q[0] - cx, ry = q[1] - cy, rz = q[2] - cz;
+                    const double nn = sqrt(rx * rx + ry * ry + rz * rz);
+                    dist[m] = nn - rad;
+                    nrm[m][0] = rx / nn; nrm[m][1] = ry / nn; nrm[m][2] = rz / nn;
+                }
+            }
+            if (dist[0] < 0 || dist[1] < 0 || dist[2] < 0 || dist[3] < 0) { done = 1; break; }
+            for (int m = 0; m < 4; ++m) {
+                const double d = dist[m] - P->motor_radius;
+                if (d < 0) {
+                    const double vn = v[0] * nrm[m][0] + v[1] * nrm[m][1] + v[2] * nrm[m][2];
+                    const double f = -P->ground_spring * d - P->ground_damping * vn;
+                    for (int j = 0; j < 3; ++j) coll[j] += f * nrm[m][j];
+                }
+            }
+        }
+    }
     /* components.py:239-240: any motor below z = 0, evaluated on the PRE-update pose, not latched */
     for (int m = 0; m < 4; ++m)
         if (mpos[m][2] < 0.0) done = 1;

@@ -201,6 +201,51 @@ def main():
     save("g9_ground_contact", dt=1e-3, actions=a, init_position=ip, init_velocity=iv, init_ypr=io_,
          wind=np.zeros(3), **stack(cs))
 
+    # ---- G10: object_list = [moving Target, Cylinder, Cylinder, Ground] (simulator.py:85 order) ----
+    from utils.components import Cylinder, Target
+    cyl_a = Cylinder(np.array([3.0, 0.0, 0.0]), 1.0, 5.0, 4, 2, random=False)
+    cyl_b = Cylinder(np.array([-2.0, 2.5, 0.0]), 0.6, 1.5, 4, 2, random=False)
+    th = 0.68                                               # the target sphere touches this point ~0.25 s in
+    ip = np.array([[1.6, 0.0, 2.0], [0.0, 0.0, 2.0], [0.0, 0.05, 5.06], [-2.0, 1.72, 0.22],
+                   [1.5 * np.cos(th), -6.0 + 1.5 * np.sin(th), 3.0], [-2.0, 2.5, 1.9]])
+    iv = np.array([[0.45, 0.0, 0.0], [5.0, 0.0, 0.0], [3.2, 0.0, 0.0], [0.0, 0.2, -0.4], [0.0, 0.0, 0.0], [0.0, 0.0, -0.4]])
+    io_ = np.array([[0, 0, 0], [0, 10.0, 0], [0, 0, 0], [5.0, 0, 0], [0, 0, 0], [0, 0, 0.0]])
+    hov = -0.646                                            # thrust = weight at this stick
+    acts = np.array([[0, 0, 0, hov], [0, 0, 0, hov], [0, 0, 0, hov - 0.004], [0, 0, 0, hov - 0.01], [0, 0, 0, hov],
+                     [0, 0, 0, hov - 0.02]])
+    T10 = 800
+    a = np.stack([sticks.constant(T10, 1, x)[:, 0] for x in acts], axis=1)
+    cs, tpos = [], None
+    for k in range(len(acts)):
+        tgt = Target(np.array([0.0, -6.0, 3.0]), 0.8, 1, path={"radius": 1.5, "resolution": 20000})
+        objs = [tgt, cyl_a, cyl_b, ground]
+        T = a.shape[0]
+        rec = {kk: [] for kk in ("state", "R", "prev_rates", "prev_thrust", "accel")}
+        done = np.zeros(T, dtype=np.uint8)
+        tp = np.zeros((T, 3))
+        with contextlib.redirect_stdout(io.StringIO()):
+            d = Drone(copy.deepcopy(P1k))
+            d.reset(position=ip[k].astype(float), velocity=iv[k].astype(float), ypr=io_[k].astype(float))
+            for t in range(T):
+                tgt.update()                                   # simulator.py:87, before the step
+                tp[t] = tgt.position
+                ret = d.step(action=a[t, k].astype(np.float64), wind_velocity_vector=np.zeros(3), object_list=objs)
+                done[t] = bool(d.done)
+                rec["state"].append(d.state.copy()); rec["R"].append(d.rotation_matrix.copy())
+                rec["prev_rates"].append(np.asarray(d.prev_rates, float).copy())
+                rec["prev_thrust"].append(float(d.prev_thrust)); rec["accel"].append(np.asarray(ret[2], float).copy())
+        c = {kk: np.asarray(v) for kk, v in rec.items()}
+        c["done"] = done
+        c["snap_steps"] = np.arange(1, T + 1)
+        c["ret_RT"] = np.asarray(ret[0], float); c["ret_gyro"] = np.asarray(ret[1], float)
+        cs.append(c)
+        tpos = tp
+    save("g10_objects", dt=1e-3, actions=a, init_position=ip, init_velocity=iv, init_ypr=io_, wind=np.zeros(3),
+         target_positions=tpos, target_radius=0.8,
+         objects=np.array([[2, 0, -6.0, 3.0, 0.8, 0.0], [1, 3.0, 0.0, 0.0, 1.0, 5.0], [1, -2.0, 2.5, 0.0, 0.6, 1.5],
+                           [0, 0, 0, 0, 0, 0]], dtype=float),
+         **stack(cs))
+
     # ---- G7/G8: Racer (rate PID -> torque) ----
     def run_racer(actions, pid_values, stride=10):
         T = actions.shape[0]

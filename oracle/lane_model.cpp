@@ -16,6 +16,18 @@ extern "C" {
 
 // state: [rows][ld] SoA like the product.  actions: [steps][n][4] (per_step) or [n][4] held.
 // accel: [3][ld] or NULL; done/reward: [n] or NULL (last step's values).  Returns 0 or FPV_E*.
+static FpvObjects g_objs = {0, {}};
+
+// object_list used by subsequent fpvl_run calls (count 0 = none)
+void fpvl_set_objects(const fpv_objects_t* t)
+{
+    g_objs.count = t ? t->count : 0;
+    for (int k = 0; k < g_objs.count; ++k) {
+        g_objs.o[k].type = t->obj[k].type; g_objs.o[k].x = t->obj[k].x; g_objs.o[k].y = t->obj[k].y; g_objs.o[k].z = t->obj[k].z;
+        g_objs.o[k].radius = t->obj[k].radius; g_objs.o[k].height = t->obj[k].height;
+    }
+}
+
 int fpvl_run(const fpv_params_t* P, int64_t n, int steps, float* st, int64_t ld, const float* actions,
              int per_step, const float wind[3], float* accel, uint8_t* done, float* reward)
 {
@@ -35,8 +47,12 @@ int fpvl_run(const fpv_params_t* P, int64_t n, int steps, float* st, int64_t ld,
             FpvStepOut o = {0, 0, 0, 0, false};
             for (int t = 0; t < steps; ++t) {
                 const float* a = actions + ((per_step ? (int64_t)t * n : 0) + i) * 4;
-                o = big ? fpv_drone_step_lane<true>(K, s, a[0], a[1], a[2], a[3], wind[0], wind[1], wind[2])
-                        : fpv_drone_step_lane<false>(K, s, a[0], a[1], a[2], a[3], wind[0], wind[1], wind[2]);
+                if (g_objs.count > 0)
+                    o = big ? fpv_drone_step_lane<true, true>(K, s, a[0], a[1], a[2], a[3], wind[0], wind[1], wind[2], &g_objs)
+                            : fpv_drone_step_lane<false, true>(K, s, a[0], a[1], a[2], a[3], wind[0], wind[1], wind[2], &g_objs);
+                else
+                    o = big ? fpv_drone_step_lane<true>(K, s, a[0], a[1], a[2], a[3], wind[0], wind[1], wind[2])
+                            : fpv_drone_step_lane<false>(K, s, a[0], a[1], a[2], a[3], wind[0], wind[1], wind[2]);
                 if ((K.flags & FPV_FLAG_AUTO_RESET) && o.done) fpv_drone_reset_lane(K, s);
             }
             st[FPV_PX * ld + i] = s.px; st[FPV_PY * ld + i] = s.py; st[FPV_PZ * ld + i] = s.pz;

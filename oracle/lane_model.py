@@ -51,6 +51,17 @@ def initial_state(p, n: int, position=None, velocity=None, ypr_deg=None, ld: Opt
     return s
 
 
+def set_objects(rows) -> None:
+    """object_list (rows of (type, x, y, z, radius, height)) for subsequent run() calls; () clears it."""
+    L = lib()
+    L.fpvl_set_objects.argtypes = [C.c_void_p]
+    if rows:
+        t = abi.pack_objects(rows)
+        L.fpvl_set_objects(C.addressof(t))
+    else:
+        L.fpvl_set_objects(None)
+
+
 def run(p, state: np.ndarray, actions: np.ndarray, steps: Optional[int] = None, wind=(0.0, 0.0, 0.0),
         n: Optional[int] = None, auto_reset: bool = False) -> Tuple[np.ndarray, np.ndarray, np.ndarray, np.ndarray]:
     """Advance the SoA fp32 `state` in place.  Returns (state, accel [3,ld], done [n], reward [n])."""

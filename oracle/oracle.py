@@ -20,6 +20,11 @@ DRONE_STATE = 19
 RACER_STATE = 20
 
 
+class OracleObject(C.Structure):
+    _fields_ = [("type", C.c_int32), ("_p", C.c_int32), ("x", C.c_double), ("y", C.c_double), ("z", C.c_double),
+                ("radius", C.c_double), ("height", C.c_double)]
+
+
 class OracleParams(C.Structure):
     _fields_ = [
         ("dt", C.c_double), ("gravity", C.c_double), ("mass", C.c_double), ("max_rates", C.c_double),
@@ -33,6 +38,7 @@ class OracleParams(C.Structure):
         ("racer_velocity_damping", C.c_double),
         ("racer_omega_dt", C.c_int32), ("ground", C.c_int32),
         ("motor_radius", C.c_double), ("ground_spring", C.c_double), ("ground_damping", C.c_double),
+        ("n_objects", C.c_int32), ("_pad2", C.c_int32), ("objects", OracleObject * 8),
     ]
 
 
@@ -86,6 +92,12 @@ def pack_params(p) -> OracleParams:
     o.racer_omega_dt = int(bool(p.racer_omega_dt))
     o.ground = int(bool(getattr(p, "ground", False)))
     o.motor_radius, o.ground_spring, o.ground_damping = p.motor_radius, p.ground_spring, p.ground_damping
+    objs = list(getattr(p, "objects", ()) or ())
+    o.n_objects = len(objs)
+    for k, ob in enumerate(objs):      # (type, x, y, z, radius, height)
+        o.objects[k].type = int(ob[0])
+        o.objects[k].x, o.objects[k].y, o.objects[k].z = float(ob[1]), float(ob[2]), float(ob[3])
+        o.objects[k].radius, o.objects[k].height = float(ob[4]), float(ob[5])
     return o
 
 

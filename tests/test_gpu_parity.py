@@ -368,7 +368,7 @@ def test_argument_errors(params_1k):
     env = _drone_batch(params_1k, 64)
     with pytest.raises(ValueError):
         env.step(torch.zeros((63, 4), device=DEV))
-    with pytest.raises(NotImplementedError):
+    with pytest.raises((TypeError, ValueError)):
         env.step(torch.zeros((64, 4), device=DEV), object_list=[object()])
     with pytest.raises(ValueError):
         env.step(None)
@@ -459,3 +459,43 @@ def test_obs_aos_rows_equal_soa_state(params_1k, n, block):
     assert torch.equal(obs[:, 0:13], env.state[0:13, :n].t())
     assert torch.equal(obs[:, 13:16], env.accel[:, :n].t())
     assert torch.equal(env.reward, plain.reward) and torch.equal(env.done_u8, plain.done_u8)
+
+
+def test_object_list_collisions_vs_reference_capture(params_1k):
+    """Drone.step(..., object_list=[Target, Cylinder, Cylinder, Ground]) with a moving target
+    (simulator.py:85-87), through the public API, against the reference capture G10."""
+    from fpyv_amd.objects import Cylinder, Ground, Target
+    from test_oracle_golden import _g10_objects
+    g = load_golden("g10_objects")
+    acts = g["actions"]
+    T, n = acts.shape[:2]
+    target = Target([0.0, -6.0, 3.0], 0.8, path={"radius": 1.5, "resolution": 20000})
+    objs = [target, Cylinder([3.0, 0.0, 0.0], 1.0, 5.0), Cylinder([-2.0, 2.5, 0.0], 0.6, 1.5), Ground()]
+    env = _drone_batch(params_1k, n)
+    model = lane_model.initial_state(params_1k, n, g["init_position"], g["init_velocity"], g["init_ypr"])
+    env.state[:, :n] = torch.from_numpy(model[:, :n]).to(DEV)
+    a = torch.from_numpy(acts).to(DEV)
+    seq = np.zeros((n, T), dtype=np.uint8)
+    try:
+        for t in range(T):
+            target.update()
+            np.testing.assert_allclose(target.position, g["target_positions"][t], atol=1e-12)
+            env.step(a[t], wind_velocity_vector=np.zeros(3), object_list=objs, return_imu=False)
+            seq[:, t] = env.done_u8.cpu().numpy()
+            lane_model.set_objects(_g10_objects(g, t))
+            lane_model.run(params_1k, model, acts[t:t + 1])
+    finally:
+        lane_model.set_objects(())
+    got = env.state.cpu().numpy()
+    assert np.array_equal(got[:, :n].view(np.uint32), model[:, :n].view(np.uint32)), "kernel != lane model (bitwise)"
+    first = lambda d: int(np.argmax(d)) if d.any() else -1      # noqa: E731
+    for i in range(n):
+        assert abs(first(seq[i]) - first(g["done"][i])) <= 2
+    ok = ~g["done"].any(axis=1)
+    ref = np.concatenate([g["state"][:, -1], g["R"][:, -1].reshape(n, 9), g["prev_rates"][:, -1],
+                          g["prev_thrust"][:, -1:]], axis=1)
+    err = soa_vs_oracle(np.ascontiguousarray(got[:, np.flatnonzero(ok)]), ref[ok], int(ok.sum()))
+    assert err["pos_comp"] < 1e-4 and err["quat_abs"] < 1e-5, err
+    # an object list and FPV_FLAG_GROUND are mutually exclusive; too many objects are rejected
+    with pytest.raises(ValueError):
+        env.step(a[0], object_list=[Ground()] * 9)

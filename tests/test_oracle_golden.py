@@ -125,3 +125,27 @@ def test_ground_plane_contact_matches_reference(params_1k):
     s = oracle.drone_initial_state(4, g["init_position"], g["init_velocity"], g["init_ypr"])
     oracle.drone_run(params_1k, s, g["actions"].astype(np.float64))
     assert s[0, 2] < 0 < g["state"][0, -1, 2]
+
+
+def _g10_objects(g, t):
+    objs = [tuple(o) for o in g["objects"]]
+    tp = g["target_positions"][t]
+    objs[0] = (2, tp[0], tp[1], tp[2], float(g["target_radius"]), 0.0)    # the Target moves before each step
+    return tuple(objs)
+
+
+def test_object_list_collisions_match_reference(params_1k):
+    """object_list = [moving Target, Cylinder, Cylinder, Ground] (simulator.py:85-87 order):
+    cylinder side / top springs, sphere contact, ground + cylinder together, and crashes that keep
+    the forces of earlier objects (components.py:198-214)."""
+    g = load_golden("g10_objects")
+    acts = g["actions"].astype(np.float64)
+    T, n = acts.shape[:2]
+    s = oracle.drone_initial_state(n, g["init_position"], g["init_velocity"], g["init_ypr"])
+    for t in range(T):
+        p = params_1k.replace(objects=_g10_objects(g, t))
+        _, accel, done = oracle.drone_run(p, s, acts[t:t + 1])
+        assert np.array_equal(done, g["done"][:, t]), t
+        assert np.abs(s[:, 0:6] - g["state"][:, t]).max() < 1e-11, t
+        assert np.abs(s[:, 6:15] - g["R"][:, t].reshape(n, 9)).max() < 1e-12
+    assert g["done"][1].any() and g["done"][5].any() and not g["done"][0].any()
