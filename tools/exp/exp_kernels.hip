@@ -198,6 +198,46 @@ __global__ __launch_bounds__(BS, MINW) void k_vecg(const FpvK K, const Buf B, co
 
 #define VG(id, V, BS, NT, NTS, W) case id: hipLaunchKernelGGL((k_vecg<V, BS, NT, NTS, W>), dim3((unsigned)((n / V + BS - 1) / BS)), dim3(BS), 0, s, K, B, n); break;
 
+
+// V5: AoS [n][16] state rows (p3 v3 q4 rates3 T, reward, done) moved as ONE float4 stream per wave
+// instruction (64 lanes x 16 B contiguous) and transposed through LDS (pitch 17) so that each lane
+// owns one drone in registers: 64 B read + 64 B write + 16 B action, no separate reward/done stores.
+template <int BS, bool PASS>
+__global__ __launch_bounds__(BS) void k_aos_lds(const FpvK K, float* __restrict__ st16, const float4* __restrict__ action, const int64_t n,
+                                                float wx, float wy, float wz)
+{
+    constexpr int P = 17;
+    __shared__ float tile[BS / 64][64 * P];
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int64_t wave_first = ((int64_t)blockIdx.x * BS + wave * 64);       // first drone of this wave
+    if (wave_first >= n) return;                                            // n % 64 == 0 assumed in this experiment
+    float4* g = reinterpret_cast<float4*>(st16) + wave_first * 4;
+    const float4 a = action[wave_first + lane];
+    float* t = tile[wave];
+    float4 r0 = g[lane], r1 = g[64 + lane], r2 = g[128 + lane], r3 = g[192 + lane];
+    {   // float4 index f = j*64+lane -> drone f>>2, column (f&3)*4
+        float4 rr[4] = {r0, r1, r2, r3};
+#pragma unroll
+        for (int j = 0; j < 4; ++j) { const int f = j * 64 + lane; float* d = &t[(f >> 2) * P + (f & 3) * 4]; d[0] = rr[j].x; d[1] = rr[j].y; d[2] = rr[j].z; d[3] = rr[j].w; }
+    }
+    __builtin_amdgcn_wave_barrier();
+    __builtin_amdgcn_s_waitcnt(0xc07f);
+    float* row = &t[lane * P];
+    FpvDroneState s;
+    s.px = row[0]; s.py = row[1]; s.pz = row[2]; s.vx = row[3]; s.vy = row[4]; s.vz = row[5];
+    s.q.w = row[6]; s.q.x = row[7]; s.q.y = row[8]; s.q.z = row[9]; s.rx = row[10]; s.ry = row[11]; s.rz = row[12]; s.thrust = row[13];
+    float reward; bool done;
+    if (PASS) { s.px += a.x * 1e-9f; s.py += a.y * 1e-9f; s.pz += a.z * 1e-9f; s.thrust += a.w * 1e-9f; reward = s.vx; done = s.vy > 1e30f; }
+    else { FpvStepOut o = fpv_drone_step_lane<false>(K, s, a.x, a.y, a.z, a.w, wx, wy, wz); reward = o.reward; done = o.done; }
+    row[0] = s.px; row[1] = s.py; row[2] = s.pz; row[3] = s.vx; row[4] = s.vy; row[5] = s.vz;
+    row[6] = s.q.w; row[7] = s.q.x; row[8] = s.q.y; row[9] = s.q.z; row[10] = s.rx; row[11] = s.ry; row[12] = s.rz; row[13] = s.thrust;
+    row[14] = reward; row[15] = done ? 1.0f : 0.0f;
+    __builtin_amdgcn_wave_barrier();
+    __builtin_amdgcn_s_waitcnt(0xc07f);
+#pragma unroll
+    for (int j = 0; j < 4; ++j) { const int f = j * 64 + lane; const float* d = &t[(f >> 2) * P + (f & 3) * 4]; g[f] = make_float4(d[0], d[1], d[2], d[3]); }
+}
+
 extern "C" int exp_step(const fpv_params_t* P, float* state, int64_t ld, const float* action, float* reward,
                         uint8_t* done, int64_t n, int variant, int grid_blocks, void* stream)
 {
@@ -226,7 +266,39 @@ extern "C" int exp_step(const fpv_params_t* P, float* state, int64_t ld, const f
         VG(120, 4, 64, false, false, 1) VG(121, 4, 128, false, false, 1) VG(122, 4, 256, false, false, 1) VG(123, 4, 128, true, false, 1) VG(124, 4, 64, true, false, 1)
         VG(125, 4, 256, true, false, 1) VG(126, 4, 128, true, true, 1) VG(127, 4, 128, true, false, 4) VG(128, 4, 64, true, false, 4) VG(129, 4, 256, true, false, 4)
         VG(130, 2, 128, true, true, 1) VG(131, 1, 128, true, true, 1)
+        case 300: hipLaunchKernelGGL((k_aos_lds<128, false>), G(128), dim3(128), 0, s, K, state, B.action, n, 0.f, 0.f, 0.f); break;
+        case 301: hipLaunchKernelGGL((k_aos_lds<128, true>), G(128), dim3(128), 0, s, K, state, B.action, n, 0.f, 0.f, 0.f); break;
+        case 302: hipLaunchKernelGGL((k_aos_lds<256, false>), G(256), dim3(256), 0, s, K, state, B.action, n, 0.f, 0.f, 0.f); break;
+        case 303: hipLaunchKernelGGL((k_aos_lds<64, false>), G(64), dim3(64), 0, s, K, state, B.action, n, 0.f, 0.f, 0.f); break;
         default: return -2;
     }
+    return hipGetLastError() == hipSuccess ? 0 : -3;
+}
+
+// K steps, S chunks on S streams: chunk c's step t+1 only follows chunk c's step t; no global
+// barrier between steps, so one chunk's tail overlaps another chunk's head.
+static hipStream_t g_streams[8];
+static hipEvent_t g_ev0, g_evs[8];
+static bool g_init = false;
+extern "C" int exp_rollout_pipelined(const fpv_params_t* P, float* state, int64_t ld, const float* actions, int64_t action_stride,
+                                     float* reward, uint8_t* done, int64_t n, int k, int S, void* stream)
+{
+    FpvK K; bool big; const char* why;
+    if (fpv_derive_constants(P, &K, &big, &why) != 0) return -1;
+    if (S < 1 || S > 8) return -2;
+    if (!g_init) { for (int i = 0; i < 8; ++i) { hipStreamCreateWithFlags(&g_streams[i], hipStreamNonBlocking); hipEventCreateWithFlags(&g_evs[i], hipEventDisableTiming); }
+                   hipEventCreateWithFlags(&g_ev0, hipEventDisableTiming); g_init = true; }
+    hipStream_t s0 = (hipStream_t)stream;
+    hipEventRecord(g_ev0, s0);
+    const int64_t chunk = ((n / S + 127) / 128) * 128;
+    for (int c = 0; c < S; ++c) hipStreamWaitEvent(g_streams[c], g_ev0, 0);
+    for (int t = 0; t < k; ++t)
+        for (int c = 0; c < S; ++c) {
+            const int64_t lo = c * chunk, cnt = (lo + chunk <= n) ? chunk : (n - lo);
+            if (cnt <= 0) continue;
+            Buf B{state + lo, ld, reinterpret_cast<const float4*>(actions + t * action_stride) + lo, reward + lo, done + lo, 0.f, 0.f, 0.f};
+            hipLaunchKernelGGL((k_vecg<1, 128, true, false, 1>), dim3((unsigned)((cnt + 127) / 128)), dim3(128), 0, g_streams[c], K, B, cnt);
+        }
+    for (int c = 0; c < S; ++c) { hipEventRecord(g_evs[c], g_streams[c]); hipStreamWaitEvent(s0, g_evs[c], 0); }
     return hipGetLastError() == hipSuccess ? 0 : -3;
 }

@@ -43,13 +43,16 @@ def main():
         variants.append((int(v), int(g) if g else 0))
     pads = [int(x) for x in a.pads.split(",")]
     maxld = n + max(pads)
-    backing = torch.zeros(14 * maxld + a.offset + 64, device=dev)
+    backing = torch.zeros(max(14 * maxld, 16 * n) + a.offset + 64, device=dev)
     reward = torch.zeros(n, device=dev); done = torch.zeros(n, dtype=torch.uint8, device=dev)
     def view(pad):
         ld = n + pad
         return backing[a.offset:a.offset + 14 * ld].view(14, ld), ld
     def reset(st):
         st.zero_(); st[2] = 10; st[3] = 1; st[6] = 1
+    def reset_aos():
+        v = backing[a.offset:a.offset + 16 * n].view(n, 16)
+        v.zero_(); v[:, 2] = 10; v[:, 3] = 1; v[:, 6] = 1
     cases = [(v, pad) for pad in pads for v in variants]
     times = {c: [] for c in cases}
     e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
@@ -59,13 +62,15 @@ def main():
             v, pad = c
             st, ld = view(pad)
             reset(st)
+            if v[0] >= 300: reset_aos()
             torch.cuda.synchronize(); e0.record()
             for t in range(a.launches):
                 rc = L.exp_step(C.byref(cp), st.data_ptr(), ld, acts[t % a.ring].data_ptr(), reward.data_ptr(), done.data_ptr(), n, v[0], v[1], None)
                 assert rc == 0, (v, rc)
             e1.record(); torch.cuda.synchronize()
             if r: times[c].append(e0.elapsed_time(e1) * 1e3 / a.launches)
-            if a.check and r == a.rounds: finals[c] = st[:, :n].clone()
+            if a.check and r == a.rounds:
+                finals[c] = (backing[a.offset:a.offset + 16 * n].view(n, 16)[:, :14].t().clone() if v[0] >= 300 else st[:, :n].clone())
     res = []
     for c in cases:
         v, pad = c
