@@ -499,3 +499,38 @@ def test_object_list_collisions_vs_reference_capture(params_1k):
     # an object list and FPV_FLAG_GROUND are mutually exclusive; too many objects are rejected
     with pytest.raises(ValueError):
         env.step(a[0], object_list=[Ground()] * 9)
+
+
+def test_config5_shard_invariance_8M(params_1k):
+    """BASELINE config 5 at its full size on ONE GPU: 8 388 608 drones as one batch vs the same
+    drones as 8 contiguous shards (what 8 ranks would own), in-kernel stick noise keyed by global
+    drone id, auto-reset on ground contact or |z| > ceiling.  Every shard must reproduce its slice
+    of the global batch bit for bit, and the concatenated done masks must equal the global mask."""
+    from fpyv_amd.dist import shard_range, unpack_done_bits
+    from fpyv_amd.env import DroneBatch
+    n_total, world, steps = 1 << 23, 8, 24
+    p = params_1k.replace(ceiling=10.02, noise_gain=3.0)      # tight ceiling + strong sticks: resets happen early
+    kw = dict(device=DEV, auto_reset=True, stick_noise=True, noise_seed=2024, with_accel=False,
+              with_done_bits=True)
+    whole = DroneBatch(p, n_total, **kw)
+    whole.reset()
+    whole.rollout(None, steps=steps)
+    torch.cuda.synchronize()
+    assert int(whole.done_u8.sum()) >= 0
+    g_state, g_done, g_bits = whole.state[:, :n_total].clone(), whole.done_u8.clone(), whole.done_bits.clone()
+    any_reset = bool((g_state[13] == 0).any())               # freshly reset lanes have prev_thrust == 0
+    del whole
+    masks = []
+    for r in range(world):
+        lo, hi = shard_range(n_total, world, r)
+        sh = DroneBatch(p, hi - lo, drone_id_offset=lo, **kw)
+        sh.reset()
+        sh.rollout(None, steps=steps)
+        torch.cuda.synchronize()
+        assert torch.equal(sh.state[:, :hi - lo], g_state[:, lo:hi]), f"shard {r} differs from its slice"
+        assert torch.equal(sh.done_u8, g_done[lo:hi])
+        masks.append(sh.done_bits.clone())
+        del sh
+    assert torch.equal(torch.cat(masks), g_bits), "all-gather of shard masks == global mask"
+    assert torch.equal(unpack_done_bits(g_bits, n_total), g_done)
+    assert any_reset, "the scenario must trigger in-kernel resets"
