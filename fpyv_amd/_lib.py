@@ -22,7 +22,7 @@ FPV_FLAG_AUTO_RESET = 1
 FPV_FLAG_GROUND = 2
 FPV_FLAG_FP16_STATE = 4
 FPV_FLAG_STICK_NOISE = 8
-FPV_HALF_ROWS = 11
+FPV_HALF_PAIR_ROWS = 6
 FPV_OBS_AOS_DIM = 16
 
 # state rows (fpv_abi.h)

@@ -23,6 +23,7 @@
 
 #include <new>
 #include <string>
+#include <type_traits>
 
 #include "../../include/fpv_abi.h"
 #include "fpv_derive.h"
@@ -54,39 +55,50 @@ struct FpvBufD {
     uint32_t seed;         // stochastic-rounding seed of this launch
 };
 
-__device__ __forceinline__ void ld_drone(const float* __restrict__ st, int64_t ld, int64_t i, FpvDroneState& s)
+// Row access = uniform 64-bit row base (SGPR pair) + 32-bit byte offset of the lane: lets the
+// compiler use the `global_load_dword v, v_off, s[base]` form instead of 64-bit vector address
+// arithmetic per row (that arithmetic was ~15 % of the kernel's VALU instructions).
+// 4*i < 2^32 because n <= 2^30 (fpv_create).
+template <class T>
+__device__ __forceinline__ T& row_at(T* row_base, uint32_t i)
 {
-    s.px = st[FPV_PX * ld + i]; s.py = st[FPV_PY * ld + i]; s.pz = st[FPV_PZ * ld + i];
-    s.vx = st[FPV_VX * ld + i]; s.vy = st[FPV_VY * ld + i]; s.vz = st[FPV_VZ * ld + i];
-    s.q.w = st[FPV_QW * ld + i]; s.q.x = st[FPV_QX * ld + i]; s.q.y = st[FPV_QY * ld + i]; s.q.z = st[FPV_QZ * ld + i];
-    s.rx = st[FPV_RX * ld + i]; s.ry = st[FPV_RY * ld + i]; s.rz = st[FPV_RZ * ld + i];
-    s.thrust = st[FPV_THRUST * ld + i];
+    return *reinterpret_cast<T*>(reinterpret_cast<char*>(const_cast<typename std::remove_const<T>::type*>(row_base)) + (uint32_t)(i * (uint32_t)sizeof(T)));
+}
+#define ROW(st, r, ld) ((st) + (int64_t)(r) * (ld))
+
+__device__ __forceinline__ void ld_drone(const float* __restrict__ st, int64_t ld, uint32_t i, FpvDroneState& s)
+{
+    s.px = row_at(ROW(st, FPV_PX, ld), i); s.py = row_at(ROW(st, FPV_PY, ld), i); s.pz = row_at(ROW(st, FPV_PZ, ld), i);
+    s.vx = row_at(ROW(st, FPV_VX, ld), i); s.vy = row_at(ROW(st, FPV_VY, ld), i); s.vz = row_at(ROW(st, FPV_VZ, ld), i);
+    s.q.w = row_at(ROW(st, FPV_QW, ld), i); s.q.x = row_at(ROW(st, FPV_QX, ld), i); s.q.y = row_at(ROW(st, FPV_QY, ld), i); s.q.z = row_at(ROW(st, FPV_QZ, ld), i);
+    s.rx = row_at(ROW(st, FPV_RX, ld), i); s.ry = row_at(ROW(st, FPV_RY, ld), i); s.rz = row_at(ROW(st, FPV_RZ, ld), i);
+    s.thrust = row_at(ROW(st, FPV_THRUST, ld), i);
 }
 
-__device__ __forceinline__ void st_drone(float* __restrict__ st, int64_t ld, int64_t i, const FpvDroneState& s)
+__device__ __forceinline__ void st_drone(float* __restrict__ st, int64_t ld, uint32_t i, const FpvDroneState& s)
 {
-    st[FPV_PX * ld + i] = s.px; st[FPV_PY * ld + i] = s.py; st[FPV_PZ * ld + i] = s.pz;
-    st[FPV_VX * ld + i] = s.vx; st[FPV_VY * ld + i] = s.vy; st[FPV_VZ * ld + i] = s.vz;
-    st[FPV_QW * ld + i] = s.q.w; st[FPV_QX * ld + i] = s.q.x; st[FPV_QY * ld + i] = s.q.y; st[FPV_QZ * ld + i] = s.q.z;
-    st[FPV_RX * ld + i] = s.rx; st[FPV_RY * ld + i] = s.ry; st[FPV_RZ * ld + i] = s.rz;
-    st[FPV_THRUST * ld + i] = s.thrust;
+    row_at(ROW(st, FPV_PX, ld), i) = s.px; row_at(ROW(st, FPV_PY, ld), i) = s.py; row_at(ROW(st, FPV_PZ, ld), i) = s.pz;
+    row_at(ROW(st, FPV_VX, ld), i) = s.vx; row_at(ROW(st, FPV_VY, ld), i) = s.vy; row_at(ROW(st, FPV_VZ, ld), i) = s.vz;
+    row_at(ROW(st, FPV_QW, ld), i) = s.q.w; row_at(ROW(st, FPV_QX, ld), i) = s.q.x; row_at(ROW(st, FPV_QY, ld), i) = s.q.y; row_at(ROW(st, FPV_QZ, ld), i) = s.q.z;
+    row_at(ROW(st, FPV_RX, ld), i) = s.rx; row_at(ROW(st, FPV_RY, ld), i) = s.ry; row_at(ROW(st, FPV_RZ, ld), i) = s.rz;
+    row_at(ROW(st, FPV_THRUST, ld), i) = s.thrust;
 }
 
 typedef float fpv_v4f __attribute__((ext_vector_type(4)));
 
 // The action batch is read once and reward/done are written once per step: non-temporal, so they
 // do not displace the state rows, which are re-read next step, from L2 / Infinity Cache.
-__device__ __forceinline__ float4 ld_action(const float4* __restrict__ a, int64_t i)
+__device__ __forceinline__ float4 ld_action(const float4* __restrict__ a, uint32_t i)
 {
-    const fpv_v4f v = __builtin_nontemporal_load(reinterpret_cast<const fpv_v4f*>(a + i));
+    const fpv_v4f v = __builtin_nontemporal_load(&row_at(reinterpret_cast<const fpv_v4f*>(a), i));
     return make_float4(v.x, v.y, v.z, v.w);
 }
 
 // Episode bookkeeping + done outputs shared by both modes.  `done` is wave-divergent data;
 // all pointer tests are wave-uniform scalar branches.
-__device__ __forceinline__ void emit_lane_outputs(const FpvBufD& B, int64_t i, float reward, bool done);
+__device__ __forceinline__ void emit_lane_outputs(const FpvBufD& B, uint32_t i, float reward, bool done);
 
-__device__ __forceinline__ void emit_outputs(const FpvBufD& B, int64_t i, bool live, float reward, bool done)
+__device__ __forceinline__ void emit_outputs(const FpvBufD& B, uint32_t i, bool live, float reward, bool done)
 {
     // done_bits: one ballot per 64 consecutive drones; i - lane is a multiple of 64 by construction
     const unsigned long long mask = __ballot(live && done);
@@ -94,10 +106,10 @@ __device__ __forceinline__ void emit_outputs(const FpvBufD& B, int64_t i, bool l
     if (live) emit_lane_outputs(B, i, reward, done);
 }
 
-__device__ __forceinline__ void emit_lane_outputs(const FpvBufD& B, int64_t i, float reward, bool done)
+__device__ __forceinline__ void emit_lane_outputs(const FpvBufD& B, uint32_t i, float reward, bool done)
 {
-    if (B.reward) __builtin_nontemporal_store(reward, &B.reward[i]);
-    if (B.done) __builtin_nontemporal_store((uint8_t)(done ? 1 : 0), &B.done[i]);
+    if (B.reward) __builtin_nontemporal_store(reward, &row_at(B.reward, i));
+    if (B.done) __builtin_nontemporal_store((uint8_t)(done ? 1 : 0), &row_at(B.done, i));
     if (B.ep_return) {
         const float r = B.ep_return[i] + reward;
         const int32_t l = B.ep_length[i] + 1;
@@ -112,14 +124,14 @@ __device__ __forceinline__ void emit_lane_outputs(const FpvBufD& B, int64_t i, f
 
 // EMA stick noise: read 4 state floats, one Philox4x32-10 block -> 4 normals, write them back,
 // perturb the action.  With no caller action (B.action null) the sticks are the pure noise profile.
-__device__ __forceinline__ float4 apply_stick_noise(const FpvK& K, const FpvBufD& B, int64_t i, float4 a)
+__device__ __forceinline__ float4 apply_stick_noise(const FpvK& K, const FpvBufD& B, uint32_t i, float4 a)
 {
     float ns[4], av[4] = {a.x, a.y, a.z, a.w};
 #pragma unroll
-    for (int k = 0; k < 4; ++k) ns[k] = B.noise_state[(int64_t)k * B.ld + i];
+    for (int k = 0; k < 4; ++k) ns[k] = row_at(ROW(B.noise_state, k, B.ld), i);
     fpv_stick_noise(K.noise, B.step, (uint64_t)i, ns, av);
 #pragma unroll
-    for (int k = 0; k < 4; ++k) B.noise_state[(int64_t)k * B.ld + i] = ns[k];
+    for (int k = 0; k < 4; ++k) row_at(ROW(B.noise_state, k, B.ld), i) = ns[k];
     const float4 r = make_float4(av[0], av[1], av[2], av[3]);
     if (B.action_out) B.action_out[i] = r;
     return r;
@@ -128,14 +140,17 @@ __device__ __forceinline__ float4 apply_stick_noise(const FpvK& K, const FpvBufD
 template <int BS, int DPL, bool BIG, bool NOISE = false, bool OBJ = false>
 __global__ __launch_bounds__(BS) void fpv_drone_step_kernel(const FpvK K, const FpvBufD B, const int64_t n)
 {
-    const int64_t base = (int64_t)blockIdx.x * (BS * DPL) + threadIdx.x;
+    const uint32_t base = blockIdx.x * (uint32_t)(BS * DPL) + threadIdx.x;    // n < 2^30 (fpv_create)
+    // one drone per lane: lanes past the end leave at once (a ballot over the remaining lanes still
+    // yields the right done bits: exited lanes contribute 0, and a wave whose lane 0 is gone is empty)
+    if (DPL == 1 && base >= n) return;
     FpvDroneState s[DPL];
     float4 a[DPL];
     bool live[DPL];
     // issue every load of every drone of this lane before the first use
 #pragma unroll
     for (int j = 0; j < DPL; ++j) {
-        const int64_t i = base + (int64_t)j * BS;
+        const uint32_t i = base + (uint32_t)j * BS;
         live[j] = i < n;
         if (live[j]) {
             a[j] = (!NOISE || B.action) ? ld_action(B.action, i) : make_float4(0.f, 0.f, 0.f, 0.f);
@@ -145,13 +160,13 @@ __global__ __launch_bounds__(BS) void fpv_drone_step_kernel(const FpvK K, const 
     }
 #pragma unroll
     for (int j = 0; j < DPL; ++j) {
-        const int64_t i = base + (int64_t)j * BS;
+        const uint32_t i = base + (uint32_t)j * BS;
         FpvStepOut o;
         o.done = false; o.reward = 0.0f; o.ax = o.ay = o.az = 0.0f;
         if (live[j]) {
             o = fpv_drone_step_lane<BIG, OBJ>(K, s[j], a[j].x, a[j].y, a[j].z, a[j].w, B.wx, B.wy, B.wz, &B.objs);
             if (B.accel) {
-                B.accel[0 * B.ld + i] = o.ax; B.accel[1 * B.ld + i] = o.ay; B.accel[2 * B.ld + i] = o.az;
+                row_at(ROW(B.accel, 0, B.ld), i) = o.ax; row_at(ROW(B.accel, 1, B.ld), i) = o.ay; row_at(ROW(B.accel, 2, B.ld), i) = o.az;
             }
             if ((K.flags & FPV_FLAG_AUTO_RESET) && o.done) fpv_drone_reset_lane(K, s[j]);
             st_drone(B.state, B.ld, i, s[j]);
@@ -172,7 +187,7 @@ __global__ __launch_bounds__(BS) void fpv_drone_step_aos_kernel(const FpvK K, co
 {
     constexpr int kPitch = 17;
     __shared__ float tile[BS / 64][64 * kPitch];
-    const int64_t i = (int64_t)blockIdx.x * BS + threadIdx.x;
+    const uint32_t i = blockIdx.x * (uint32_t)BS + threadIdx.x;
     const bool live = i < n;
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     FpvStepOut o;
@@ -183,7 +198,7 @@ __global__ __launch_bounds__(BS) void fpv_drone_step_aos_kernel(const FpvK K, co
         ld_drone(B.state, B.ld, i, s);
         o = fpv_drone_step_lane<BIG>(K, s, a.x, a.y, a.z, a.w, B.wx, B.wy, B.wz);
         if (B.accel) {
-            B.accel[0 * B.ld + i] = o.ax; B.accel[1 * B.ld + i] = o.ay; B.accel[2 * B.ld + i] = o.az;
+            row_at(ROW(B.accel, 0, B.ld), i) = o.ax; row_at(ROW(B.accel, 1, B.ld), i) = o.ay; row_at(ROW(B.accel, 2, B.ld), i) = o.az;
         }
         if ((K.flags & FPV_FLAG_AUTO_RESET) && o.done) fpv_drone_reset_lane(K, s);
         st_drone(B.state, B.ld, i, s);
@@ -194,8 +209,8 @@ __global__ __launch_bounds__(BS) void fpv_drone_step_aos_kernel(const FpvK K, co
     }
     emit_outputs(B, i, live, o.reward, o.done);
     __syncthreads();
-    const int64_t wave_first = i - lane;                 // first drone of this wave's tile
-    float4* out = reinterpret_cast<float4*>(B.obs_aos) + wave_first * 4;
+    const uint32_t wave_first = i - lane;                // first drone of this wave's tile
+    float4* out = reinterpret_cast<float4*>(B.obs_aos) + (int64_t)wave_first * 4;
 #pragma unroll
     for (int j = 0; j < 4; ++j) {
         const int f4 = j * 64 + lane;                    // float4 index inside the 64 x 16 tile
@@ -207,135 +222,91 @@ __global__ __launch_bounds__(BS) void fpv_drone_step_aos_kernel(const FpvK K, co
     }
 }
 
-// fp16-storage variant (BASELINE config 4): position rows fp32, the other 11 rows binary16.
-// 89 algorithmic bytes per env-step instead of 133; arithmetic and the lane function are unchanged.
-__device__ __forceinline__ void st_drone_h(const FpvBufD& B, int64_t i, const FpvDroneState& s)
+// fp16-storage variant (BASELINE config 4): position rows fp32; the 11 other values of a drone are
+// binary16, stored as SIX rows of half2 pairs - (vx,vy) (vz,qw) (qx,qy) (qz,rx) (ry,rz) (thrust,0) -
+// so that one lane = one drone still moves nothing narrower than a dword (two-byte accesses waste
+// the memory pipeline: with 11 separate half rows this kernel ran slower than the fp32 one).
+// 3*4 + 6*4 = 36 state bytes each way: 93 algorithmic bytes per env-step instead of 133;
+// arithmetic and the lane function are unchanged.
+__device__ __forceinline__ void ld_drone_h(const FpvBufD& B, uint32_t i, FpvDroneState& s)
 {
-    B.state[0 * B.ld + i] = s.px; B.state[1 * B.ld + i] = s.py; B.state[2 * B.ld + i] = s.pz;
+    s.px = row_at(ROW(B.state, 0, B.ld), i); s.py = row_at(ROW(B.state, 1, B.ld), i); s.pz = row_at(ROW(B.state, 2, B.ld), i);
+    const uint32_t* __restrict__ sh = reinterpret_cast<const uint32_t*>(B.state_h);
+    uint32_t w[FPV_HALF_PAIR_ROWS];
+#pragma unroll
+    for (int k = 0; k < FPV_HALF_PAIR_ROWS; ++k) w[k] = row_at(ROW(sh, k, B.ld), i);
+    FpvHalfState h;
+    fpv_split_pairs(w, h);
+    fpv_unpack_half(h, s);
+}
+
+__device__ __forceinline__ void st_drone_h(const FpvBufD& B, uint32_t i, const FpvDroneState& s)
+{
+    row_at(ROW(B.state, 0, B.ld), i) = s.px; row_at(ROW(B.state, 1, B.ld), i) = s.py; row_at(ROW(B.state, 2, B.ld), i) = s.pz;
     FpvHalfState h;
     fpv_pack_half(s, B.seed, (uint32_t)i, h);
-    uint16_t* __restrict__ sh = B.state_h;
-    sh[0 * B.ld + i] = h.v[0]; sh[1 * B.ld + i] = h.v[1]; sh[2 * B.ld + i] = h.v[2];
-    sh[3 * B.ld + i] = h.q[0]; sh[4 * B.ld + i] = h.q[1]; sh[5 * B.ld + i] = h.q[2]; sh[6 * B.ld + i] = h.q[3];
-    sh[7 * B.ld + i] = h.r[0]; sh[8 * B.ld + i] = h.r[1]; sh[9 * B.ld + i] = h.r[2];
-    sh[10 * B.ld + i] = h.t;
+    uint32_t w[FPV_HALF_PAIR_ROWS];
+    fpv_join_pairs(h, w);
+    uint32_t* __restrict__ sh = reinterpret_cast<uint32_t*>(B.state_h);
+#pragma unroll
+    for (int k = 0; k < FPV_HALF_PAIR_ROWS; ++k) row_at(ROW(sh, k, B.ld), i) = w[k];
 }
 
-// V consecutive drones per lane (V = 2 or 4): every fp16 row access is then one dword / qword per
-// lane (two-byte accesses waste the memory pipeline: the one-drone-per-lane form of this kernel ran
-// SLOWER than the fp32 kernel despite moving 2/3 of the bytes), position rows are float2/float4.
-// Lanes past the end re-store what they loaded, so padding columns keep their values.
-template <int V> struct FpvVec;
-template <> struct FpvVec<2> { typedef uint32_t H; typedef float __attribute__((ext_vector_type(2))) F; };
-template <> struct FpvVec<4> { typedef uint2 H; typedef float __attribute__((ext_vector_type(4))) F; };
-
-template <int V, int BS, bool BIG>
+template <int BS, bool BIG>
 __global__ __launch_bounds__(BS) void fpv_drone_step_h_kernel(const FpvK K, const FpvBufD B, const int64_t n)
 {
-    typedef typename FpvVec<V>::H hv_t;
-    typedef typename FpvVec<V>::F fv_t;
-    const int64_t i0 = ((int64_t)blockIdx.x * BS + threadIdx.x) * V;
-    const bool any_live = i0 < n;
-    fv_t pr[3];
-    hv_t hr[FPV_HALF_ROWS];
-    float4 act[V];
-    if (any_live) {
-#pragma unroll
-        for (int j = 0; j < V; ++j)
-            act[j] = (i0 + j < n) ? ld_action(B.action, i0 + j) : make_float4(0.f, 0.f, 0.f, 0.f);
-#pragma unroll
-        for (int k = 0; k < 3; ++k) pr[k] = *reinterpret_cast<const fv_t*>(&B.state[(int64_t)k * B.ld + i0]);
-#pragma unroll
-        for (int k = 0; k < FPV_HALF_ROWS; ++k) hr[k] = *reinterpret_cast<const hv_t*>(&B.state_h[(int64_t)k * B.ld + i0]);
-    }
-    unsigned long long my_done = 0;
-    if (any_live) {
-        float* pf = reinterpret_cast<float*>(pr);
-        uint16_t* hh = reinterpret_cast<uint16_t*>(hr);
-#pragma unroll
-        for (int j = 0; j < V; ++j) {
-            const int64_t i = i0 + j;
-            if (i < n) {
-                FpvDroneState s;
-                FpvHalfState h;
-                s.px = pf[0 * V + j]; s.py = pf[1 * V + j]; s.pz = pf[2 * V + j];
-#pragma unroll
-                for (int k = 0; k < 3; ++k) h.v[k] = hh[(0 + k) * V + j];
-#pragma unroll
-                for (int k = 0; k < 4; ++k) h.q[k] = hh[(3 + k) * V + j];
-#pragma unroll
-                for (int k = 0; k < 3; ++k) h.r[k] = hh[(7 + k) * V + j];
-                h.t = hh[10 * V + j];
-                fpv_unpack_half(h, s);
-                const FpvStepOut o = fpv_drone_step_lane<BIG>(K, s, act[j].x, act[j].y, act[j].z, act[j].w, B.wx, B.wy, B.wz);
-                if (B.accel) {
-                    B.accel[0 * B.ld + i] = o.ax; B.accel[1 * B.ld + i] = o.ay; B.accel[2 * B.ld + i] = o.az;
-                }
-                if ((K.flags & FPV_FLAG_AUTO_RESET) && o.done) fpv_drone_reset_lane(K, s);
-                fpv_pack_half(s, B.seed, (uint32_t)i, h);
-                pf[0 * V + j] = s.px; pf[1 * V + j] = s.py; pf[2 * V + j] = s.pz;
-#pragma unroll
-                for (int k = 0; k < 3; ++k) hh[(0 + k) * V + j] = h.v[k];
-#pragma unroll
-                for (int k = 0; k < 4; ++k) hh[(3 + k) * V + j] = h.q[k];
-#pragma unroll
-                for (int k = 0; k < 3; ++k) hh[(7 + k) * V + j] = h.r[k];
-                hh[10 * V + j] = h.t;
-                emit_lane_outputs(B, i, o.reward, o.done);
-                my_done |= (unsigned long long)(o.done ? 1 : 0) << j;
-            }
+    const uint32_t i = blockIdx.x * (uint32_t)BS + threadIdx.x;
+    if (i >= n) return;                      // see fpv_drone_step_kernel: the ballot stays correct
+    const bool live = true;
+    FpvStepOut o;
+    o.done = false; o.reward = 0.0f; o.ax = o.ay = o.az = 0.0f;
+    if (live) {
+        FpvDroneState s;
+        const float4 a = ld_action(B.action, i);
+        ld_drone_h(B, i, s);
+        o = fpv_drone_step_lane<BIG>(K, s, a.x, a.y, a.z, a.w, B.wx, B.wy, B.wz);
+        if (B.accel) {
+            row_at(ROW(B.accel, 0, B.ld), i) = o.ax; row_at(ROW(B.accel, 1, B.ld), i) = o.ay; row_at(ROW(B.accel, 2, B.ld), i) = o.az;
         }
-#pragma unroll
-        for (int k = 0; k < 3; ++k) *reinterpret_cast<fv_t*>(&B.state[(int64_t)k * B.ld + i0]) = pr[k];
-#pragma unroll
-        for (int k = 0; k < FPV_HALF_ROWS; ++k) *reinterpret_cast<hv_t*>(&B.state_h[(int64_t)k * B.ld + i0]) = hr[k];
+        if ((K.flags & FPV_FLAG_AUTO_RESET) && o.done) fpv_drone_reset_lane(K, s);
+        st_drone_h(B, i, s);
     }
-    if (B.done_bits) {
-        // lane l owns bits [V*l, V*l+V) of its wave's V consecutive mask words: OR-reduce the 64/V lanes
-        // that share a word with xor-shuffles, the first lane of each group stores it
-        const int lane = threadIdx.x & 63;
-        unsigned long long w = my_done << ((V * lane) & 63);
-#pragma unroll
-        for (int off = 1; off < 64 / V; off <<= 1) {
-            const uint32_t lo = __shfl_xor((uint32_t)w, off), hi = __shfl_xor((uint32_t)(w >> 32), off);
-            w |= ((unsigned long long)hi << 32) | lo;
-        }
-        if ((lane % (64 / V)) == 0 && any_live) B.done_bits[i0 >> 6] = w;
-    }
+    emit_outputs(B, i, live, o.reward, o.done);
 }
 
-__device__ __forceinline__ void ld_racer(const float* __restrict__ st, int64_t ld, int64_t i, FpvRacerState& s)
+__device__ __forceinline__ void ld_racer(const float* __restrict__ st, int64_t ld, uint32_t i, FpvRacerState& s)
 {
-    s.px = st[FPV_PX * ld + i]; s.py = st[FPV_PY * ld + i]; s.pz = st[FPV_PZ * ld + i];
-    s.vx = st[FPV_VX * ld + i]; s.vy = st[FPV_VY * ld + i]; s.vz = st[FPV_VZ * ld + i];
-    s.q.w = st[FPV_QW * ld + i]; s.q.x = st[FPV_QX * ld + i]; s.q.y = st[FPV_QY * ld + i]; s.q.z = st[FPV_QZ * ld + i];
+    s.px = row_at(ROW(st, FPV_PX, ld), i); s.py = row_at(ROW(st, FPV_PY, ld), i); s.pz = row_at(ROW(st, FPV_PZ, ld), i);
+    s.vx = row_at(ROW(st, FPV_VX, ld), i); s.vy = row_at(ROW(st, FPV_VY, ld), i); s.vz = row_at(ROW(st, FPV_VZ, ld), i);
+    s.q.w = row_at(ROW(st, FPV_QW, ld), i); s.q.x = row_at(ROW(st, FPV_QX, ld), i); s.q.y = row_at(ROW(st, FPV_QY, ld), i); s.q.z = row_at(ROW(st, FPV_QZ, ld), i);
 #pragma unroll
     for (int k = 0; k < 3; ++k) {
-        s.w[k] = st[(FPV_R_OMEGA + k) * ld + i];
-        s.ierr[k] = st[(FPV_R_IERR + k) * ld + i];
-        s.lerr[k] = st[(FPV_R_LERR + k) * ld + i];
+        s.w[k] = row_at(ROW(st, (FPV_R_OMEGA + k), ld), i);
+        s.ierr[k] = row_at(ROW(st, (FPV_R_IERR + k), ld), i);
+        s.lerr[k] = row_at(ROW(st, (FPV_R_LERR + k), ld), i);
     }
-    s.first = st[FPV_R_FIRST * ld + i];
+    s.first = row_at(ROW(st, FPV_R_FIRST, ld), i);
 }
 
-__device__ __forceinline__ void st_racer(float* __restrict__ st, int64_t ld, int64_t i, const FpvRacerState& s)
+__device__ __forceinline__ void st_racer(float* __restrict__ st, int64_t ld, uint32_t i, const FpvRacerState& s)
 {
-    st[FPV_PX * ld + i] = s.px; st[FPV_PY * ld + i] = s.py; st[FPV_PZ * ld + i] = s.pz;
-    st[FPV_VX * ld + i] = s.vx; st[FPV_VY * ld + i] = s.vy; st[FPV_VZ * ld + i] = s.vz;
-    st[FPV_QW * ld + i] = s.q.w; st[FPV_QX * ld + i] = s.q.x; st[FPV_QY * ld + i] = s.q.y; st[FPV_QZ * ld + i] = s.q.z;
+    row_at(ROW(st, FPV_PX, ld), i) = s.px; row_at(ROW(st, FPV_PY, ld), i) = s.py; row_at(ROW(st, FPV_PZ, ld), i) = s.pz;
+    row_at(ROW(st, FPV_VX, ld), i) = s.vx; row_at(ROW(st, FPV_VY, ld), i) = s.vy; row_at(ROW(st, FPV_VZ, ld), i) = s.vz;
+    row_at(ROW(st, FPV_QW, ld), i) = s.q.w; row_at(ROW(st, FPV_QX, ld), i) = s.q.x; row_at(ROW(st, FPV_QY, ld), i) = s.q.y; row_at(ROW(st, FPV_QZ, ld), i) = s.q.z;
 #pragma unroll
     for (int k = 0; k < 3; ++k) {
-        st[(FPV_R_OMEGA + k) * ld + i] = s.w[k];
-        st[(FPV_R_IERR + k) * ld + i] = s.ierr[k];
-        st[(FPV_R_LERR + k) * ld + i] = s.lerr[k];
+        row_at(ROW(st, (FPV_R_OMEGA + k), ld), i) = s.w[k];
+        row_at(ROW(st, (FPV_R_IERR + k), ld), i) = s.ierr[k];
+        row_at(ROW(st, (FPV_R_LERR + k), ld), i) = s.lerr[k];
     }
-    st[FPV_R_FIRST * ld + i] = s.first;
+    row_at(ROW(st, FPV_R_FIRST, ld), i) = s.first;
 }
 
 __global__ __launch_bounds__(kBlock) void fpv_racer_step_kernel(const FpvK K, const FpvBufD B, const int64_t n)
 {
-    const int64_t i = (int64_t)blockIdx.x * kBlock + threadIdx.x;
-    const bool live = i < n;
+    const uint32_t i = blockIdx.x * (uint32_t)kBlock + threadIdx.x;
+    if (i >= n) return;
+    const bool live = true;
     float reward = 0.0f;
     bool done = false;
     if (live) {
@@ -388,7 +359,7 @@ __global__ __launch_bounds__(kBlock) void fpv_reset_kernel(const FpvK K, const F
     if (B.ep_return) { B.ep_return[i] = 0.0f; B.ep_length[i] = 0; }
     if (B.noise_state) {
 #pragma unroll
-        for (int k = 0; k < 4; ++k) B.noise_state[(int64_t)k * B.ld + i] = 0.0f;      // x_s(0) = 0
+        for (int k = 0; k < 4; ++k) row_at(ROW(B.noise_state, k, B.ld), i) = 0.0f;      // x_s(0) = 0
     }
 }
 
@@ -535,18 +506,14 @@ int launch_step(fpv_env* h, const FpvBufD& d_in, hipStream_t s)
     d.step = h->launches;
     d.seed = d_in.seed + h->launches++;
     if (h->mode == FPV_MODE_DRONE && (h->K.flags & FPV_FLAG_FP16_STATE)) {
-        const int v = h->dpl == 4 ? 4 : 2;
-        const int64_t per_block = (int64_t)h->block * v;
-        const dim3 grid((unsigned)((h->n + per_block - 1) / per_block));
-#define FPV_LAUNCH_H(V, BS, BIG) hipLaunchKernelGGL((fpv_drone_step_h_kernel<V, BS, BIG>), grid, dim3(BS), 0, s, h->K, d, h->n)
-        if (v == 4) {
-            if (h->block == 256) { if (h->big_angle) FPV_LAUNCH_H(4, 256, true); else FPV_LAUNCH_H(4, 256, false); }
-            else { if (h->big_angle) FPV_LAUNCH_H(4, 128, true); else FPV_LAUNCH_H(4, 128, false); }
+        const dim3 grid((unsigned)((h->n + h->block - 1) / h->block));
+        if (h->block == 256) {
+            if (h->big_angle) hipLaunchKernelGGL((fpv_drone_step_h_kernel<256, true>), grid, dim3(256), 0, s, h->K, d, h->n);
+            else hipLaunchKernelGGL((fpv_drone_step_h_kernel<256, false>), grid, dim3(256), 0, s, h->K, d, h->n);
         } else {
-            if (h->block == 256) { if (h->big_angle) FPV_LAUNCH_H(2, 256, true); else FPV_LAUNCH_H(2, 256, false); }
-            else { if (h->big_angle) FPV_LAUNCH_H(2, 128, true); else FPV_LAUNCH_H(2, 128, false); }
+            if (h->big_angle) hipLaunchKernelGGL((fpv_drone_step_h_kernel<128, true>), grid, dim3(128), 0, s, h->K, d, h->n);
+            else hipLaunchKernelGGL((fpv_drone_step_h_kernel<128, false>), grid, dim3(128), 0, s, h->K, d, h->n);
         }
-#undef FPV_LAUNCH_H
     } else if (h->mode == FPV_MODE_DRONE && (h->K.flags & FPV_FLAG_STICK_NOISE)) {
         const int bs = h->block;
         const dim3 grid((unsigned)((h->n + bs - 1) / bs));
@@ -612,7 +579,7 @@ int fpv_handle_algorithmic_bytes(fpv_handle_t h)
 {
     if (!h) return fail(FPV_EINVAL, "null handle");
     if (h->mode == FPV_MODE_DRONE && (h->K.flags & FPV_FLAG_FP16_STATE))
-        return (3 * 4 + FPV_HALF_ROWS * 2) * 2 + 16 + 4 + 1;   // 89
+        return (3 * 4 + FPV_HALF_PAIR_ROWS * 4) * 2 + 16 + 4 + 1;   // 93
     return fpv_algorithmic_bytes(h->mode);
 }
 
@@ -621,7 +588,7 @@ int fpv_create(const fpv_params_t* params, int64_t n, int device, fpv_handle_t* 
     if (!params || !out) return fail(FPV_EINVAL, "null argument");
     *out = nullptr;
     if (n <= 0) return fail(FPV_EINVAL, "n must be positive");
-    if (n > ((int64_t)1 << 31) * kBlock) return fail(FPV_EINVAL, "n exceeds the launch grid");
+    if (n > ((int64_t)1 << 30)) return fail(FPV_EINVAL, "n exceeds 2^30 drones per handle (32-bit lane offsets)");
     int count = 0;
     hipError_t e = hipGetDeviceCount(&count);
     if (e != hipSuccess || count <= 0)

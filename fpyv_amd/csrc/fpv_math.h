@@ -211,7 +211,28 @@ FPV_HD uint32_t fpv_mix32(uint32_t x)
     return x;
 }
 
-struct FpvHalfState { uint16_t v[3], q[4], r[3], t; };   // the 11 fp16 rows of one drone
+struct FpvHalfState { uint16_t v[3], q[4], r[3], t; };   // the 11 binary16 values of one drone
+
+// storage order: six half2 rows (low half first): (vx,vy) (vz,qw) (qx,qy) (qz,rx) (ry,rz) (thrust,0)
+#define FPV_HALF_PAIR_ROWS_M 6
+FPV_HD void fpv_split_pairs(const uint32_t w[6], FpvHalfState& h)
+{
+    h.v[0] = (uint16_t)w[0]; h.v[1] = (uint16_t)(w[0] >> 16);
+    h.v[2] = (uint16_t)w[1]; h.q[0] = (uint16_t)(w[1] >> 16);
+    h.q[1] = (uint16_t)w[2]; h.q[2] = (uint16_t)(w[2] >> 16);
+    h.q[3] = (uint16_t)w[3]; h.r[0] = (uint16_t)(w[3] >> 16);
+    h.r[1] = (uint16_t)w[4]; h.r[2] = (uint16_t)(w[4] >> 16);
+    h.t = (uint16_t)w[5];
+}
+FPV_HD void fpv_join_pairs(const FpvHalfState& h, uint32_t w[6])
+{
+    w[0] = (uint32_t)h.v[0] | ((uint32_t)h.v[1] << 16);
+    w[1] = (uint32_t)h.v[2] | ((uint32_t)h.q[0] << 16);
+    w[2] = (uint32_t)h.q[1] | ((uint32_t)h.q[2] << 16);
+    w[3] = (uint32_t)h.q[3] | ((uint32_t)h.r[0] << 16);
+    w[4] = (uint32_t)h.r[1] | ((uint32_t)h.r[2] << 16);
+    w[5] = (uint32_t)h.t;
+}
 
 FPV_HD void fpv_unpack_half(const FpvHalfState& h, FpvDroneState& s)
 {

@@ -61,9 +61,10 @@ class _Batch:
         _lib.check(self._L.fpv_create(C.byref(self._cparams), self.n, dev_index, C.byref(self._handle)))
         f32 = dict(dtype=torch.float32, device=self.device)
         if self.fp16_state:
-            # BASELINE config 4: position rows fp32, the other 11 rows binary16 (89 B per env-step)
+            # BASELINE config 4: position rows fp32; v, q, rates, thrust as binary16 in six rows of
+            # half2 pairs (vx,vy) (vz,qw) (qx,qy) (qz,rx) (ry,rz) (thrust,0): 93 B per env-step
             self.state = torch.zeros((3, self.ld), **f32)
-            self.state_h = torch.zeros((_lib.FPV_HALF_ROWS, self.ld), dtype=torch.float16, device=self.device)
+            self.state_h = torch.zeros((_lib.FPV_HALF_PAIR_ROWS, self.ld, 2), dtype=torch.float16, device=self.device)
         else:
             self.state = torch.zeros((self.rows, self.ld), **f32)
             self.state_h = None
@@ -111,7 +112,8 @@ class _Batch:
         if r0 < 3:
             parts.append(self.state[r0:min(r1, 3), :self.n])
         if r1 > 3:
-            parts.append(self.state_h[max(r0, 3) - 3:r1 - 3, :self.n].float())
+            flat = self.state_h[:, :self.n].permute(0, 2, 1).reshape(2 * _lib.FPV_HALF_PAIR_ROWS, self.n)   # value r-3 = row
+            parts.append(flat[max(r0, 3) - 3:r1 - 3].float())
         return torch.cat(parts, dim=0).t()
 
     def algorithmic_bytes(self) -> int:

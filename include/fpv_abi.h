@@ -68,11 +68,13 @@ enum {
                                    keyed by seed / global drone id / step) and ADDS gain * noise to the action
                                    (clipped to [-1,1]); fpv_buffers_t.action may then be NULL (pure noise sticks) */
     FPV_FLAG_FP16_STATE = 4u    /* drone mode only: v, q, prev_rates, prev_thrust stored as IEEE binary16 in
-                                   fpv_buffers_t.state_h[11][ld]; fpv_buffers_t.state holds only the 3 position
-                                   rows in fp32; arithmetic stays fp32 (BASELINE config 4) */
+                                   fpv_buffers_t.state_h; fpv_buffers_t.state holds only the 3 position rows in
+                                   fp32; arithmetic stays fp32 (BASELINE config 4) */
 };
-/* rows of state_h under FPV_FLAG_FP16_STATE: row (FPV_VX - 3) .. (FPV_THRUST - 3) */
-#define FPV_HALF_ROWS 11
+/* state_h under FPV_FLAG_FP16_STATE: FPV_HALF_PAIR_ROWS rows of ld half2 pairs (low half first):
+ * (vx,vy) (vz,qw) (qx,qy) (qz,rx) (ry,rz) (thrust,0) - i.e. value r (FPV_VX..FPV_THRUST) of drone i is
+ * half ((r-3) & 1) of pair state_h[((r-3) >> 1) * ld + i]. */
+#define FPV_HALF_PAIR_ROWS 6
 #define FPV_OBS_AOS_DIM 16
 
 /* Host-side description of one drone type; doubles, narrowed to fp32 by fpv_create.
@@ -140,7 +142,7 @@ typedef struct fpv_buffers {
     int32_t* last_length;    /* [n] */
     float wind[3];           /* wind_velocity_vector of this step (kinematics.py:35: ADDED to v) */
     uint32_t rounding_seed;  /* FPV_FLAG_FP16_STATE: mixed with the handle's launch counter for the stochastic rounding */
-    uint16_t* state_h;       /* FPV_FLAG_FP16_STATE: [FPV_HALF_ROWS][ld] binary16, 8-byte aligned; else unused */
+    uint16_t* state_h;       /* FPV_FLAG_FP16_STATE: [FPV_HALF_PAIR_ROWS][ld] half2 pairs (4 bytes each), 8-byte aligned; else unused */
     float* noise_state;      /* FPV_FLAG_STICK_NOISE: [4][ld] EMA stick-noise state (read-modify-write); else unused */
     float* action_out;       /* [n][4] the action actually applied (after noise and clipping), 16-byte aligned, or NULL */
     const struct fpv_objects* objects; /* HOST pointer, read during the call: the step's object_list, or NULL.
@@ -157,7 +159,7 @@ int fpv_abi_version(void);
 int fpv_state_rows(int mode);
 /* bytes each env-step must move at minimum (state R+W, action R, reward+done W) - roofline bookkeeping */
 int fpv_algorithmic_bytes(int mode);
-/* same for a live handle (accounts for FPV_FLAG_FP16_STATE: 3*4 + 11*2 bytes of state each way = 89 B) */
+/* same for a live handle (accounts for FPV_FLAG_FP16_STATE: 3*4 + 6*4 bytes of state each way = 93 B) */
 int fpv_handle_algorithmic_bytes(fpv_handle_t h);
 
 /* Replaces Drone.__init__'s physics set-up (components.py:86-142) / Racer.__init__ (:68-83).

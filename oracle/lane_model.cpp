@@ -97,9 +97,9 @@ int fpvl_run(const fpv_params_t* P, int64_t n, int steps, float* st, int64_t ld,
 
 }  // extern "C"
 
-// fp16-storage variant: pos [3][ld] fp32, sh [11][ld] binary16; every step goes through the same
+// fp16-storage variant: pos [3][ld] fp32, sh [6][ld] half2 pairs (uint32); every step goes through the same
 // unpack -> step -> pack (stochastic rounding keyed by seed0 + t) as fpv_drone_step_h_kernel.
-extern "C" int fpvl_run_h(const fpv_params_t* P, int64_t n, int steps, float* pos, uint16_t* sh, int64_t ld,
+extern "C" int fpvl_run_h(const fpv_params_t* P, int64_t n, int steps, float* pos, uint32_t* sh, int64_t ld,
                           const float* actions, int per_step, const float wind[3], uint32_t seed0,
                           uint8_t* done, float* reward)
 {
@@ -114,10 +114,9 @@ extern "C" int fpvl_run_h(const fpv_params_t* P, int64_t n, int steps, float* po
             FpvDroneState s;
             FpvHalfState h;
             s.px = pos[0 * ld + i]; s.py = pos[1 * ld + i]; s.pz = pos[2 * ld + i];
-            for (int k = 0; k < 3; ++k) h.v[k] = sh[(0 + k) * ld + i];
-            for (int k = 0; k < 4; ++k) h.q[k] = sh[(3 + k) * ld + i];
-            for (int k = 0; k < 3; ++k) h.r[k] = sh[(7 + k) * ld + i];
-            h.t = sh[10 * ld + i];
+            uint32_t w[6];
+            for (int k = 0; k < 6; ++k) w[k] = sh[k * ld + i];
+            fpv_split_pairs(w, h);
             fpv_unpack_half(h, s);
             const float* a = actions + ((per_step ? (int64_t)t * n : 0) + i) * 4;
             o = big ? fpv_drone_step_lane<true>(K, s, a[0], a[1], a[2], a[3], wind[0], wind[1], wind[2])
@@ -125,10 +124,8 @@ extern "C" int fpvl_run_h(const fpv_params_t* P, int64_t n, int steps, float* po
             if ((K.flags & FPV_FLAG_AUTO_RESET) && o.done) fpv_drone_reset_lane(K, s);
             fpv_pack_half(s, seed0 + (uint32_t)t, (uint32_t)i, h);
             pos[0 * ld + i] = s.px; pos[1 * ld + i] = s.py; pos[2 * ld + i] = s.pz;
-            for (int k = 0; k < 3; ++k) sh[(0 + k) * ld + i] = h.v[k];
-            for (int k = 0; k < 4; ++k) sh[(3 + k) * ld + i] = h.q[k];
-            for (int k = 0; k < 3; ++k) sh[(7 + k) * ld + i] = h.r[k];
-            sh[10 * ld + i] = h.t;
+            fpv_join_pairs(h, w);
+            for (int k = 0; k < 6; ++k) sh[k * ld + i] = w[k];
         }
         if (done) done[i] = o.done ? 1 : 0;
         if (reward) reward[i] = o.reward;

@@ -87,12 +87,13 @@ def run(p, state: np.ndarray, actions: np.ndarray, steps: Optional[int] = None, 
 
 def run_h(p, pos: np.ndarray, sh: np.ndarray, actions: np.ndarray, steps: Optional[int] = None,
           wind=(0.0, 0.0, 0.0), seed0: int = 0, n: Optional[int] = None, auto_reset: bool = False):
-    """fp16-storage variant: pos [3, ld] float32 and sh [11, ld] uint16 (binary16 bits), advanced in
-    place exactly like fpv_drone_step_h_kernel.  Returns (done [n], reward [n])."""
+    """fp16-storage variant: pos [3, ld] float32 and sh [6, ld, 2] uint16 (binary16 bits in the half2
+    pair-row layout of fpv_abi.h), advanced in place exactly like fpv_drone_step_h_kernel.
+    Returns (done [n], reward [n])."""
     L = lib()
     if not hasattr(L, "_h_ready"):
         L.fpvl_run_h.argtypes = [C.POINTER(abi.FpvParams), C.c_int64, C.c_int, C.POINTER(C.c_float),
-                                 C.POINTER(C.c_uint16), C.c_int64, C.POINTER(C.c_float), C.c_int,
+                                 C.c_void_p, C.c_int64, C.POINTER(C.c_float), C.c_int,
                                  C.POINTER(C.c_float), C.c_uint32, C.POINTER(C.c_uint8), C.POINTER(C.c_float)]
         L.fpvl_run_h.restype = C.c_int
         L.fpvl_f32_to_f16.argtypes = [C.c_float, C.c_uint32, C.c_int]
@@ -102,7 +103,7 @@ def run_h(p, pos: np.ndarray, sh: np.ndarray, actions: np.ndarray, steps: Option
         L._h_ready = True
     assert pos.dtype == np.float32 and sh.dtype == np.uint16 and pos.flags.c_contiguous and sh.flags.c_contiguous
     ld = pos.shape[1]
-    assert sh.shape == (11, ld)
+    assert sh.shape == (6, ld, 2)
     actions = np.ascontiguousarray(actions, dtype=np.float32)
     per_step = actions.ndim == 3
     n = n if n is not None else actions.shape[-2]
@@ -113,7 +114,7 @@ def run_h(p, pos: np.ndarray, sh: np.ndarray, actions: np.ndarray, steps: Option
     w = np.asarray(wind, dtype=np.float32)
     cp = abi.pack_params(p, auto_reset=auto_reset, fp16_state=True)
     fp = lambda a: a.ctypes.data_as(C.POINTER(C.c_float))  # noqa: E731
-    rc = L.fpvl_run_h(C.byref(cp), n, steps, fp(pos), sh.ctypes.data_as(C.POINTER(C.c_uint16)), ld, fp(actions),
+    rc = L.fpvl_run_h(C.byref(cp), n, steps, fp(pos), sh.ctypes.data, ld, fp(actions),
                       int(per_step), fp(w), seed0, done.ctypes.data_as(C.POINTER(C.c_uint8)), fp(reward))
     if rc != 0:
         raise RuntimeError(f"fpvl_run_h failed with {rc}")
@@ -121,13 +122,18 @@ def run_h(p, pos: np.ndarray, sh: np.ndarray, actions: np.ndarray, steps: Option
 
 
 def split_half(state: np.ndarray):
-    """[14, ld] fp32 SoA -> (pos [3, ld] fp32, sh [11, ld] uint16) with round-to-nearest halves
-    (a freshly reset state is exactly representable, so the rounding mode does not matter)."""
-    return np.ascontiguousarray(state[0:3]), np.ascontiguousarray(state[3:14].astype(np.float16).view(np.uint16))
+    """[14, ld] fp32 SoA -> (pos [3, ld] fp32, sh [6, ld, 2] uint16 pair rows) with round-to-nearest
+    halves (a freshly reset state is exactly representable, so the rounding mode does not matter)."""
+    ld = state.shape[1]
+    h = np.zeros((12, ld), dtype=np.float16)
+    h[:11] = state[3:14].astype(np.float16)
+    sh = np.ascontiguousarray(h.reshape(6, 2, ld).transpose(0, 2, 1)).view(np.uint16)
+    return np.ascontiguousarray(state[0:3]), sh
 
 
 def join_half(pos: np.ndarray, sh: np.ndarray) -> np.ndarray:
-    return np.concatenate([pos, sh.view(np.float16).astype(np.float32)], axis=0)
+    h = sh.view(np.float16).transpose(0, 2, 1).reshape(12, -1)[:11]
+    return np.concatenate([pos, h.astype(np.float32)], axis=0)
 
 
 def stick_noise(p, n: int, steps: int, noise_seed: int = 0, drone_id_offset: int = 0, base_actions=None,

@@ -399,17 +399,17 @@ def test_fp16_state_bitwise_vs_lane_model_and_restated_tolerance(params_1k):
     acts = g["actions"]
     T, n = acts.shape[:2]
     env = _drone_batch(params_1k, n, fp16_state=True, rounding_seed=5, with_accel=False)
-    assert env.algorithmic_bytes() == 89 and env.state.shape[0] == 3 and env.state_h.dtype == torch.float16
+    assert env.algorithmic_bytes() == 93 and env.state.shape[0] == 3 and env.state_h.dtype == torch.float16
     env.reset()
     env.rollout(torch.from_numpy(acts).to(DEV))
     torch.cuda.synchronize()
     pos, sh = lane_model.split_half(lane_model.initial_state(params_1k, n))
     lane_model.run_h(params_1k, pos, sh, acts, seed0=5)
     assert np.array_equal(env.state.cpu().numpy()[:, :n].view(np.uint32), pos[:, :n].view(np.uint32))
-    assert np.array_equal(env.state_h.cpu().numpy()[:, :n].view(np.uint16), sh[:, :n])
+    assert np.array_equal(env.state_h.cpu().numpy()[:, :n].view(np.uint16), sh[:, :n])     # [6, n, 2] pair rows
     ref = oracle.drone_initial_state(n, params_1k.init_position, params_1k.init_velocity, [0, 0, 0])
     oracle.drone_run(params_1k, ref, acts.astype(np.float64))
-    got = np.concatenate([env.state.cpu().numpy(), env.state_h.float().cpu().numpy()], axis=0)
+    got = lane_model.join_half(env.state.cpu().numpy(), env.state_h.cpu().numpy().view(np.uint16))
     err = soa_vs_oracle(got, ref, n)
     for k, tol in FP16_TOL.items():
         assert err[k] <= tol, (k, err[k])

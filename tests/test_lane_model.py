@@ -147,7 +147,7 @@ FP16_TOL = dict(pos_rel=2e-2, vel_rel=4e-2, quat_abs=1.5e-2)
 
 def test_fp16_conversions_match_ieee_and_stochastic_rounding_is_unbiased():
     L = lane_model.lib()
-    lane_model.run_h(load_params_1k(), np.zeros((3, 64), np.float32), np.zeros((11, 64), np.uint16),
+    lane_model.run_h(load_params_1k(), np.zeros((3, 64), np.float32), np.zeros((6, 64, 2), np.uint16),
                      np.zeros((1, 4), np.float32), steps=0, n=1)          # sets argtypes
     rng = np.random.default_rng(0)
     xs = rng.standard_normal(5000).astype(np.float32) * np.float32(10.0) ** rng.integers(-9, 5, 5000).astype(np.float32)

@@ -40,9 +40,9 @@ def main():
     if a.fp16:
         e16 = DroneBatch(p, a.n, device=dev, with_accel=False, fp16_state=True)
         e16.reset()
-        for g in ("h2x128", "h4x128", "h2x256", "h4x256"):      # fp16 storage: V drones per lane x block
+        for g in ("h1x128", "h1x256"):                          # fp16 storage (half2 pair rows) x block
             envs[g] = e16
-        a.geom = list(a.geom) + ["h2x128", "h4x128", "h2x256", "h4x256"]
+        a.geom = list(a.geom) + ["h1x128", "h1x256"]
     if a.aos:
         ea = DroneBatch(p, a.n, device=dev, with_accel=False, with_obs_aos=True)
         ea.reset()
