@@ -1,0 +1,57 @@
+"""Property tests (hypothesis) of the kernel's per-lane arithmetic on the host lane model: things
+that must hold for ANY parameters / sticks, not just the golden profiles.  (The GPU suite repeats
+the size-independent ones - unit quaternions, batch/lane/shard invariance - at 2^20 and 2^23 drones.)"""
+import numpy as np
+from hypothesis import given, settings, strategies as st
+
+from fpyv_amd import load_params
+from oracle import lane_model, oracle
+from parity import soa_vs_oracle
+
+P = load_params(fps=1000)
+sticks_st = st.lists(st.floats(-1.5, 1.5, allow_nan=False, width=32), min_size=4, max_size=4)
+
+
+@settings(max_examples=40, deadline=None)
+@given(a=sticks_st, ypr=st.lists(st.floats(-179, 179), min_size=3, max_size=3),
+       v0=st.lists(st.floats(-15, 15), min_size=3, max_size=3), steps=st.integers(1, 400),
+       fps=st.sampled_from([60, 250, 1000]))
+def test_unit_quaternion_finite_state_and_oracle_agreement(a, ypr, v0, steps, fps):
+    p = P.replace(dt=1.0 / fps)
+    act = np.array([a], dtype=np.float32)
+    s = lane_model.initial_state(p, 1, [0, 0, 50.0], v0, ypr)
+    lane_model.run(p, s, act, steps=steps)
+    assert np.all(np.isfinite(s[:, 0]))
+    assert abs(np.linalg.norm(s[6:10, 0].astype(np.float64)) - 1) < 5e-7
+    assert np.all(np.abs(s[10:13, 0]) <= p.max_rates * (1 + 1e-6)), "low-passed rates stay inside +-max_rates"
+    ref = oracle.drone_initial_state(1, [0, 0, 50.0], v0, ypr)
+    oracle.drone_run(p, ref, act.astype(np.float64), steps=steps)
+    err = soa_vs_oracle(s, ref, 1)
+    # fp32 vs float64 over <= 400 steps from arbitrary attitudes and speeds
+    assert err["pos_rel"] < 2e-5 and err["quat_abs"] < 2e-5, err
+
+
+@settings(max_examples=25, deadline=None)
+@given(seed=st.integers(0, 2 ** 31 - 1), n=st.integers(1, 70), k=st.integers(0, 69))
+def test_a_drone_does_not_depend_on_its_batch_or_lane(seed, n, k):
+    k = k % n
+    rng = np.random.default_rng(seed)
+    acts = rng.uniform(-1, 1, (30, n, 4)).astype(np.float32)
+    pos = rng.uniform(-5, 5, (n, 3)); pos[:, 2] += 20
+    ypr = rng.uniform(-90, 90, (n, 3))
+    s = lane_model.initial_state(P, n, pos, [1.0, 0, 0], ypr)
+    lane_model.run(P, s, acts)
+    alone = lane_model.initial_state(P, 1, pos[k], [1.0, 0, 0], ypr[k])
+    lane_model.run(P, alone, np.ascontiguousarray(acts[:, k:k + 1]))
+    assert np.array_equal(s[:, k].view(np.uint32), alone[:, 0].view(np.uint32))
+
+
+@settings(max_examples=30, deadline=None)
+@given(z=st.floats(-0.5, 0.5), roll=st.floats(-80, 80), pitch=st.floats(-80, 80))
+def test_done_flag_is_exactly_any_motor_below_ground(z, roll, pitch):
+    s = lane_model.initial_state(P, 1, [0, 0, z], [0, 0, 0], [roll, pitch, 0])
+    R = oracle.quat_to_matrix(s[6:10, 0].astype(np.float64))[0]
+    motors_z = np.float32(z) + (P.motor_xy @ R[2, :2])
+    _, _, done, _ = lane_model.run(P, s, np.zeros((1, 4), np.float32), steps=1)
+    if np.min(np.abs(motors_z)) > 1e-5:            # away from the fp32 decision boundary
+        assert bool(done[0]) == bool((motors_z < 0).any())

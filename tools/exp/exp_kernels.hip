@@ -238,6 +238,31 @@ __global__ __launch_bounds__(BS) void k_aos_lds(const FpvK K, float* __restrict_
     for (int j = 0; j < 4; ++j) { const int f = j * 64 + lane; const float* d = &t[(f >> 2) * P + (f & 3) * 4]; g[f] = make_float4(d[0], d[1], d[2], d[3]); }
 }
 
+
+// V6: phase de-correlation experiments on the product shape (BS=128, nt): odd blocks sleep SLEEP*64
+// cycles before their loads; LDSB bytes of dummy LDS cap the resident blocks per CU (more "rounds").
+template <int SLEEP, int LDSB>
+__global__ __launch_bounds__(128) void k_stagger(const FpvK K, const Buf B, const int64_t n)
+{
+    __shared__ float pad[LDSB / 4 + 1];
+    if (LDSB > 0 && threadIdx.x == 0 && B.wx == 12345.f) pad[0] = 1.f;          // keep the allocation alive
+    if (SLEEP > 0 && (blockIdx.x & 1)) {
+#pragma unroll
+        for (int k = 0; k < SLEEP / 100; ++k) __builtin_amdgcn_s_sleep(100);
+        if (SLEEP % 100) __builtin_amdgcn_s_sleep(SLEEP % 100);
+    }
+    const uint32_t i = blockIdx.x * 128u + threadIdx.x;
+    if (i >= n) return;
+    FpvDroneState s;
+    float4 a = nt_load4(&B.action[i]);
+    ld_drone(B.state, B.ld, i, s);
+    FpvStepOut o = fpv_drone_step_lane<false>(K, s, a.x, a.y, a.z, a.w, B.wx, B.wy, B.wz);
+    st_drone(B.state, B.ld, i, s);
+    __builtin_nontemporal_store(o.reward, &B.reward[i]); __builtin_nontemporal_store((uint8_t)(o.done ? 1 : 0), &B.done[i]);
+    if (LDSB > 0 && B.wx == 54321.f) B.reward[i] = pad[0];
+}
+#define STG(id, SL, LB) case id: hipLaunchKernelGGL((k_stagger<SL, LB>), G(128), dim3(128), 0, s, K, B, n); break;
+
 extern "C" int exp_step(const fpv_params_t* P, float* state, int64_t ld, const float* action, float* reward,
                         uint8_t* done, int64_t n, int variant, int grid_blocks, void* stream)
 {
@@ -270,6 +295,8 @@ extern "C" int exp_step(const fpv_params_t* P, float* state, int64_t ld, const f
         case 301: hipLaunchKernelGGL((k_aos_lds<128, true>), G(128), dim3(128), 0, s, K, state, B.action, n, 0.f, 0.f, 0.f); break;
         case 302: hipLaunchKernelGGL((k_aos_lds<256, false>), G(256), dim3(256), 0, s, K, state, B.action, n, 0.f, 0.f, 0.f); break;
         case 303: hipLaunchKernelGGL((k_aos_lds<64, false>), G(64), dim3(64), 0, s, K, state, B.action, n, 0.f, 0.f, 0.f); break;
+        STG(400, 0, 0) STG(401, 20, 0) STG(402, 50, 0) STG(403, 100, 0) STG(404, 200, 0) STG(405, 400, 0)
+        STG(410, 0, 20480) STG(411, 0, 40960) STG(412, 0, 10240) STG(413, 50, 20480)
         default: return -2;
     }
     return hipGetLastError() == hipSuccess ? 0 : -3;
