@@ -20,7 +20,7 @@ REPO = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
 
 def counters(d):
-    f = glob.glob(os.path.join(d, "**", "*_counter_collection.csv"), recursive=True)[0]
+    f = max(glob.glob(os.path.join(d, "**", "*_counter_collection.csv"), recursive=True), key=os.path.getmtime)
     agg = collections.defaultdict(list)
     for r in csv.DictReader(open(f)):
         k = r["Kernel_Name"]
@@ -44,7 +44,7 @@ def main():
     os.makedirs(out_dir, exist_ok=True)
 
     # kernel-trace stats: keep our kernels' rows verbatim
-    ks = glob.glob(os.path.join(a.kt, "**", "*_kernel_stats.csv"), recursive=True)[0]
+    ks = max(glob.glob(os.path.join(a.kt, "**", "*_kernel_stats.csv"), recursive=True), key=os.path.getmtime)
     rows = list(csv.reader(open(ks)))
     keep = [rows[0]] + [r for r in rows[1:] if "fpv_" in r[0]]
     with open(os.path.join(out_dir, f"{a.round}_kernel_stats.csv"), "w", newline="") as f:
