@@ -88,7 +88,7 @@ class FpvBuffers(C.Structure):
         ("done", C.c_void_p), ("done_bits", C.c_void_p), ("accel", C.c_void_p), ("ep_return", C.c_void_p),
         ("ep_length", C.c_void_p), ("last_return", C.c_void_p), ("last_length", C.c_void_p),
         ("wind", C.c_float * 3), ("rounding_seed", C.c_uint32), ("state_h", C.c_void_p),
-        ("noise_state", C.c_void_p), ("action_out", C.c_void_p), ("objects", C.c_void_p), ("obs_aos", C.c_void_p),
+        ("pos_comp", C.c_void_p), ("noise_state", C.c_void_p), ("action_out", C.c_void_p), ("objects", C.c_void_p), ("obs_aos", C.c_void_p),
     ]
 
 

@@ -47,6 +47,7 @@ struct FpvBufD {
     int32_t* last_length;
     float wx, wy, wz;
     float* obs_aos;        // [n][16] row-major observation (p3 v3 q4 rates3 accel3) or null
+    float* pos_comp;       // [6][ld] Kahan compensation of p and v, or null
     float* noise_state;    // FPV_FLAG_STICK_NOISE: [4][ld] EMA stick-noise state
     float4* action_out;    // [n] applied action or null
     uint32_t step;         // launch index of the handle: Philox counter word
@@ -137,7 +138,7 @@ __device__ __forceinline__ float4 apply_stick_noise(const FpvK& K, const FpvBufD
     return r;
 }
 
-template <int BS, int DPL, bool BIG, bool NOISE = false, bool OBJ = false>
+template <int BS, int DPL, bool BIG, bool NOISE = false, bool OBJ = false, bool KAHAN = false>
 __global__ __launch_bounds__(BS) void fpv_drone_step_kernel(const FpvK K, const FpvBufD B, const int64_t n)
 {
     const uint32_t base = blockIdx.x * (uint32_t)(BS * DPL) + threadIdx.x;    // n < 2^30 (fpv_create)
@@ -164,7 +165,18 @@ __global__ __launch_bounds__(BS) void fpv_drone_step_kernel(const FpvK K, const 
         FpvStepOut o;
         o.done = false; o.reward = 0.0f; o.ax = o.ay = o.az = 0.0f;
         if (live[j]) {
-            o = fpv_drone_step_lane<BIG, OBJ>(K, s[j], a[j].x, a[j].y, a[j].z, a[j].w, B.wx, B.wy, B.wz, &B.objs);
+            float kc[6];
+            if (KAHAN) {
+#pragma unroll
+                for (int k = 0; k < 6; ++k) kc[k] = row_at(ROW(B.pos_comp, k, B.ld), i);
+            }
+            o = fpv_drone_step_lane<BIG, OBJ>(K, s[j], a[j].x, a[j].y, a[j].z, a[j].w, B.wx, B.wy, B.wz, &B.objs,
+                                              KAHAN ? kc : nullptr);
+            if (KAHAN) {
+                const bool rst = (K.flags & FPV_FLAG_AUTO_RESET) && o.done;
+#pragma unroll
+                for (int k = 0; k < 6; ++k) row_at(ROW(B.pos_comp, k, B.ld), i) = rst ? 0.0f : kc[k];
+            }
             if (B.accel) {
                 row_at(ROW(B.accel, 0, B.ld), i) = o.ax; row_at(ROW(B.accel, 1, B.ld), i) = o.ay; row_at(ROW(B.accel, 2, B.ld), i) = o.az;
             }
@@ -361,6 +373,10 @@ __global__ __launch_bounds__(kBlock) void fpv_reset_kernel(const FpvK K, const F
 #pragma unroll
         for (int k = 0; k < 4; ++k) row_at(ROW(B.noise_state, k, B.ld), i) = 0.0f;      // x_s(0) = 0
     }
+    if (B.pos_comp) {
+#pragma unroll
+        for (int k = 0; k < 6; ++k) row_at(ROW(B.pos_comp, k, B.ld), i) = 0.0f;
+    }
 }
 
 // Counter calibration: a copy with the step kernel's access shape (one dword per lane per
@@ -429,6 +445,12 @@ int check_buffers(const fpv_env* h, const fpv_buffers_t* b, bool need_action)  /
             if (b->objects->obj[k].type < FPV_OBJ_GROUND || b->objects->obj[k].type > FPV_OBJ_SPHERE)
                 return fail(FPV_EINVAL, "unknown object type");
     }
+    if (b->pos_comp) {
+        if (h->mode != FPV_MODE_DRONE || (h->K.flags & (FPV_FLAG_FP16_STATE | FPV_FLAG_STICK_NOISE)) || b->obs_aos ||
+            (b->objects && b->objects->count != 0))
+            return fail(FPV_EINVAL, "pos_comp needs drone mode with fp32 state and cannot be combined with obs_aos, stick noise or objects");
+        if ((uintptr_t)b->pos_comp & 15) return fail(FPV_EALIGN, "pos_comp must be 16-byte aligned");
+    }
     if (b->obs_aos) {
         if (h->mode != FPV_MODE_DRONE || (h->K.flags & FPV_FLAG_FP16_STATE))
             return fail(FPV_EINVAL, "obs_aos is available in drone mode with fp32 state only");
@@ -454,6 +476,7 @@ FpvBufD to_device_view(const fpv_buffers_t* b)
     d.last_return = b->last_return; d.last_length = b->last_length;
     d.wx = b->wind[0]; d.wy = b->wind[1]; d.wz = b->wind[2];
     d.state_h = b->state_h; d.seed = b->rounding_seed; d.obs_aos = b->obs_aos;
+    d.pos_comp = b->pos_comp;
     d.noise_state = b->noise_state; d.action_out = reinterpret_cast<float4*>(b->action_out); d.step = 0;
     d.objs.count = 0;
     if (b->objects) {
@@ -523,6 +546,16 @@ int launch_step(fpv_env* h, const FpvBufD& d_in, hipStream_t s)
         } else {
             if (h->big_angle) hipLaunchKernelGGL((fpv_drone_step_kernel<128, 1, true, true>), grid, dim3(128), 0, s, h->K, d, h->n);
             else hipLaunchKernelGGL((fpv_drone_step_kernel<128, 1, false, true>), grid, dim3(128), 0, s, h->K, d, h->n);
+        }
+    } else if (h->mode == FPV_MODE_DRONE && d.pos_comp) {
+        const int bs = h->block;
+        const dim3 grid((unsigned)((h->n + bs - 1) / bs));
+        if (bs == 256) {
+            if (h->big_angle) hipLaunchKernelGGL((fpv_drone_step_kernel<256, 1, true, false, false, true>), grid, dim3(256), 0, s, h->K, d, h->n);
+            else hipLaunchKernelGGL((fpv_drone_step_kernel<256, 1, false, false, false, true>), grid, dim3(256), 0, s, h->K, d, h->n);
+        } else {
+            if (h->big_angle) hipLaunchKernelGGL((fpv_drone_step_kernel<128, 1, true, false, false, true>), grid, dim3(128), 0, s, h->K, d, h->n);
+            else hipLaunchKernelGGL((fpv_drone_step_kernel<128, 1, false, false, false, true>), grid, dim3(128), 0, s, h->K, d, h->n);
         }
     } else if (h->mode == FPV_MODE_DRONE && d.objs.count > 0) {
         const int bs = h->block;

@@ -38,7 +38,7 @@ class _Batch:
                  track_episodes: bool = False, with_accel: bool = False, with_done_bits: bool = False,
                  fp16_state: bool = False, rounding_seed: int = 0, with_obs_aos: bool = False,
                  stick_noise: bool = False, noise_seed: int = 0, drone_id_offset: int = 0,
-                 with_action_out: bool = False):
+                 with_action_out: bool = False, kahan_position: bool = False):
         if num_envs <= 0:
             raise ValueError("num_envs must be positive")
         self.params = params
@@ -80,6 +80,8 @@ class _Batch:
             self.last_length = torch.zeros(self.n, dtype=torch.int32, device=self.device)
         else:
             self.ep_return = self.ep_length = self.last_return = self.last_length = None
+        # Kahan compensation rows of the position accumulation (10^4+-step fp32 accuracy, config 1)
+        self.pos_comp = torch.zeros((6, self.ld), **f32) if kahan_position else None
         # in-kernel EMA stick noise state (x_s per channel) and the action actually applied
         self.noise_state = torch.zeros((4, self.ld), **f32) if self.stick_noise else None
         self.action_out = torch.zeros((self.n, 4), **f32) if with_action_out else None
@@ -102,6 +104,7 @@ class _Batch:
         b.state_h, b.rounding_seed = ptr(self.state_h), self.rounding_seed
         b.obs_aos = ptr(self.obs_aos)
         b.noise_state, b.action_out = ptr(self.noise_state), ptr(self.action_out)
+        b.pos_comp = ptr(self.pos_comp)
 
     def rows_f32(self, r0: int, r1: int) -> torch.Tensor:
         """[num_envs, r1-r0] fp32 values of state rows r0..r1-1 (fpv_abi.h row numbering), whatever the

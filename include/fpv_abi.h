@@ -143,6 +143,9 @@ typedef struct fpv_buffers {
     float wind[3];           /* wind_velocity_vector of this step (kinematics.py:35: ADDED to v) */
     uint32_t rounding_seed;  /* FPV_FLAG_FP16_STATE: mixed with the handle's launch counter for the stochastic rounding */
     uint16_t* state_h;       /* FPV_FLAG_FP16_STATE: [FPV_HALF_PAIR_ROWS][ld] half2 pairs (4 bytes each), 8-byte aligned; else unused */
+    float* pos_comp;         /* [6][ld] Kahan compensation of the p and v accumulations, or NULL (plain fp32 sums).
+                                Keeps p, v within ~1 ulp over 10^4+ steps (config 1); +48 B per env-step; drone mode,
+                                fp32 state, not combinable with obs_aos / stick noise / objects */
     float* noise_state;      /* FPV_FLAG_STICK_NOISE: [4][ld] EMA stick-noise state (read-modify-write); else unused */
     float* action_out;       /* [n][4] the action actually applied (after noise and clipping), 16-byte aligned, or NULL */
     const struct fpv_objects* objects; /* HOST pointer, read during the call: the step's object_list, or NULL.

@@ -17,6 +17,8 @@ extern "C" {
 // state: [rows][ld] SoA like the product.  actions: [steps][n][4] (per_step) or [n][4] held.
 // accel: [3][ld] or NULL; done/reward: [n] or NULL (last step's values).  Returns 0 or FPV_E*.
 static FpvObjects g_objs = {0, {}};
+static float* g_pos_comp = nullptr;      // [6][ld] Kahan compensation rows (p, v) used by subsequent fpvl_run calls, or null
+void fpvl_set_pos_comp(float* c) { g_pos_comp = c; }
 
 // object_list used by subsequent fpvl_run calls (count 0 = none)
 void fpvl_set_objects(const fpv_objects_t* t)
@@ -47,7 +49,14 @@ int fpvl_run(const fpv_params_t* P, int64_t n, int steps, float* st, int64_t ld,
             FpvStepOut o = {0, 0, 0, 0, false};
             for (int t = 0; t < steps; ++t) {
                 const float* a = actions + ((per_step ? (int64_t)t * n : 0) + i) * 4;
-                if (g_objs.count > 0)
+                float kc[6] = {0, 0, 0, 0, 0, 0};
+                if (g_pos_comp) { for (int k = 0; k < 6; ++k) kc[k] = g_pos_comp[k * ld + i]; }
+                if (g_pos_comp) {
+                    o = big ? fpv_drone_step_lane<true>(K, s, a[0], a[1], a[2], a[3], wind[0], wind[1], wind[2], nullptr, kc)
+                            : fpv_drone_step_lane<false>(K, s, a[0], a[1], a[2], a[3], wind[0], wind[1], wind[2], nullptr, kc);
+                    const bool rst = (K.flags & FPV_FLAG_AUTO_RESET) && o.done;
+                    for (int k = 0; k < 6; ++k) g_pos_comp[k * ld + i] = rst ? 0.0f : kc[k];
+                } else if (g_objs.count > 0)
                     o = big ? fpv_drone_step_lane<true, true>(K, s, a[0], a[1], a[2], a[3], wind[0], wind[1], wind[2], &g_objs)
                             : fpv_drone_step_lane<false, true>(K, s, a[0], a[1], a[2], a[3], wind[0], wind[1], wind[2], &g_objs);
                 else

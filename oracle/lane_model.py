@@ -51,6 +51,13 @@ def initial_state(p, n: int, position=None, velocity=None, ypr_deg=None, ld: Opt
     return s
 
 
+def set_pos_comp(comp: Optional[np.ndarray]) -> None:
+    """[6, ld] fp32 Kahan compensation rows (p, v) for subsequent run() calls (same ld as the state); None = plain sums."""
+    L = lib()
+    L.fpvl_set_pos_comp.argtypes = [C.c_void_p]
+    L.fpvl_set_pos_comp(None if comp is None else comp.ctypes.data)
+
+
 def set_objects(rows) -> None:
     """object_list (rows of (type, x, y, z, radius, height)) for subsequent run() calls; () clears it."""
     L = lib()

@@ -534,3 +534,34 @@ def test_config5_shard_invariance_8M(params_1k):
     assert torch.equal(torch.cat(masks), g_bits), "all-gather of shard masks == global mask"
     assert torch.equal(unpack_done_bits(g_bits, n_total), g_done)
     assert any_reset, "the scenario must trigger in-kernel resets"
+
+
+def test_config1_10k_steps_with_kahan_rows(params_1k):
+    """BASELINE config 1 end to end on the GPU at the 1e-5 bar: 10 000 zero-stick steps with the Kahan
+    compensation rows; also bit-identical to the host lane model, and the rows reset with the lane."""
+    g = load_golden("g1_zero_10k")
+    env = _drone_batch(params_1k, 3, kahan_position=True)
+    env.reset()
+    a = torch.zeros((1000, 3, 4), dtype=torch.float32, device=DEV)
+    for _ in range(10):
+        env.rollout(a)
+    torch.cuda.synchronize()
+    got = env.state.cpu().numpy()
+    ref = np.concatenate([g["state"][:, -1], g["R"][:, -1].reshape(1, 9), g["prev_rates"][:, -1],
+                          g["prev_thrust"][:, -1:]], axis=1)
+    err = soa_vs_oracle(got[:, :1].copy(), ref, 1)
+    assert_parity(err, REL_TOL, "config 1 @10k with Kahan rows")
+    assert err["pos_rel"] < 1e-6, err
+    model = lane_model.initial_state(params_1k, 3)
+    comp = np.zeros((6, model.shape[1]), dtype=np.float32)
+    lane_model.set_pos_comp(comp)
+    try:
+        lane_model.run(params_1k, model, np.zeros((3, 4), np.float32), steps=10000)
+    finally:
+        lane_model.set_pos_comp(None)
+    assert np.array_equal(got[:, :3].view(np.uint32), model[:, :3].view(np.uint32))
+    assert np.array_equal(env.pos_comp.cpu().numpy()[:, :3].view(np.uint32), comp[:, :3].view(np.uint32))
+    env.reset(mask=np.array([1, 0, 0], dtype=np.uint8))
+    torch.cuda.synchronize()
+    pc = env.pos_comp.cpu().numpy()
+    assert np.all(pc[:, 0] == 0) and np.any(pc[:, 1] != 0)

@@ -232,3 +232,20 @@ def test_object_list_collisions_fp32(params_1k):
     err = soa_vs_oracle(np.ascontiguousarray(s[:, np.flatnonzero(ok)]), ref[ok], int(ok.sum()))
     # contact episodes amplify fp32 rounding (stiff, undamped springs): 1e-4 on position after 0.8 s
     assert err["pos_comp"] < 1e-4 and err["quat_abs"] < 1e-5, err
+
+
+def test_config1_10k_steps_with_kahan_compensation(params_1k):
+    """The optional Kahan rows (fpv_buffers_t.pos_comp, [6][ld]: p and v) close the 10 000-step gap of
+    config 1: from 1.2e-4 (plain fp32 sums) to < 1e-6 relative against the reference capture."""
+    g = load_golden("g1_zero_10k")
+    s = lane_model.initial_state(params_1k, 1)
+    comp = np.zeros((6, s.shape[1]), dtype=np.float32)
+    lane_model.set_pos_comp(comp)
+    try:
+        lane_model.run(params_1k, s, np.zeros((1, 4), np.float32), steps=10000)
+    finally:
+        lane_model.set_pos_comp(None)
+    ref = np.concatenate([g["state"][:, -1], g["R"][:, -1].reshape(1, 9), g["prev_rates"][:, -1],
+                          g["prev_thrust"][:, -1:]], axis=1)
+    err = soa_vs_oracle(s, ref, 1)
+    assert err["pos_rel"] < 1e-6 and err["vel_rel"] < 1e-6 and err["quat_abs"] < 1e-6, err
