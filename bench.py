@@ -58,7 +58,7 @@ def cpu_baseline(params, seconds_budget=12.0):
     return {"value": all_cores, "unit": "env-steps/s", "cores": threads, "kind": "port",
             "sample": f"{n} drones x {steps_done} steps of EMA-noise sticks, float64 C restatement of Drone.step "
                       f"(oracle/fpv_oracle.c), OpenMP over drones; 1-thread rate {one_core:.3e} env-steps/s; "
-                      f"reference's own Python Drone.step measured in the build container: ~4.0e3 env-steps/s/core",
+                      f"reference's own Python Drone.step, timed in the build container only (it cannot travel): 2.7e3-4.0e3 env-steps/s on one core (profiles/r01_reference_python_timing.json)",
             "one_thread_value": one_core, "host_cpus": os.cpu_count()}
 
 
