@@ -88,6 +88,7 @@ class _Batch:
         # optional row-major [num_envs, 16] observation written by the kernel through an LDS transpose
         self.obs_aos = (torch.zeros((self.n, _lib.FPV_OBS_AOS_DIM), **f32) if with_obs_aos else None)
         self._bcast_action = None
+        self._steps_launched = 0        # mirrors the handle's launch counter (fpv_set_step_counter)
         self._buf = _lib.FpvBuffers()
         self._fill_buffers()
 
@@ -149,6 +150,7 @@ class _Batch:
     def set_step_counter(self, step: int) -> None:
         """Step index keying the stick-noise stream / stochastic rounding (counts launches from 0)."""
         _lib.check(self._L.fpv_set_step_counter(self._handle, int(step) & 0xFFFFFFFF))
+        self._steps_launched = int(step) & 0xFFFFFFFF
 
     def set_tuning(self, drones_per_lane: int = 0, block_threads: int = 0) -> None:
         _lib.check(self._L.fpv_set_tuning(self._handle, int(drones_per_lane), int(block_threads)))
@@ -158,6 +160,28 @@ class _Batch:
         cp = _lib.pack_params(params, auto_reset=flags_auto, **self._pack_kw)
         _lib.check(self._L.fpv_set_params(self._handle, C.byref(cp)))
         self.params, self._cparams = params, cp
+
+    # -- checkpoint / resume (the reference has none; state is just tensors here) ------------------
+    _CKPT_TENSORS = ("state", "state_h", "reward", "done_u8", "ep_return", "ep_length", "last_return",
+                     "last_length", "noise_state", "pos_comp")
+
+    def state_dict(self) -> Dict[str, Any]:
+        """Everything needed to continue a run bit-for-bit: the device tensors (cloned) and the step
+        counter that keys the stick-noise stream / stochastic rounding."""
+        d: Dict[str, Any] = {k: getattr(self, k).clone() for k in self._CKPT_TENSORS if getattr(self, k, None) is not None}
+        d["step_counter"] = int(self._steps_launched)
+        d["num_envs"], d["mode"] = self.n, self.mode
+        return d
+
+    def load_state_dict(self, d: Dict[str, Any]) -> None:
+        if d["num_envs"] != self.n or d["mode"] != self.mode:
+            raise ValueError("checkpoint was taken from a batch of different size or mode")
+        for k in self._CKPT_TENSORS:
+            if k in d:
+                if getattr(self, k, None) is None:
+                    raise ValueError(f"checkpoint has {k!r} but this batch was built without it")
+                getattr(self, k).copy_(d[k])
+        self.set_step_counter(d["step_counter"])
 
     def close(self) -> None:
         if getattr(self, "_handle", None) is not None and self._handle.value:
@@ -206,6 +230,7 @@ class _Batch:
         if wind is not None:
             b.wind[0], b.wind[1], b.wind[2] = float(wind[0]), float(wind[1]), float(wind[2])
         _lib.check(self._L.fpv_step(self._handle, C.byref(b), self._stream()))
+        self._steps_launched = (self._steps_launched + 1) & 0xFFFFFFFF
 
     def rollout(self, actions: Optional[torch.Tensor], wind: Optional[Sequence[float]] = None,
                 rewards: Optional[torch.Tensor] = None, dones: Optional[torch.Tensor] = None,
@@ -243,6 +268,7 @@ class _Batch:
             b.done = dones.data_ptr() if dones is not None else None
         try:
             _lib.check(self._L.fpv_rollout(self._handle, C.byref(b), int(k), stride, out_stride, self._stream()))
+            self._steps_launched = (self._steps_launched + int(k)) & 0xFFFFFFFF
         finally:
             b.reward, b.done = saved
 
@@ -369,15 +395,20 @@ class FpvVecEnv:
 
     def __init__(self, params: Optional[DroneParams] = None, num_envs: int = 1, device: Any = "cuda:0",
                  mode: str = "drone", auto_reset: bool = True, track_episodes: bool = True,
-                 wind: Sequence[float] = (0.0, 0.0, 0.0)):
+                 wind: Sequence[float] = (0.0, 0.0, 0.0), object_list=(), **batch_options: Any):
+        """`batch_options` go to DroneBatch / RacerBatch (stick_noise=, noise_seed=, drone_id_offset=,
+        fp16_state=, with_obs_aos=, kahan_position=, with_done_bits=, ...); `object_list` is the
+        collision world of every step (fpyv_amd.objects)."""
         params = params if params is not None else load_params(fps=1000)
         cls = DroneBatch if mode == "drone" else RacerBatch
         kw: Dict[str, Any] = dict(auto_reset=auto_reset, track_episodes=track_episodes)
         if mode == "drone":
             kw["with_accel"] = False
+        kw.update(batch_options)
         self.batch = cls(params, num_envs, device, **kw)
         self.num_envs = self.batch.n
         self.wind = tuple(float(w) for w in wind)
+        self.object_list = list(object_list)
         self.obs_dim = 13
         self.action_dim = 4
 
@@ -390,6 +421,8 @@ class FpvVecEnv:
         return self.obs
 
     def step(self, action) -> Tuple[torch.Tensor, torch.Tensor, torch.Tensor, Dict[str, Any]]:
+        if self.object_list or self.batch._buf.objects:
+            self.batch._set_objects(self.object_list)
         self.batch._step_raw(action, self.wind)
         info: Dict[str, Any] = {}
         if self.batch.last_return is not None:

@@ -565,3 +565,51 @@ def test_config1_10k_steps_with_kahan_rows(params_1k):
     torch.cuda.synchronize()
     pc = env.pos_comp.cpu().numpy()
     assert np.all(pc[:, 0] == 0) and np.any(pc[:, 1] != 0)
+
+
+def test_checkpoint_resume_is_bit_exact(params_1k, tmp_path):
+    """state_dict()/load_state_dict(): tensors + step counter; a resumed run (in-kernel stick noise,
+    auto-reset, episode bookkeeping) continues bit for bit, also through torch.save/torch.load."""
+    from fpyv_amd.env import DroneBatch
+    kw = dict(device=DEV, stick_noise=True, noise_seed=11, auto_reset=True, track_episodes=True, with_accel=False)
+    p = params_1k.replace(ceiling=10.3, noise_gain=2.0)
+    a, b = DroneBatch(p, 5000, **kw), DroneBatch(p, 5000, **kw)
+    a.reset(); b.reset()
+    a.rollout(None, steps=120)
+    ck = a.state_dict()
+    torch.save(ck, tmp_path / "ckpt.pt")
+    a.rollout(None, steps=80)
+    b.load_state_dict(torch.load(tmp_path / "ckpt.pt", weights_only=True))
+    b.rollout(None, steps=80)
+    torch.cuda.synchronize()
+    for k in ("state", "noise_state", "ep_return", "ep_length", "last_return", "reward", "done_u8"):
+        assert torch.equal(getattr(a, k), getattr(b, k)), k
+    assert a.state_dict()["step_counter"] == b.state_dict()["step_counter"] == 200
+    with pytest.raises(ValueError):
+        DroneBatch(p, 4999, **kw).load_state_dict(ck)
+
+
+def test_vec_env_options_pass_through(params_1k):
+    from fpyv_amd.env import FpvVecEnv
+    from fpyv_amd.objects import Ground
+    low = params_1k.replace(init_position=np.array([0.0, 0.0, 0.3]))
+    # in-kernel noise sticks over the ground-plane flag (FPV_FLAG_GROUND lives in the common lane function)
+    env = FpvVecEnv(low.replace(ground=True), num_envs=256, device=DEV, auto_reset=False, stick_noise=True,
+                    noise_seed=3, with_action_out=True)
+    env.reset()
+    for _ in range(300):
+        obs, reward, done, info = env.step(None)
+    torch.cuda.synchronize()
+    assert obs.shape == (256, 13) and bool(torch.isfinite(obs).all())
+    assert 0 < float(env.batch.action_out.abs().max()) <= 1.0
+    # a collision world given as object_list: same physics as the ground flag for [Ground()]
+    e1 = FpvVecEnv(low, num_envs=64, device=DEV, object_list=[Ground()], auto_reset=False)
+    e2 = FpvVecEnv(low.replace(ground=True), num_envs=64, device=DEV, auto_reset=False)
+    e1.reset(); e2.reset()
+    a = torch.zeros((64, 4), device=DEV); a[:, 3] = -0.8
+    for _ in range(400):
+        e1.step(a); e2.step(a)
+    torch.cuda.synchronize()
+    assert torch.equal(e1.batch.state, e2.batch.state)
+    with pytest.raises(_lib.FpvError):                  # documented restriction: objects x in-kernel noise
+        FpvVecEnv(low, num_envs=8, device=DEV, object_list=[Ground()], stick_noise=True).step(None)
