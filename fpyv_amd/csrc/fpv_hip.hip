@@ -428,7 +428,7 @@ int check_buffers(const fpv_env* h, const fpv_buffers_t* b, bool need_action)  /
     if (need_action && !b->action && !noise) return fail(FPV_EINVAL, "fpv_buffers_t.action is null");
     if (noise) {
         if (!b->noise_state) return fail(FPV_EINVAL, "FPV_FLAG_STICK_NOISE needs fpv_buffers_t.noise_state");
-        if (b->obs_aos) return fail(FPV_EINVAL, "obs_aos and FPV_FLAG_STICK_NOISE cannot be combined yet");
+        if (b->obs_aos) return fail(FPV_EINVAL, "obs_aos and FPV_FLAG_STICK_NOISE cannot be combined");
     }
     if ((uintptr_t)b->action_out & 15) return fail(FPV_EALIGN, "action_out must be 16-byte aligned");
     if (b->ld < h->n) return fail(FPV_EALIGN, "fpv_buffers_t.ld is smaller than the number of drones");
@@ -438,17 +438,16 @@ int check_buffers(const fpv_env* h, const fpv_buffers_t* b, bool need_action)  /
     if ((uintptr_t)b->done_bits & 7) return fail(FPV_EALIGN, "done_bits must be 8-byte aligned");
     if (b->objects && b->objects->count != 0) {
         if (b->objects->count < 0 || b->objects->count > FPV_MAX_OBJECTS) return fail(FPV_EINVAL, "objects.count out of range");
-        if (h->mode != FPV_MODE_DRONE || (h->K.flags & (FPV_FLAG_FP16_STATE | FPV_FLAG_STICK_NOISE | FPV_FLAG_GROUND)) || b->obs_aos)
+        if (h->mode != FPV_MODE_DRONE || (h->K.flags & (FPV_FLAG_FP16_STATE | FPV_FLAG_GROUND)) || b->obs_aos)
             return fail(FPV_EINVAL, "objects need drone mode with fp32 state and cannot be combined with "
-                                    "FPV_FLAG_GROUND (use a Ground entry), stick noise or obs_aos");
+                                    "FPV_FLAG_GROUND (use a Ground entry) or obs_aos");
         for (int k = 0; k < b->objects->count; ++k)
             if (b->objects->obj[k].type < FPV_OBJ_GROUND || b->objects->obj[k].type > FPV_OBJ_SPHERE)
                 return fail(FPV_EINVAL, "unknown object type");
     }
     if (b->pos_comp) {
-        if (h->mode != FPV_MODE_DRONE || (h->K.flags & (FPV_FLAG_FP16_STATE | FPV_FLAG_STICK_NOISE)) || b->obs_aos ||
-            (b->objects && b->objects->count != 0))
-            return fail(FPV_EINVAL, "pos_comp needs drone mode with fp32 state and cannot be combined with obs_aos, stick noise or objects");
+        if (h->mode != FPV_MODE_DRONE || (h->K.flags & FPV_FLAG_FP16_STATE) || b->obs_aos)
+            return fail(FPV_EINVAL, "pos_comp needs drone mode with fp32 state and cannot be combined with obs_aos");
         if ((uintptr_t)b->pos_comp & 15) return fail(FPV_EALIGN, "pos_comp must be 16-byte aligned");
     }
     if (b->obs_aos) {
@@ -523,6 +522,38 @@ void launch_drone_bs(const fpv_env* h, const FpvBufD& d, hipStream_t s)
     }
 }
 
+template <int BS, bool BIG, bool NOISE, bool OBJ, bool KAHAN>
+void launch_feature_kernel(const fpv_env* h, const FpvBufD& d, hipStream_t s)
+{
+    const dim3 grid((unsigned)((h->n + BS - 1) / BS));
+    hipLaunchKernelGGL((fpv_drone_step_kernel<BS, 1, BIG, NOISE, OBJ, KAHAN>), grid, dim3(BS), 0, s, h->K, d, h->n);
+}
+
+template <bool NOISE, bool OBJ, bool KAHAN>
+void launch_features_bs(const fpv_env* h, const FpvBufD& d, hipStream_t s)
+{
+    if (h->block == 256) {
+        if (h->big_angle) launch_feature_kernel<256, true, NOISE, OBJ, KAHAN>(h, d, s);
+        else launch_feature_kernel<256, false, NOISE, OBJ, KAHAN>(h, d, s);
+    } else {
+        if (h->big_angle) launch_feature_kernel<128, true, NOISE, OBJ, KAHAN>(h, d, s);
+        else launch_feature_kernel<128, false, NOISE, OBJ, KAHAN>(h, d, s);
+    }
+}
+
+void launch_features(const fpv_env* h, const FpvBufD& d, hipStream_t s, bool noise, bool obj, bool kahan)
+{
+    switch ((noise ? 4 : 0) | (obj ? 2 : 0) | (kahan ? 1 : 0)) {
+        case 1: launch_features_bs<false, false, true>(h, d, s); break;
+        case 2: launch_features_bs<false, true, false>(h, d, s); break;
+        case 3: launch_features_bs<false, true, true>(h, d, s); break;
+        case 4: launch_features_bs<true, false, false>(h, d, s); break;
+        case 5: launch_features_bs<true, false, true>(h, d, s); break;
+        case 6: launch_features_bs<true, true, false>(h, d, s); break;
+        default: launch_features_bs<true, true, true>(h, d, s); break;
+    }
+}
+
 int launch_step(fpv_env* h, const FpvBufD& d_in, hipStream_t s)
 {
     FpvBufD d = d_in;
@@ -537,36 +568,13 @@ int launch_step(fpv_env* h, const FpvBufD& d_in, hipStream_t s)
             if (h->big_angle) hipLaunchKernelGGL((fpv_drone_step_h_kernel<128, true>), grid, dim3(128), 0, s, h->K, d, h->n);
             else hipLaunchKernelGGL((fpv_drone_step_h_kernel<128, false>), grid, dim3(128), 0, s, h->K, d, h->n);
         }
-    } else if (h->mode == FPV_MODE_DRONE && (h->K.flags & FPV_FLAG_STICK_NOISE)) {
-        const int bs = h->block;
-        const dim3 grid((unsigned)((h->n + bs - 1) / bs));
-        if (bs == 256) {
-            if (h->big_angle) hipLaunchKernelGGL((fpv_drone_step_kernel<256, 1, true, true>), grid, dim3(256), 0, s, h->K, d, h->n);
-            else hipLaunchKernelGGL((fpv_drone_step_kernel<256, 1, false, true>), grid, dim3(256), 0, s, h->K, d, h->n);
-        } else {
-            if (h->big_angle) hipLaunchKernelGGL((fpv_drone_step_kernel<128, 1, true, true>), grid, dim3(128), 0, s, h->K, d, h->n);
-            else hipLaunchKernelGGL((fpv_drone_step_kernel<128, 1, false, true>), grid, dim3(128), 0, s, h->K, d, h->n);
-        }
-    } else if (h->mode == FPV_MODE_DRONE && d.pos_comp) {
-        const int bs = h->block;
-        const dim3 grid((unsigned)((h->n + bs - 1) / bs));
-        if (bs == 256) {
-            if (h->big_angle) hipLaunchKernelGGL((fpv_drone_step_kernel<256, 1, true, false, false, true>), grid, dim3(256), 0, s, h->K, d, h->n);
-            else hipLaunchKernelGGL((fpv_drone_step_kernel<256, 1, false, false, false, true>), grid, dim3(256), 0, s, h->K, d, h->n);
-        } else {
-            if (h->big_angle) hipLaunchKernelGGL((fpv_drone_step_kernel<128, 1, true, false, false, true>), grid, dim3(128), 0, s, h->K, d, h->n);
-            else hipLaunchKernelGGL((fpv_drone_step_kernel<128, 1, false, false, false, true>), grid, dim3(128), 0, s, h->K, d, h->n);
-        }
-    } else if (h->mode == FPV_MODE_DRONE && d.objs.count > 0) {
-        const int bs = h->block;
-        const dim3 grid((unsigned)((h->n + bs - 1) / bs));
-        if (bs == 256) {
-            if (h->big_angle) hipLaunchKernelGGL((fpv_drone_step_kernel<256, 1, true, false, true>), grid, dim3(256), 0, s, h->K, d, h->n);
-            else hipLaunchKernelGGL((fpv_drone_step_kernel<256, 1, false, false, true>), grid, dim3(256), 0, s, h->K, d, h->n);
-        } else {
-            if (h->big_angle) hipLaunchKernelGGL((fpv_drone_step_kernel<128, 1, true, false, true>), grid, dim3(128), 0, s, h->K, d, h->n);
-            else hipLaunchKernelGGL((fpv_drone_step_kernel<128, 1, false, false, true>), grid, dim3(128), 0, s, h->K, d, h->n);
-        }
+    } else if (h->mode == FPV_MODE_DRONE && !d.obs_aos &&
+               ((h->K.flags & FPV_FLAG_STICK_NOISE) || d.pos_comp || d.objs.count > 0)) {
+        // optional features of the one-drone-per-lane kernel are independent template switches:
+        // in-kernel stick noise x object_list collisions x Kahan rows (each its own instantiation, so
+        // the plain kernel keeps its register budget)
+        const bool noise = (h->K.flags & FPV_FLAG_STICK_NOISE) != 0, obj = d.objs.count > 0, kahan = d.pos_comp != nullptr;
+        launch_features(h, d, s, noise, obj, kahan);
     } else if (h->mode == FPV_MODE_DRONE && d.obs_aos) {
         const dim3 grid((unsigned)((h->n + h->block - 1) / h->block));
         if (h->block == 256) {

@@ -145,11 +145,12 @@ typedef struct fpv_buffers {
     uint16_t* state_h;       /* FPV_FLAG_FP16_STATE: [FPV_HALF_PAIR_ROWS][ld] half2 pairs (4 bytes each), 8-byte aligned; else unused */
     float* pos_comp;         /* [6][ld] Kahan compensation of the p and v accumulations, or NULL (plain fp32 sums).
                                 Keeps p, v within ~1 ulp over 10^4+ steps (config 1); +48 B per env-step; drone mode,
-                                fp32 state, not combinable with obs_aos / stick noise / objects */
+                                fp32 state; combines with stick noise and objects, not with obs_aos */
     float* noise_state;      /* FPV_FLAG_STICK_NOISE: [4][ld] EMA stick-noise state (read-modify-write); else unused */
     float* action_out;       /* [n][4] the action actually applied (after noise and clipping), 16-byte aligned, or NULL */
     const struct fpv_objects* objects; /* HOST pointer, read during the call: the step's object_list, or NULL.
-                                Drone mode, fp32 state; not combinable with FPV_FLAG_GROUND (put a Ground entry in the list) */
+                                Drone mode, fp32 state; combines with stick noise and pos_comp; not with obs_aos or
+                                FPV_FLAG_GROUND (put a Ground entry in the list instead) */
     float* obs_aos;          /* [n][FPV_OBS_AOS_DIM] row-major observation per drone, 16-byte aligned, or NULL:
                                 p3, v3, q4 (wxyz), prev_rates3, R_new@acc 3 - the values Drone.step returns
                                 (components.py:247-248) gathered in one row; drone mode, fp32 state only */

@@ -611,5 +611,14 @@ def test_vec_env_options_pass_through(params_1k):
         e1.step(a); e2.step(a)
     torch.cuda.synchronize()
     assert torch.equal(e1.batch.state, e2.batch.state)
-    with pytest.raises(_lib.FpvError):                  # documented restriction: objects x in-kernel noise
-        FpvVecEnv(low, num_envs=8, device=DEV, object_list=[Ground()], stick_noise=True).step(None)
+    # features are orthogonal: object_list x in-kernel noise x Kahan rows == ground flag x noise x Kahan rows
+    kw = dict(num_envs=64, device=DEV, auto_reset=True, stick_noise=True, noise_seed=5, kahan_position=True)
+    e3 = FpvVecEnv(low, object_list=[Ground()], **kw)
+    e4 = FpvVecEnv(low.replace(ground=True), **kw)
+    e3.reset(); e4.reset()
+    for _ in range(300):
+        e3.step(None); e4.step(None)
+    torch.cuda.synchronize()
+    assert torch.equal(e3.batch.state, e4.batch.state) and torch.equal(e3.batch.pos_comp, e4.batch.pos_comp)
+    with pytest.raises(_lib.FpvError):                  # documented restriction: a Ground entry replaces the flag
+        FpvVecEnv(low.replace(ground=True), num_envs=8, device=DEV, object_list=[Ground()]).step(a[:8])
