@@ -26,6 +26,7 @@ def main():
     ap.add_argument("--fp16", action="store_true", help="also time the fp16-storage kernel (config 4, 89 B/env-step)")
     ap.add_argument("--aos", action="store_true", help="also time the step with the [n,16] AoS observation head")
     ap.add_argument("--noise", action="store_true", help="also time pure in-kernel noise sticks (no action read)")
+    ap.add_argument("--extras", action="store_true", help="also time the Kahan-row and 4-object collision variants")
     ap.add_argument("--out", default=None)
     a = ap.parse_args()
     dev = torch.device("cuda:0")
@@ -53,6 +54,16 @@ def main():
         en.reset()
         envs["noise1x128"] = en
         a.geom = list(a.geom) + ["noise1x128"]
+    if a.extras:
+        from fpyv_amd.objects import Cylinder, Ground, Target
+        ek = DroneBatch(p, a.n, device=dev, with_accel=False, kahan_position=True)
+        ek.reset()
+        envs["kahan1x128"] = ek
+        eo = DroneBatch(p, a.n, device=dev, with_accel=False)
+        eo.reset()
+        eo._set_objects([Target([0, -6, 3], 0.8), Cylinder([3, 0, 0], 1.0, 5.0), Cylinder([-2, 2.5, 0], 0.6, 1.5), Ground()])
+        envs["obj1x128"] = eo
+        a.geom = list(a.geom) + ["kahan1x128", "obj1x128"]
     variants = [(g, api) for g in a.geom for api in ("rollout", "step")]
     times = {v: [] for v in variants}
     ev0, ev1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
@@ -60,7 +71,7 @@ def main():
         for v in variants:
             d, api = v
             e = envs[d]
-            e.set_tuning(*[int(x) for x in d.replace("aos", "").replace("noise", "").lstrip("h").split("x")])
+            e.set_tuning(*[int(x) for x in d.replace("aos", "").replace("noise", "").replace("kahan", "").replace("obj", "").lstrip("h").split("x")])
             torch.cuda.synchronize()
             ev0.record()
             done = 0
@@ -84,7 +95,7 @@ def main():
                 times[v].append(ev0.elapsed_time(ev1) * 1e3 / a.launches)
     res = []
     for v in variants:
-        B = envs[v[0]].algorithmic_bytes() + (64 if v[0].startswith("aos") else 0) + (16 if v[0].startswith("noise") else 0)
+        B = envs[v[0]].algorithmic_bytes() + (64 if v[0].startswith("aos") else 0) + (16 if v[0].startswith("noise") else 0) + (48 if v[0].startswith("kahan") else 0)
         med, mn = statistics.median(times[v]), min(times[v])
         res.append({"geom": v[0], "api": v[1], "median_us": med, "min_us": mn,
                     "GBps_alg_median": B * a.n / med / 1e3, "env_steps_per_s_median": a.n / med * 1e6})
