@@ -215,8 +215,13 @@ class _Batch:
 
     def _set_objects(self, object_list) -> None:
         """Bind the step's object_list (host-side table, read by fpv_step during the call)."""
+        if object_list is None or not len(object_list):
+            if self._buf.objects:
+                self._objects = None
+                self._buf.objects = None
+            return
         from .objects import to_rows
-        rows = to_rows(object_list) if object_list is not None and len(object_list) else ()
+        rows = to_rows(object_list)
         if rows:
             self._objects = _lib.pack_objects(rows)
             self._buf.objects = C.addressof(self._objects)
