@@ -51,17 +51,17 @@ int fpvl_run(const fpv_params_t* P, int64_t n, int steps, float* st, int64_t ld,
                 const float* a = actions + ((per_step ? (int64_t)t * n : 0) + i) * 4;
                 float kc[6] = {0, 0, 0, 0, 0, 0};
                 if (g_pos_comp) { for (int k = 0; k < 6; ++k) kc[k] = g_pos_comp[k * ld + i]; }
+                float* kp = g_pos_comp ? kc : nullptr;
+                if (g_objs.count > 0)
+                    o = big ? fpv_drone_step_lane<true, true>(K, s, a[0], a[1], a[2], a[3], wind[0], wind[1], wind[2], &g_objs, kp)
+                            : fpv_drone_step_lane<false, true>(K, s, a[0], a[1], a[2], a[3], wind[0], wind[1], wind[2], &g_objs, kp);
+                else
+                    o = big ? fpv_drone_step_lane<true>(K, s, a[0], a[1], a[2], a[3], wind[0], wind[1], wind[2], nullptr, kp)
+                            : fpv_drone_step_lane<false>(K, s, a[0], a[1], a[2], a[3], wind[0], wind[1], wind[2], nullptr, kp);
                 if (g_pos_comp) {
-                    o = big ? fpv_drone_step_lane<true>(K, s, a[0], a[1], a[2], a[3], wind[0], wind[1], wind[2], nullptr, kc)
-                            : fpv_drone_step_lane<false>(K, s, a[0], a[1], a[2], a[3], wind[0], wind[1], wind[2], nullptr, kc);
                     const bool rst = (K.flags & FPV_FLAG_AUTO_RESET) && o.done;
                     for (int k = 0; k < 6; ++k) g_pos_comp[k * ld + i] = rst ? 0.0f : kc[k];
-                } else if (g_objs.count > 0)
-                    o = big ? fpv_drone_step_lane<true, true>(K, s, a[0], a[1], a[2], a[3], wind[0], wind[1], wind[2], &g_objs)
-                            : fpv_drone_step_lane<false, true>(K, s, a[0], a[1], a[2], a[3], wind[0], wind[1], wind[2], &g_objs);
-                else
-                    o = big ? fpv_drone_step_lane<true>(K, s, a[0], a[1], a[2], a[3], wind[0], wind[1], wind[2])
-                            : fpv_drone_step_lane<false>(K, s, a[0], a[1], a[2], a[3], wind[0], wind[1], wind[2]);
+                }
                 if ((K.flags & FPV_FLAG_AUTO_RESET) && o.done) fpv_drone_reset_lane(K, s);
             }
             st[FPV_PX * ld + i] = s.px; st[FPV_PY * ld + i] = s.py; st[FPV_PZ * ld + i] = s.pz;

@@ -622,3 +622,44 @@ def test_vec_env_options_pass_through(params_1k):
     assert torch.equal(e3.batch.state, e4.batch.state) and torch.equal(e3.batch.pos_comp, e4.batch.pos_comp)
     with pytest.raises(_lib.FpvError):                  # documented restriction: a Ground entry replaces the flag
         FpvVecEnv(low.replace(ground=True), num_envs=8, device=DEV, object_list=[Ground()]).step(a[:8])
+
+
+def test_feature_combinations_fuzz_bitwise(params_1k):
+    """Every combination of the independent switches (auto-reset, ground flag | object list, Kahan
+    rows, block width, ragged n) must select a kernel instantiation whose result equals the host
+    lane model bit for bit."""
+    rng = np.random.default_rng(2025)
+    objs = ((2, 0.3, -0.2, 0.9, 0.35, 0.0), (1, 1.2, 0.4, 0.0, 0.5, 1.1), (0, 0, 0, 0, 0, 0))
+    base = params_1k.replace(init_position=np.array([0.0, 0.0, 0.55]), ceiling=1.6)
+    for case in range(24):
+        auto, kahan = bool(case & 1), bool(case & 2)
+        world = ("none", "flag", "list")[case % 3]
+        n = int(rng.integers(1, 700))
+        steps = int(rng.integers(5, 60))
+        block = (128, 256)[(case // 3) % 2]
+        p = base.replace(ground=(world == "flag"))
+        acts = rng.uniform(-1, 1, (steps, n, 4)).astype(np.float32)
+        acts[..., 3] = rng.uniform(-1, -0.3, (steps, n))            # mostly below hover: ground/objects get hit
+        pos = np.concatenate([rng.uniform(-0.5, 0.5, (n, 2)), rng.uniform(0.3, 1.2, (n, 1))], axis=1).astype(np.float32)
+        env = _drone_batch(p, n, auto_reset=auto, kahan_position=kahan, with_done_bits=True)
+        env.set_tuning(1, block)
+        model = lane_model.initial_state(p, n, pos, [0.5, 0, 0], [0, 0, 0])
+        env.state[:, :n] = torch.from_numpy(model[:, :n]).to(DEV)
+        comp = np.zeros((6, model.shape[1]), dtype=np.float32)
+        a = torch.from_numpy(acts).to(DEV)
+        try:
+            lane_model.set_pos_comp(comp if kahan else None)
+            lane_model.set_objects(objs if world == "list" else ())
+            for t in range(steps):
+                env.step(a[t], object_list=objs if world == "list" else (), return_imu=False)
+            _, acc, done, rew = lane_model.run(p, model, acts, auto_reset=auto)
+        finally:
+            lane_model.set_pos_comp(None)
+            lane_model.set_objects(())
+        torch.cuda.synchronize()
+        tag = f"case {case}: auto={auto} kahan={kahan} world={world} n={n} steps={steps} block={block}"
+        assert np.array_equal(env.state.cpu().numpy()[:, :n].view(np.uint32), model[:, :n].view(np.uint32)), tag
+        assert np.array_equal(env.done_u8.cpu().numpy(), done), tag
+        assert np.array_equal(env.reward.cpu().numpy().view(np.uint32), rew.view(np.uint32)), tag
+        if kahan:
+            assert np.array_equal(env.pos_comp.cpu().numpy()[:, :n].view(np.uint32), comp[:, :n].view(np.uint32)), tag
