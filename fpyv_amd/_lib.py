@@ -189,7 +189,3 @@ def state_rows(mode: int) -> int:
 def algorithmic_bytes(mode: int) -> int:
     """state read + write, action read, reward + done write (fpv_algorithmic_bytes)."""
     return state_rows(mode) * 8 + 16 + 4 + 1
-
-
-def as_float32_soa(a: np.ndarray) -> np.ndarray:
-    return np.ascontiguousarray(a, dtype=np.float32)

@@ -18,7 +18,6 @@
 
 #include <math.h>
 #include <stdint.h>
-#include <stdio.h>
 #include <string.h>
 
 #include <new>

@@ -1,6 +1,6 @@
 // fpv_math.h - per-drone (per-lane) fp32 arithmetic of the fused step kernel.
 //
-// One call advances ONE drone by one step entirely in registers; fpv_kernels.hip wraps it with the
+// One call advances ONE drone by one step entirely in registers; fpv_hip.hip wraps it with the
 // coalesced SoA loads/stores.  The same header is compiled for the host by the test-only lane
 // model (oracle/lane_model.cpp) so that fp32 rounding can be studied without a GPU; the product
 // never runs it on the CPU.
@@ -139,8 +139,9 @@ struct FpvDroneState {
 
 // ------------------------------------------------------------------------------------------------
 // fp16 storage (BASELINE config 4: "fp16 state / fp32 integrator"): v, q, prev_rates, prev_thrust
-// live in HBM as IEEE binary16, position stays fp32, all arithmetic stays fp32.  Conversions are
-// integer bit manipulation so the host lane model and the kernel agree bit for bit.
+// live in HBM as IEEE binary16, position stays fp32, all arithmetic stays fp32.  The kernel converts
+// with the hardware instructions, the host lane model with integer bit manipulation; both are
+// exact IEEE round-to-nearest-even, so they agree bit for bit.
 //   * low-pass states (rates, thrust) are rounded to nearest-even: their error does not accumulate;
 //   * integrator states (v, q) are rounded STOCHASTICALLY: at dt = 1 ms one step's increment is
 //     often below half an fp16 ulp (0.03 m/s against ulp 0.016 at 20 m/s; 3e-4 of quaternion against
@@ -214,7 +215,6 @@ FPV_HD uint32_t fpv_mix32(uint32_t x)
 struct FpvHalfState { uint16_t v[3], q[4], r[3], t; };   // the 11 binary16 values of one drone
 
 // storage order: six half2 rows (low half first): (vx,vy) (vz,qw) (qx,qy) (qz,rx) (ry,rz) (thrust,0)
-#define FPV_HALF_PAIR_ROWS_M 6
 FPV_HD void fpv_split_pairs(const uint32_t w[6], FpvHalfState& h)
 {
     h.v[0] = (uint16_t)w[0]; h.v[1] = (uint16_t)(w[0] >> 16);
