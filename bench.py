@@ -89,7 +89,7 @@ def main():
 
     import torch
     import torch.distributed as dist
-    from fpyv_amd import _lib, load_params, sticks
+    from fpyv_amd import load_params, sticks
     from fpyv_amd.dist import DoneGather
     from fpyv_amd.env import DroneBatch
 

@@ -9,7 +9,6 @@ import ctypes as C
 import os
 from typing import Optional
 
-import numpy as np
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, "libfpv_hip.so")

@@ -13,8 +13,7 @@ the Trail never collide in the reference (components.py:202) and have no counter
 from __future__ import annotations
 
 import dataclasses
-import math
-from typing import Iterator, Optional, Sequence, Tuple
+from typing import Optional, Sequence, Tuple
 
 import numpy as np
 
