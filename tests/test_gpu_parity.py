@@ -663,3 +663,30 @@ def test_feature_combinations_fuzz_bitwise(params_1k):
         assert np.array_equal(env.reward.cpu().numpy().view(np.uint32), rew.view(np.uint32)), tag
         if kahan:
             assert np.array_equal(env.pos_comp.cpu().numpy()[:, :n].view(np.uint32), comp[:, :n].view(np.uint32)), tag
+
+
+def test_big_angle_path_on_gpu(params_1k):
+    """max_rates so large that one step can turn more than 90 degrees: fpv_create selects the library
+    sincos instantiation (BIG); same physical trajectory as the small-angle kernel and the oracle."""
+    g = load_golden("g3_ema_noise")
+    n = g["actions"].shape[1]
+    p_big = params_1k.replace(max_rates=2.0e5)
+    acts = (g["actions"] * np.float32(1e-3)).astype(np.float32)
+    acts[..., 3] = g["actions"][..., 3]
+    env = _drone_batch(p_big, n)
+    env.reset()
+    env.rollout(torch.from_numpy(acts).to(DEV))
+    torch.cuda.synchronize()
+    ref = oracle.drone_initial_state(n, p_big.init_position, p_big.init_velocity, [0, 0, 0])
+    oracle.drone_run(p_big, ref, acts.astype(np.float64))
+    assert_parity(soa_vs_oracle(env.state.cpu().numpy(), ref, n), 2e-5, "big-angle kernel")
+    # genuinely large per-step rotations (tumbling at 40 000 deg/s with dt = 1 ms = 80 deg per application)
+    acts2 = np.zeros((200, n, 4), dtype=np.float32)
+    acts2[..., 0] = 0.2; acts2[..., 1] = -0.15; acts2[..., 3] = -0.5
+    env.reset()
+    env.rollout(torch.from_numpy(acts2).to(DEV))
+    torch.cuda.synchronize()
+    ref = oracle.drone_initial_state(n, p_big.init_position, p_big.init_velocity, [0, 0, 0])
+    oracle.drone_run(p_big, ref, acts2.astype(np.float64))
+    err = soa_vs_oracle(env.state.cpu().numpy(), ref, n)
+    assert err["quat_abs"] < 5e-5 and err["pos_rel"] < 5e-5, err

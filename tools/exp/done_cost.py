@@ -1,0 +1,27 @@
+#!/usr/bin/env python3
+"""What do the reward (dword) and done (byte) output streams cost?  Same env, pointers nulled, interleaved."""
+import os, statistics, sys
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
+import torch
+from fpyv_amd import load_params, sticks
+from fpyv_amd.env import DroneBatch
+dev = torch.device("cuda:0"); n = 1 << 20; ring = 32
+p = load_params(fps=1000)
+acts = sticks.ema_noise_device(ring, n, dev)
+env = DroneBatch(p, n, device=dev, with_accel=False, with_done_bits=True); env.reset()
+ptrs = dict(reward=env._buf.reward, done=env._buf.done, bits=env._buf.done_bits)
+cases = {"reward+done": ("reward", "done"), "reward+done+bits": ("reward", "done", "bits"), "reward+bits": ("reward", "bits"), "reward only": ("reward",), "none": ()}
+res = {k: [] for k in cases}
+e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+for r in range(7):
+    for k, on in cases.items():
+        env._buf.reward = ptrs["reward"] if "reward" in on else None
+        env._buf.done = ptrs["done"] if "done" in on else None
+        env._buf.done_bits = ptrs["bits"] if "bits" in on else None
+        torch.cuda.synchronize(); e0.record()
+        for rep in range(8):
+            env.rollout(acts)
+        e1.record(); torch.cuda.synchronize()
+        if r: res[k].append(e0.elapsed_time(e1) * 1e3 / (8 * ring))
+for k in cases:
+    print(f"{k:18s}: {statistics.median(res[k]):.3f} us")
