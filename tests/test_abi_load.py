@@ -70,3 +70,15 @@ def test_product_never_imports_the_oracle():
                     if re.search(r"^\s*(from|import)\s+oracle|#include\s+\"[^\"]*oracle|fpvo_|fpvl_", txt, flags=re.M):
                         bad.append(os.path.join(d, f))
     assert not bad, bad
+
+
+def test_components_module_mirrors_reference_names():
+    import fpyv_amd.components as c
+    from fpyv_amd.env import DroneBatch, RacerBatch
+    assert c.Drone is DroneBatch and c.Racer is RacerBatch
+    assert c.Ground().as_row()[0] == 0 and c.Cylinder([1, 2, 0], 0.5, 2.0).as_row() == (1, 1.0, 2.0, 0.0, 0.5, 2.0)
+    t = c.Target([0, 0, 3], 0.8, path={"radius": 2.0, "resolution": 8})
+    t.update()
+    assert t.as_row()[:4] == (2, 2.0, 0.0, 3.0)          # first path point: centre + (radius, 0, 0)
+    with pytest.raises(AssertionError):
+        c.Cylinder([0, 0, 0], -1.0, 2.0)                  # components.py:688
