@@ -27,7 +27,7 @@ import numpy as np
 import yaml
 
 _DATA_DIR = os.path.join(os.path.dirname(os.path.abspath(__file__)), "data")
-DEFAULT_PARAMS_PATH = os.path.join(_DATA_DIR, "params.yaml")
+DEFAULT_PARAMS_PATH = os.path.join(_DATA_DIR, "stepper_defaults.yaml")
 
 MODE_DRONE = 0   # Drone.step arithmetic (components.py:220-248)
 MODE_RACER = 1   # Racer.step arithmetic (tests/racer_drone_test.py:95-103)
