@@ -83,6 +83,9 @@ def main():
     ap.add_argument("--no-gather", action="store_true", help="skip the done-mask all-gather (N > 1)")
     ap.add_argument("--gather-block", type=int, default=64,
                     help="steps of done masks bucketed into one all-gather (N > 1)")
+    ap.add_argument("--gather-returns", action="store_true",
+                    help="N > 1: also all-gather the per-drone last episode return (fp32) once per bucket; turns on "
+                         "episode bookkeeping (+16 B per env-step), so it is off for the headline numbers")
     ap.add_argument("--force-dist", action="store_true",
                     help="rehearsal: run the RCCL process group + all-gather path even with one rank")
     args = ap.parse_args()
@@ -113,7 +116,8 @@ def main():
     # (BASELINE configs[4] semantics; costs no extra bytes), so a long run stays a flight workload
     params = load_params(fps=1000, ceiling=args.ceiling)
     env = DroneBatch(params, n, device=dev, auto_reset=not args.no_auto_reset, with_accel=False,
-                     with_done_bits=multi, fp16_state=args.fp16_state)
+                     with_done_bits=multi, fp16_state=args.fp16_state,
+                     track_episodes=bool(multi and args.gather_returns))
     if args.dpl:
         env.set_tuning(args.dpl)
     env.reset()
@@ -126,6 +130,9 @@ def main():
     gather = None
     if multi and not args.no_gather:
         gather = DoneGather((env.done_bits.numel(),), torch.int64, dev, block=args.gather_block)
+    returns_all, returns_work = None, None
+    if gather is not None and args.gather_returns:
+        returns_all = torch.zeros(dist.get_world_size() * n, dtype=torch.float32, device=dev)
 
     def run(k, t_base):
         """k steps = k launches.  Without the gather: whole ring spans go through fpv_rollout."""
@@ -143,6 +150,11 @@ def main():
                 env.step(actions[t % ring], return_imu=False)
                 if gather is not None:
                     gather.step_done(t)
+                    if returns_all is not None and (t + 1) % args.gather_block == 0:
+                        nonlocal returns_work
+                        if returns_work is not None:
+                            returns_work.wait()
+                        returns_work = dist.all_gather_into_tensor(returns_all, env.last_return, async_op=True)
 
     def fence():
         torch.cuda.synchronize()
@@ -168,6 +180,8 @@ def main():
     if gather is not None:
         gather.flush(args.warmup + args.steps - 1)
         gather.drain()
+        if returns_work is not None:
+            returns_work.wait()
     fence()
     elapsed = time.perf_counter() - t0
     dev_ms = ev0.elapsed_time(ev1)
@@ -201,7 +215,8 @@ def main():
                        + "1.05M drones/GPU, EMA-noise sticks (noise_smooth_test profile), fp32 math, dt=1ms, "
                        + ("no auto-reset" if args.no_auto_reset else f"in-kernel auto-reset on ground contact or |z|>{args.ceiling:g} m"),
                        "drones_per_gpu": n, "global_drones": n * world, "action_ring": ring, "api": args.api,
-                       "parallelism": f"shard{world}" + ("+allgather(done_bits x" + str(args.gather_block) + " steps)" if gather is not None else ""),
+                       "parallelism": f"shard{world}" + ("+allgather(done_bits x" + str(args.gather_block) + " steps"
+                                                              + (", last_return" if args.gather_returns else "") + ")" if gather is not None else ""),
                        "drones_per_lane": args.dpl or "default"},
             "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": achieved / HBM_PEAK_GBS, "traffic": traffic, "traffic_source": traffic_src,
