@@ -30,7 +30,7 @@ R_OMEGA, R_IERR, R_LERR, R_FIRST = 10, 13, 16, 19
 
 # every symbol include/fpv_abi.h declares
 EXPORTS = ("fpv_abi_version", "fpv_state_rows", "fpv_algorithmic_bytes", "fpv_handle_algorithmic_bytes", "fpv_create", "fpv_destroy",
-           "fpv_reset", "fpv_step", "fpv_rollout", "fpv_set_params", "fpv_set_step_counter", "fpv_set_tuning", "fpv_recommended_ld",
+           "fpv_reset", "fpv_step", "fpv_rollout", "fpv_rollout_graph", "fpv_set_params", "fpv_set_step_counter", "fpv_set_tuning", "fpv_recommended_ld",
            "fpv_diag_stream_copy", "fpv_last_error",
            "fpv_error_name")
 
@@ -159,6 +159,7 @@ def lib() -> C.CDLL:
     L.fpv_reset.argtypes = [vp, pb, vp, vp, vp, vp, vp]
     L.fpv_step.argtypes = [vp, pb, vp]
     L.fpv_rollout.argtypes = [vp, pb, C.c_int, i64, i64, vp]
+    L.fpv_rollout_graph.argtypes = [vp, pb, C.c_int, i64, i64, vp]
     L.fpv_set_params.argtypes = [vp, pp]
     L.fpv_set_tuning.argtypes = [vp, C.c_int, C.c_int]
     L.fpv_set_step_counter.argtypes = [vp, C.c_uint32]

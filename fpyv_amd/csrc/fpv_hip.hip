@@ -413,6 +413,10 @@ struct fpv_env {
     int dpl;        // drones per lane (1, 2 or 4)
     int block;      // threads per workgroup of the drone step kernel (128 or 256)
     uint32_t launches;   // counts step launches; feeds the stochastic-rounding seed
+    // cached hipGraph of the last fpv_rollout_graph call (launch-bound small batches)
+    hipGraph_t graph = nullptr;
+    hipGraphExec_t graph_exec = nullptr;
+    std::string graph_key;
     bool big_angle;
 };
 
@@ -468,6 +472,7 @@ int check_buffers(const fpv_env* h, const fpv_buffers_t* b, bool need_action)  /
 FpvBufD to_device_view(const fpv_buffers_t* b)
 {
     FpvBufD d;
+    memset(&d, 0, sizeof(d));          // padding bytes are part of the graph-cache key
     d.state = b->state; d.ld = b->ld; d.action = reinterpret_cast<const float4*>(b->action);
     d.reward = b->reward; d.done = b->done; d.done_bits = reinterpret_cast<unsigned long long*>(b->done_bits);
     d.accel = b->accel; d.ep_return = b->ep_return; d.ep_length = b->ep_length;
@@ -500,57 +505,59 @@ int bind_device(const fpv_env* h)
     return FPV_OK;
 }
 
-template <int BS, int DPL>
-void launch_drone(const fpv_env* h, const FpvBufD& d, hipStream_t s)
+// ---- kernel selection: every step kernel has the signature (FpvK, FpvBufD, int64_t) ----------------
+typedef void (*StepKernel)(const FpvK, const FpvBufD, const int64_t);
+struct KernelChoice { StepKernel func; unsigned grid, block; };
+
+template <bool BIG, bool NOISE, bool OBJ, bool KAHAN>
+StepKernel feature_kernel(int block, int dpl)
 {
-    const int64_t per_block = (int64_t)BS * DPL;
-    const dim3 grid((unsigned)((h->n + per_block - 1) / per_block));
-    if (h->big_angle)
-        hipLaunchKernelGGL((fpv_drone_step_kernel<BS, DPL, true>), grid, dim3(BS), 0, s, h->K, d, h->n);
-    else
-        hipLaunchKernelGGL((fpv_drone_step_kernel<BS, DPL, false>), grid, dim3(BS), 0, s, h->K, d, h->n);
+    if (!NOISE && !OBJ && !KAHAN && dpl == 2) return block == 256 ? fpv_drone_step_kernel<256, 2, BIG> : fpv_drone_step_kernel<128, 2, BIG>;
+    if (!NOISE && !OBJ && !KAHAN && dpl == 4) return block == 256 ? fpv_drone_step_kernel<256, 4, BIG> : fpv_drone_step_kernel<128, 4, BIG>;
+    return block == 256 ? fpv_drone_step_kernel<256, 1, BIG, NOISE, OBJ, KAHAN> : fpv_drone_step_kernel<128, 1, BIG, NOISE, OBJ, KAHAN>;
 }
 
-template <int BS>
-void launch_drone_bs(const fpv_env* h, const FpvBufD& d, hipStream_t s)
+template <bool BIG>
+StepKernel drone_kernel(int block, int dpl, bool noise, bool obj, bool kahan)
 {
-    switch (h->dpl) {
-        case 4: launch_drone<BS, 4>(h, d, s); break;
-        case 2: launch_drone<BS, 2>(h, d, s); break;
-        default: launch_drone<BS, 1>(h, d, s); break;
-    }
-}
-
-template <int BS, bool BIG, bool NOISE, bool OBJ, bool KAHAN>
-void launch_feature_kernel(const fpv_env* h, const FpvBufD& d, hipStream_t s)
-{
-    const dim3 grid((unsigned)((h->n + BS - 1) / BS));
-    hipLaunchKernelGGL((fpv_drone_step_kernel<BS, 1, BIG, NOISE, OBJ, KAHAN>), grid, dim3(BS), 0, s, h->K, d, h->n);
-}
-
-template <bool NOISE, bool OBJ, bool KAHAN>
-void launch_features_bs(const fpv_env* h, const FpvBufD& d, hipStream_t s)
-{
-    if (h->block == 256) {
-        if (h->big_angle) launch_feature_kernel<256, true, NOISE, OBJ, KAHAN>(h, d, s);
-        else launch_feature_kernel<256, false, NOISE, OBJ, KAHAN>(h, d, s);
-    } else {
-        if (h->big_angle) launch_feature_kernel<128, true, NOISE, OBJ, KAHAN>(h, d, s);
-        else launch_feature_kernel<128, false, NOISE, OBJ, KAHAN>(h, d, s);
-    }
-}
-
-void launch_features(const fpv_env* h, const FpvBufD& d, hipStream_t s, bool noise, bool obj, bool kahan)
-{
+    // optional features of the one-drone-per-lane kernel are independent template switches
+    // (in-kernel stick noise x object_list collisions x Kahan rows), each combination its own
+    // instantiation, so the plain kernel keeps its register budget
     switch ((noise ? 4 : 0) | (obj ? 2 : 0) | (kahan ? 1 : 0)) {
-        case 1: launch_features_bs<false, false, true>(h, d, s); break;
-        case 2: launch_features_bs<false, true, false>(h, d, s); break;
-        case 3: launch_features_bs<false, true, true>(h, d, s); break;
-        case 4: launch_features_bs<true, false, false>(h, d, s); break;
-        case 5: launch_features_bs<true, false, true>(h, d, s); break;
-        case 6: launch_features_bs<true, true, false>(h, d, s); break;
-        default: launch_features_bs<true, true, true>(h, d, s); break;
+        case 0: return feature_kernel<BIG, false, false, false>(block, dpl);
+        case 1: return feature_kernel<BIG, false, false, true>(block, dpl);
+        case 2: return feature_kernel<BIG, false, true, false>(block, dpl);
+        case 3: return feature_kernel<BIG, false, true, true>(block, dpl);
+        case 4: return feature_kernel<BIG, true, false, false>(block, dpl);
+        case 5: return feature_kernel<BIG, true, false, true>(block, dpl);
+        case 6: return feature_kernel<BIG, true, true, false>(block, dpl);
+        default: return feature_kernel<BIG, true, true, true>(block, dpl);
     }
+}
+
+KernelChoice choose_kernel(const fpv_env* h, const FpvBufD& d)
+{
+    KernelChoice c;
+    c.block = (unsigned)h->block;
+    int64_t per_block = h->block;
+    const bool big = h->big_angle;
+    if (h->mode != FPV_MODE_DRONE) {
+        c.block = kBlock; per_block = kBlock;
+        c.func = fpv_racer_step_kernel;
+    } else if (h->K.flags & FPV_FLAG_FP16_STATE) {
+        c.func = h->block == 256 ? (big ? fpv_drone_step_h_kernel<256, true> : fpv_drone_step_h_kernel<256, false>)
+                                 : (big ? fpv_drone_step_h_kernel<128, true> : fpv_drone_step_h_kernel<128, false>);
+    } else if (d.obs_aos) {
+        c.func = h->block == 256 ? (big ? fpv_drone_step_aos_kernel<256, true> : fpv_drone_step_aos_kernel<256, false>)
+                                 : (big ? fpv_drone_step_aos_kernel<128, true> : fpv_drone_step_aos_kernel<128, false>);
+    } else {
+        const bool noise = (h->K.flags & FPV_FLAG_STICK_NOISE) != 0, obj = d.objs.count > 0, kahan = d.pos_comp != nullptr;
+        const int dpl = (noise || obj || kahan) ? 1 : h->dpl;
+        per_block = (int64_t)h->block * dpl;
+        c.func = big ? drone_kernel<true>(h->block, dpl, noise, obj, kahan) : drone_kernel<false>(h->block, dpl, noise, obj, kahan);
+    }
+    c.grid = (unsigned)((h->n + per_block - 1) / per_block);
+    return c;
 }
 
 int launch_step(fpv_env* h, const FpvBufD& d_in, hipStream_t s)
@@ -558,38 +565,8 @@ int launch_step(fpv_env* h, const FpvBufD& d_in, hipStream_t s)
     FpvBufD d = d_in;
     d.step = h->launches;
     d.seed = d_in.seed + h->launches++;
-    if (h->mode == FPV_MODE_DRONE && (h->K.flags & FPV_FLAG_FP16_STATE)) {
-        const dim3 grid((unsigned)((h->n + h->block - 1) / h->block));
-        if (h->block == 256) {
-            if (h->big_angle) hipLaunchKernelGGL((fpv_drone_step_h_kernel<256, true>), grid, dim3(256), 0, s, h->K, d, h->n);
-            else hipLaunchKernelGGL((fpv_drone_step_h_kernel<256, false>), grid, dim3(256), 0, s, h->K, d, h->n);
-        } else {
-            if (h->big_angle) hipLaunchKernelGGL((fpv_drone_step_h_kernel<128, true>), grid, dim3(128), 0, s, h->K, d, h->n);
-            else hipLaunchKernelGGL((fpv_drone_step_h_kernel<128, false>), grid, dim3(128), 0, s, h->K, d, h->n);
-        }
-    } else if (h->mode == FPV_MODE_DRONE && !d.obs_aos &&
-               ((h->K.flags & FPV_FLAG_STICK_NOISE) || d.pos_comp || d.objs.count > 0)) {
-        // optional features of the one-drone-per-lane kernel are independent template switches:
-        // in-kernel stick noise x object_list collisions x Kahan rows (each its own instantiation, so
-        // the plain kernel keeps its register budget)
-        const bool noise = (h->K.flags & FPV_FLAG_STICK_NOISE) != 0, obj = d.objs.count > 0, kahan = d.pos_comp != nullptr;
-        launch_features(h, d, s, noise, obj, kahan);
-    } else if (h->mode == FPV_MODE_DRONE && d.obs_aos) {
-        const dim3 grid((unsigned)((h->n + h->block - 1) / h->block));
-        if (h->block == 256) {
-            if (h->big_angle) hipLaunchKernelGGL((fpv_drone_step_aos_kernel<256, true>), grid, dim3(256), 0, s, h->K, d, h->n);
-            else hipLaunchKernelGGL((fpv_drone_step_aos_kernel<256, false>), grid, dim3(256), 0, s, h->K, d, h->n);
-        } else {
-            if (h->big_angle) hipLaunchKernelGGL((fpv_drone_step_aos_kernel<128, true>), grid, dim3(128), 0, s, h->K, d, h->n);
-            else hipLaunchKernelGGL((fpv_drone_step_aos_kernel<128, false>), grid, dim3(128), 0, s, h->K, d, h->n);
-        }
-    } else if (h->mode == FPV_MODE_DRONE) {
-        if (h->block == 256) launch_drone_bs<256>(h, d, s);
-        else launch_drone_bs<128>(h, d, s);
-    } else {
-        const dim3 grid((unsigned)((h->n + kBlock - 1) / kBlock));
-        hipLaunchKernelGGL(fpv_racer_step_kernel, grid, dim3(kBlock), 0, s, h->K, d, h->n);
-    }
+    const KernelChoice c = choose_kernel(h, d);
+    hipLaunchKernelGGL(c.func, dim3(c.grid), dim3(c.block), 0, s, h->K, d, h->n);
     const hipError_t e = hipGetLastError();
     if (e != hipSuccess) return hip_fail(e, "step kernel launch");
     return FPV_OK;
@@ -647,7 +624,13 @@ int fpv_create(const fpv_params_t* params, int64_t n, int device, fpv_handle_t* 
     return FPV_OK;
 }
 
-void fpv_destroy(fpv_handle_t h) { delete h; }
+void fpv_destroy(fpv_handle_t h)
+{
+    if (!h) return;
+    if (h->graph_exec) (void)hipGraphExecDestroy(h->graph_exec);
+    if (h->graph) (void)hipGraphDestroy(h->graph);
+    delete h;
+}
 
 int fpv_set_params(fpv_handle_t h, const fpv_params_t* params)
 {
@@ -745,6 +728,60 @@ int fpv_diag_stream_copy(float* dst, const float* src, int64_t n_floats, void* s
     hipLaunchKernelGGL(fpv_diag_copy_kernel, grid, dim3(kBlock), 0, (hipStream_t)stream, dst, src, n_floats);
     const hipError_t e = hipGetLastError();
     if (e != hipSuccess) return hip_fail(e, "diag copy launch");
+    return FPV_OK;
+}
+
+int fpv_rollout_graph(fpv_handle_t h, const fpv_buffers_t* b, int k, int64_t action_stride, int64_t out_stride,
+                      void* stream)
+{
+    int rc = check_buffers(h, b, true);
+    if (rc != FPV_OK) return rc;
+    if (k <= 0) return fail(FPV_EINVAL, "k must be positive");
+    if (action_stride % 4) return fail(FPV_EALIGN, "action_stride must keep 16-byte alignment");
+    if (h->K.flags & (FPV_FLAG_STICK_NOISE | FPV_FLAG_FP16_STATE))
+        return fail(FPV_EINVAL, "fpv_rollout_graph replays frozen kernel arguments; stick noise and fp16 state need the "
+                                "per-launch step index - use fpv_rollout");
+    if ((rc = bind_device(h)) != FPV_OK) return rc;
+    // the graph is valid for exactly these arguments
+    FpvBufD d0 = to_device_view(b);
+    std::string key(reinterpret_cast<const char*>(&d0), sizeof(d0));
+    key.append(reinterpret_cast<const char*>(&h->K), sizeof(h->K));
+    const int64_t meta[6] = {k, action_stride, out_stride, h->dpl, h->block, h->n};
+    key.append(reinterpret_cast<const char*>(meta), sizeof(meta));
+    if (!h->graph_exec || key != h->graph_key) {
+        if (h->graph_exec) { (void)hipGraphExecDestroy(h->graph_exec); h->graph_exec = nullptr; }
+        if (h->graph) { (void)hipGraphDestroy(h->graph); h->graph = nullptr; }
+        hipError_t e = hipGraphCreate(&h->graph, 0);
+        if (e != hipSuccess) return hip_fail(e, "hipGraphCreate");
+        hipGraphNode_t prev = nullptr;
+        FpvK K = h->K;
+        int64_t n = h->n;
+        for (int t = 0; t < k; ++t) {
+            FpvBufD d = d0;
+            d.action = reinterpret_cast<const float4*>(b->action + (int64_t)t * action_stride);
+            if (out_stride) {
+                if (b->reward) d.reward = b->reward + (int64_t)t * out_stride;
+                if (b->done) d.done = b->done + (int64_t)t * out_stride;
+            }
+            const KernelChoice c = choose_kernel(h, d);
+            void* args[3] = {&K, &d, &n};                 // copied by hipGraphAddKernelNode
+            hipKernelNodeParams np;
+            memset(&np, 0, sizeof(np));
+            np.func = reinterpret_cast<void*>(c.func);
+            np.gridDim = dim3(c.grid); np.blockDim = dim3(c.block);
+            np.sharedMemBytes = 0; np.kernelParams = args; np.extra = nullptr;
+            hipGraphNode_t node;
+            e = hipGraphAddKernelNode(&node, h->graph, prev ? &prev : nullptr, prev ? 1 : 0, &np);
+            if (e != hipSuccess) return hip_fail(e, "hipGraphAddKernelNode");
+            prev = node;
+        }
+        e = hipGraphInstantiate(&h->graph_exec, h->graph, nullptr, nullptr, 0);
+        if (e != hipSuccess) return hip_fail(e, "hipGraphInstantiate");
+        h->graph_key = key;
+    }
+    const hipError_t e = hipGraphLaunch(h->graph_exec, (hipStream_t)stream);
+    if (e != hipSuccess) return hip_fail(e, "hipGraphLaunch");
+    h->launches += (uint32_t)k;
     return FPV_OK;
 }
 

@@ -239,7 +239,7 @@ class _Batch:
 
     def rollout(self, actions: Optional[torch.Tensor], wind: Optional[Sequence[float]] = None,
                 rewards: Optional[torch.Tensor] = None, dones: Optional[torch.Tensor] = None,
-                steps: Optional[int] = None) -> None:
+                steps: Optional[int] = None, graph: bool = False) -> None:
         """k steps back to back without returning to Python: actions [k, num_envs, 4] (one batch
         per step) or [num_envs, 4] with `rewards`/`dones` of shape [k, num_envs] (or `steps`) giving
         k; actions=None with stick_noise=True runs `steps` steps of pure in-kernel noise sticks."""
@@ -272,7 +272,8 @@ class _Batch:
             b.reward = rewards.data_ptr() if rewards is not None else None
             b.done = dones.data_ptr() if dones is not None else None
         try:
-            _lib.check(self._L.fpv_rollout(self._handle, C.byref(b), int(k), stride, out_stride, self._stream()))
+            fn = self._L.fpv_rollout_graph if graph else self._L.fpv_rollout     # graph: cached hipGraph replay
+            _lib.check(fn(self._handle, C.byref(b), int(k), stride, out_stride, self._stream()))
             self._steps_launched = (self._steps_launched + int(k)) & 0xFFFFFFFF
         finally:
             b.reward, b.done = saved

@@ -191,6 +191,13 @@ int fpv_rollout(fpv_handle_t h, const fpv_buffers_t* b, int k, int64_t action_st
  * handle from 0; set it to resume / replay a run. */
 int fpv_set_step_counter(fpv_handle_t h, uint32_t step);
 
+/* Same k steps as fpv_rollout, replayed from a hipGraph that is built on the first call with a given
+ * set of arguments and cached in the handle: for small, launch-bound batches (a 4096-drone step is
+ * ~2 us of kernel behind ~4 us of launch).  Frozen arguments mean no per-launch step index, so handles
+ * with FPV_FLAG_STICK_NOISE or FPV_FLAG_FP16_STATE are refused (use fpv_rollout). */
+int fpv_rollout_graph(fpv_handle_t h, const fpv_buffers_t* b, int k, int64_t action_stride,
+                      int64_t out_stride, void* stream);
+
 /* Replace the drone type of a live handle (e.g. domain randomisation between episodes). */
 int fpv_set_params(fpv_handle_t h, const fpv_params_t* params);
 

@@ -690,3 +690,26 @@ def test_big_angle_path_on_gpu(params_1k):
     oracle.drone_run(p_big, ref, acts2.astype(np.float64))
     err = soa_vs_oracle(env.state.cpu().numpy(), ref, n)
     assert err["quat_abs"] < 5e-5 and err["pos_rel"] < 5e-5, err
+
+
+def test_graph_rollout_equals_plain_rollout(params_1k):
+    """fpv_rollout_graph: k launches replayed from a cached hipGraph (small, launch-bound batches)."""
+    from fpyv_amd.env import DroneBatch
+    n, k = 4096, 40
+    acts = torch.from_numpy(sticks.ema_noise(k, range(n), seed=8)).to(DEV)
+    acts2 = (acts * 0.5).contiguous()
+    e1, e2 = _drone_batch(params_1k, n), _drone_batch(params_1k, n)
+    e1.reset(); e2.reset()
+    r1 = torch.zeros((k, n), device=DEV); r2 = torch.zeros((k, n), device=DEV)
+    for rep in range(3):                               # same arguments: the cached graph is replayed
+        e1.rollout(acts, rewards=r1)
+        e2.rollout(acts, rewards=r2, graph=True)
+    e1.rollout(acts2); e2.rollout(acts2, graph=True)   # new arguments: the graph is rebuilt
+    e1.rollout(acts, rewards=r1); e2.rollout(acts, rewards=r2, graph=True)
+    torch.cuda.synchronize()
+    assert torch.equal(e1.state, e2.state) and torch.equal(r1, r2) and torch.equal(e1.done_u8, e2.done_u8)
+    assert e1.state_dict()["step_counter"] == e2.state_dict()["step_counter"] == 5 * k
+    noisy = DroneBatch(params_1k, 64, device=DEV, stick_noise=True)
+    noisy.reset()
+    with pytest.raises(_lib.FpvError, match="fpv_rollout"):
+        noisy.rollout(acts[:, :64].contiguous(), graph=True)

@@ -27,6 +27,7 @@ def main():
     ap.add_argument("--aos", action="store_true", help="also time the step with the [n,16] AoS observation head")
     ap.add_argument("--noise", action="store_true", help="also time pure in-kernel noise sticks (no action read)")
     ap.add_argument("--extras", action="store_true", help="also time the Kahan-row and 4-object collision variants")
+    ap.add_argument("--graph", action="store_true", help="also time the hipGraph-replayed rollout")
     ap.add_argument("--out", default=None)
     a = ap.parse_args()
     dev = torch.device("cuda:0")
@@ -65,6 +66,8 @@ def main():
         envs["obj1x128"] = eo
         a.geom = list(a.geom) + ["kahan1x128", "obj1x128"]
     variants = [(g, api) for g in a.geom for api in ("rollout", "step")]
+    if a.graph:
+        variants += [(g, "graph") for g in a.geom if g[0].isdigit()]
     times = {v: [] for v in variants}
     ev0, ev1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
     for r in range(a.rounds + 1):
@@ -83,6 +86,8 @@ def main():
                     else:
                         for t in range(span):
                             e.step(None, return_imu=False)
+                elif api == "graph":
+                    e.rollout(acts[:span], graph=True)
                 elif api == "rollout":
                     e.rollout(acts[:span])
                 else:
