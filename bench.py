@@ -109,7 +109,20 @@ def main():
     if multi:
         if "MASTER_ADDR" not in os.environ:
             os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT="29517", RANK="0", WORLD_SIZE="1")
-        dist.init_process_group(backend="nccl", device_id=dev)
+        # RCCL prints a version banner on STDOUT when the first communicator comes up; the driver reads
+        # exactly one JSON line there, so route fd 1 to stderr until the communicator exists
+        sys.stdout.flush()
+        saved_fd = os.dup(1)
+        os.dup2(2, 1)
+        try:
+            dist.init_process_group(backend="nccl", device_id=dev)
+            warm = torch.zeros(1, device=dev)
+            dist.all_reduce(warm)
+            torch.cuda.synchronize()
+        finally:
+            sys.stdout.flush()
+            os.dup2(saved_fd, 1)
+            os.close(saved_fd)
 
     n = args.drones_per_gpu
     # dt = 1 ms; lanes that hit the ground or leave |z| <= ceiling are re-initialised in-kernel
