@@ -239,10 +239,12 @@ class _Batch:
 
     def rollout(self, actions: Optional[torch.Tensor], wind: Optional[Sequence[float]] = None,
                 rewards: Optional[torch.Tensor] = None, dones: Optional[torch.Tensor] = None,
-                steps: Optional[int] = None, graph: bool = False) -> None:
+                steps: Optional[int] = None, graph: Optional[bool] = None) -> None:
         """k steps back to back without returning to Python: actions [k, num_envs, 4] (one batch
         per step) or [num_envs, 4] with `rewards`/`dones` of shape [k, num_envs] (or `steps`) giving
-        k; actions=None with stick_noise=True runs `steps` steps of pure in-kernel noise sticks."""
+        k; actions=None with stick_noise=True runs `steps` steps of pure in-kernel noise sticks.
+        graph=True replays the launches from a hipGraph cached in the handle (fpv_rollout_graph);
+        the default (None) does so for launch-bound batches (<= 2^17 drones) when the handle allows it."""
         b = self._buf
         if actions is None:
             if not self.stick_noise or steps is None:
@@ -272,6 +274,8 @@ class _Batch:
             b.reward = rewards.data_ptr() if rewards is not None else None
             b.done = dones.data_ptr() if dones is not None else None
         try:
+            if graph is None:
+                graph = (self.n <= (1 << 17) and actions is not None and not self.stick_noise and not self.fp16_state)
             fn = self._L.fpv_rollout_graph if graph else self._L.fpv_rollout     # graph: cached hipGraph replay
             _lib.check(fn(self._handle, C.byref(b), int(k), stride, out_stride, self._stream()))
             self._steps_launched = (self._steps_launched + int(k)) & 0xFFFFFFFF
