@@ -51,6 +51,7 @@ class _Batch:
         self.rows = _lib.state_rows(self.mode)
         self.ld = int(self._L.fpv_recommended_ld(self.n))
         dev_index = self.device.index if self.device.index is not None else torch.cuda.current_device()
+        self._dev_index = int(dev_index)
         self._handle = C.c_void_p()
         self.fp16_state = bool(fp16_state)
         self.rounding_seed = int(rounding_seed) & 0xFFFFFFFF
@@ -88,8 +89,11 @@ class _Batch:
         # optional row-major [num_envs, 16] observation written by the kernel through an LDS transpose
         self.obs_aos = (torch.zeros((self.n, _lib.FPV_OBS_AOS_DIM), **f32) if with_obs_aos else None)
         self._bcast_action = None
+        self._ashape = torch.Size((self.n, 4))
         self._steps_launched = 0        # mirrors the handle's launch counter (fpv_set_step_counter)
         self._buf = _lib.FpvBuffers()
+        self._buf_ref = C.byref(self._buf)
+        self._fpv_step = self._L.fpv_step
         self._fill_buffers()
 
     # -- plumbing ---------------------------------------------------------------------------------
@@ -124,13 +128,23 @@ class _Batch:
         return int(self._L.fpv_handle_algorithmic_bytes(self._handle))
 
     def _stream(self) -> int:
-        return torch.cuda.current_stream(self.device).cuda_stream
+        """hipStream_t of torch's current stream on this device (raw handle; ~5x cheaper than building
+        a torch.cuda.Stream object on every step)."""
+        try:
+            return torch._C._cuda_getCurrentRawStream(self._dev_index)
+        except AttributeError:                       # private fast path gone in some future torch
+            return torch.cuda.current_stream(self.device).cuda_stream
 
     def _action_ptr(self, action: Any) -> Optional[int]:
         if action is None:
             if not self.stick_noise:
                 raise ValueError("action=None is only meaningful with stick_noise=True (pure noise sticks)")
             return None
+        # hot path: a contiguous float32 [num_envs, 4] tensor on the env's device
+        if (type(action) is torch.Tensor and action.dtype is torch.float32 and action.shape == self._ashape
+                and action.is_contiguous() and action.device == self.state.device):
+            self._keepalive = action
+            return action.data_ptr()
         if not torch.is_tensor(action):
             action = torch.as_tensor(np.asarray(action, dtype=np.float32), device=self.device)
         if action.dim() == 1:
@@ -234,7 +248,9 @@ class _Batch:
         b.action = self._action_ptr(action)
         if wind is not None:
             b.wind[0], b.wind[1], b.wind[2] = float(wind[0]), float(wind[1]), float(wind[2])
-        _lib.check(self._L.fpv_step(self._handle, C.byref(b), self._stream()))
+        rc = self._fpv_step(self._handle, self._buf_ref, self._stream())
+        if rc < 0:
+            _lib.check(rc)
         self._steps_launched = (self._steps_launched + 1) & 0xFFFFFFFF
 
     def rollout(self, actions: Optional[torch.Tensor], wind: Optional[Sequence[float]] = None,
