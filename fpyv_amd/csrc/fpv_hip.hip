@@ -642,7 +642,7 @@ int fpv_set_params(fpv_handle_t h, const fpv_params_t* params)
     if (!h || !params) return fail(FPV_EINVAL, "null argument");
     if ((int)params->mode != h->mode) return fail(FPV_EINVAL, "mode cannot change on a live handle (state layout differs)");
     if ((params->flags ^ h->P.flags) & (FPV_FLAG_FP16_STATE | FPV_FLAG_STICK_NOISE))
-        return fail(FPV_EINVAL, "FPV_FLAG_FP16_STATE cannot change on a live handle (state layout differs)");
+        return fail(FPV_EINVAL, "FPV_FLAG_FP16_STATE / FPV_FLAG_STICK_NOISE cannot change on a live handle (buffer layout differs)");
     FpvK K;
     bool big = false;
     const char* why = "";

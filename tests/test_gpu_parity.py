@@ -713,3 +713,27 @@ def test_graph_rollout_equals_plain_rollout(params_1k):
     noisy.reset()
     with pytest.raises(_lib.FpvError, match="fpv_rollout"):
         noisy.rollout(acts[:, :64].contiguous(), graph=True)
+
+
+def test_set_params_on_a_live_handle(params_1k):
+    """fpv_set_params: swap the drone type mid-run (domain randomisation); equals a fresh handle with the
+    new parameters started from the same state; layout-changing switches are refused."""
+    n = 500
+    acts = torch.from_numpy(sticks.ema_noise(60, range(n), seed=4)).to(DEV)
+    heavy = params_1k.replace(mass=1.1, max_rates=350.0, drag_coefficients=np.array([2.2, 2.0, 1.0]))
+    a = _drone_batch(params_1k, n)
+    a.reset()
+    a.rollout(acts[:30])
+    mid = a.state.clone()
+    a.set_params(heavy)
+    a.rollout(acts[30:])
+    b = _drone_batch(heavy, n)
+    b.state.copy_(mid)
+    b.rollout(acts[30:])
+    torch.cuda.synchronize()
+    assert torch.equal(a.state, b.state)
+    assert not torch.equal(a.state, mid)
+    with pytest.raises(_lib.FpvError):
+        a.set_params(heavy.replace(mode=1))
+    with pytest.raises(_lib.FpvError, match="dt"):
+        a.set_params(heavy.replace(dt=-1.0))
