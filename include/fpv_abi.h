@@ -205,9 +205,9 @@ int fpv_set_params(fpv_handle_t h, const fpv_params_t* params);
  * the built-in choice (1 drone per lane, 128 threads - the fastest measured on MI355X). */
 int fpv_set_tuning(fpv_handle_t h, int drones_per_lane, int block_threads);
 
-/* Row stride (in floats) to allocate for n drones: n rounded up to 64, plus 256 when that would
- * make the stride a multiple of 8 KiB (power-of-two strides put all 14 rows on the same HBM
- * channel/bank set).  Any ld >= n that is a multiple of 4 is accepted by fpv_step. */
+/* Row stride (in floats) to allocate for n drones: n rounded up to 64, padded so that the stride in
+ * bytes is at least 1 KiB past a multiple of 8 KiB (strides at or near a multiple of 8 KiB put all 14
+ * rows on the same HBM channel/bank set).  Any ld >= n that is a multiple of 4 is accepted by fpv_step. */
 int64_t fpv_recommended_ld(int64_t n);
 
 /* Diagnostics only: dst[i] = src[i] for n_floats fp32 values with the step kernel's access shape
