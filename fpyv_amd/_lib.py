@@ -29,7 +29,7 @@ PX, PY, PZ, VX, VY, VZ, QW, QX, QY, QZ, RX, RY, RZ, THRUST = range(14)
 R_OMEGA, R_IERR, R_LERR, R_FIRST = 10, 13, 16, 19
 
 # every symbol include/fpv_abi.h declares
-EXPORTS = ("fpv_abi_version", "fpv_state_rows", "fpv_algorithmic_bytes", "fpv_handle_algorithmic_bytes", "fpv_create", "fpv_destroy",
+EXPORTS = ("fpv_abi_version", "fpv_sizeof", "fpv_state_rows", "fpv_algorithmic_bytes", "fpv_handle_algorithmic_bytes", "fpv_create", "fpv_destroy",
            "fpv_reset", "fpv_step", "fpv_rollout", "fpv_rollout_graph", "fpv_set_params", "fpv_set_step_counter", "fpv_set_tuning", "fpv_recommended_ld",
            "fpv_diag_stream_copy", "fpv_last_error",
            "fpv_error_name")
@@ -87,7 +87,7 @@ class FpvBuffers(C.Structure):
         ("done", C.c_void_p), ("done_bits", C.c_void_p), ("accel", C.c_void_p), ("ep_return", C.c_void_p),
         ("ep_length", C.c_void_p), ("last_return", C.c_void_p), ("last_length", C.c_void_p),
         ("wind", C.c_float * 3), ("rounding_seed", C.c_uint32), ("state_h", C.c_void_p),
-        ("pos_comp", C.c_void_p), ("noise_state", C.c_void_p), ("action_out", C.c_void_p), ("objects", C.c_void_p), ("obs_aos", C.c_void_p),
+        ("pos_comp", C.c_void_p), ("noise_state", C.c_void_p), ("action_out", C.c_void_p), ("action_ld", C.c_int64), ("objects", C.c_void_p), ("obs_aos", C.c_void_p),
     ]
 
 
@@ -169,6 +169,11 @@ def lib() -> C.CDLL:
     L.fpv_last_error.restype = C.c_char_p
     L.fpv_error_name.argtypes = [C.c_int]
     L.fpv_error_name.restype = C.c_char_p
+    L.fpv_sizeof.argtypes = [C.c_int]
+    for which, struct in ((0, FpvParams), (1, FpvBuffers), (2, FpvObjects)):
+        if L.fpv_sizeof(which) != C.sizeof(struct):
+            raise ImportError(f"{struct.__name__}: ctypes declares {C.sizeof(struct)} bytes, libfpv_hip.so has "
+                              f"{L.fpv_sizeof(which)} - _lib.py and include/fpv_abi.h are out of step")
     if L.fpv_abi_version() != FPV_ABI_VERSION:
         raise ImportError(f"libfpv_hip.so ABI {L.fpv_abi_version()} != binding {FPV_ABI_VERSION}")
     _lib = L

@@ -50,6 +50,7 @@ struct FpvBufD {
     float* noise_state;    // FPV_FLAG_STICK_NOISE: [4][ld] EMA stick-noise state
     float4* action_out;    // [n] applied action or null
     uint32_t step;         // launch index of the handle: Philox counter word
+    int64_t action_ld;     // 0: action is [n][4] rows; > 0: action is [4][action_ld] SoA (a GEMM's [4, n] output)
     FpvObjects objs;       // the step's object_list (count 0 = none); only the OBJ instantiation reads it
     uint16_t* state_h;     // FPV_FLAG_FP16_STATE: [11][ld] binary16 rows (v, q, rates, thrust)
     uint32_t seed;         // stochastic-rounding seed of this launch
@@ -92,6 +93,18 @@ __device__ __forceinline__ float4 ld_action(const float4* __restrict__ a, uint32
 {
     const fpv_v4f v = __builtin_nontemporal_load(&row_at(reinterpret_cast<const fpv_v4f*>(a), i));
     return make_float4(v.x, v.y, v.z, v.w);
+}
+
+// either layout: rows [n][4] (one 16-byte load) or SoA [4][action_ld] (four dword loads) - the latter is
+// what `W[4,13] @ obs[13,n]` produces, so a policy can feed the stepper without a transpose kernel
+__device__ __forceinline__ float4 ld_action_any(const float4* __restrict__ a, int64_t action_ld, uint32_t i)
+{
+    if (action_ld == 0) return ld_action(a, i);
+    const float* __restrict__ f = reinterpret_cast<const float*>(a);
+    return make_float4(__builtin_nontemporal_load(&row_at(ROW(f, 0, action_ld), i)),
+                       __builtin_nontemporal_load(&row_at(ROW(f, 1, action_ld), i)),
+                       __builtin_nontemporal_load(&row_at(ROW(f, 2, action_ld), i)),
+                       __builtin_nontemporal_load(&row_at(ROW(f, 3, action_ld), i)));
 }
 
 // Episode bookkeeping + done outputs shared by both modes.  `done` is wave-divergent data;
@@ -153,7 +166,7 @@ __global__ __launch_bounds__(BS) void fpv_drone_step_kernel(const FpvK K, const 
         const uint32_t i = base + (uint32_t)j * BS;
         live[j] = i < n;
         if (live[j]) {
-            a[j] = (!NOISE || B.action) ? ld_action(B.action, i) : make_float4(0.f, 0.f, 0.f, 0.f);
+            a[j] = (!NOISE || B.action) ? ld_action_any(B.action, B.action_ld, i) : make_float4(0.f, 0.f, 0.f, 0.f);
             ld_drone(B.state, B.ld, i, s[j]);
             if (NOISE) a[j] = apply_stick_noise(K, B, i, a[j]);
         }
@@ -439,6 +452,11 @@ int check_buffers(const fpv_env* h, const fpv_buffers_t* b, bool need_action)  /
         if (b->obs_aos) return fail(FPV_EINVAL, "obs_aos and FPV_FLAG_STICK_NOISE cannot be combined");
     }
     if ((uintptr_t)b->action_out & 15) return fail(FPV_EALIGN, "action_out must be 16-byte aligned");
+    if (b->action_ld) {
+        if (b->action_ld < h->n) return fail(FPV_EALIGN, "action_ld must be >= n");   // dword loads: no alignment rule
+        if (h->mode != FPV_MODE_DRONE || (h->K.flags & FPV_FLAG_FP16_STATE) || b->obs_aos)
+            return fail(FPV_EINVAL, "SoA actions (action_ld) are supported by the fp32 drone kernel without obs_aos");
+    }
     if (b->ld < h->n) return fail(FPV_EALIGN, "fpv_buffers_t.ld is smaller than the number of drones");
     if (b->ld % 4) return fail(FPV_EALIGN, "fpv_buffers_t.ld must be a multiple of 4 floats");
     if (((uintptr_t)b->state & 15) || ((uintptr_t)b->action & 15))
@@ -486,6 +504,7 @@ FpvBufD to_device_view(const fpv_buffers_t* b)
     d.state_h = b->state_h; d.seed = b->rounding_seed; d.obs_aos = b->obs_aos;
     d.pos_comp = b->pos_comp;
     d.noise_state = b->noise_state; d.action_out = reinterpret_cast<float4*>(b->action_out); d.step = 0;
+    d.action_ld = b->action_ld;
     d.objs.count = 0;
     if (b->objects) {
         d.objs.count = b->objects->count;
@@ -582,6 +601,16 @@ int launch_step(fpv_env* h, const FpvBufD& d_in, hipStream_t s)
 extern "C" {
 
 int fpv_abi_version(void) { return FPV_ABI_VERSION; }
+
+int fpv_sizeof(int which)
+{
+    switch (which) {
+        case 0: return (int)sizeof(fpv_params_t);
+        case 1: return (int)sizeof(fpv_buffers_t);
+        case 2: return (int)sizeof(fpv_objects_t);
+        default: return fail(FPV_EINVAL, "fpv_sizeof: 0 = fpv_params_t, 1 = fpv_buffers_t, 2 = fpv_objects_t");
+    }
+}
 
 int fpv_state_rows(int mode)
 {

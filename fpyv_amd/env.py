@@ -144,7 +144,16 @@ class _Batch:
         if (type(action) is torch.Tensor and action.dtype is torch.float32 and action.shape == self._ashape
                 and action.is_contiguous() and action.device == self.state.device):
             self._keepalive = action
+            self._buf.action_ld = 0
             return action.data_ptr()
+        # SoA sticks [4, num_envs] (e.g. the output of `W @ obs_soa`): consumed in place, no transpose
+        if (type(action) is torch.Tensor and action.dim() == 2 and action.shape[0] == 4 and action.shape[1] == self.n
+                and self.n != 4 and action.dtype is torch.float32 and action.stride(1) == 1 and action.stride(0) >= self.n
+                and action.device == self.state.device):
+            self._keepalive = action
+            self._buf.action_ld = action.stride(0)
+            return action.data_ptr()
+        self._buf.action_ld = 0
         if not torch.is_tensor(action):
             action = torch.as_tensor(np.asarray(action, dtype=np.float32), device=self.device)
         if action.dim() == 1:
@@ -278,6 +287,7 @@ class _Batch:
                                     or actions.device != self.state.device):
             raise ValueError("actions must be a contiguous float32 tensor on the env's device")
         b.action = actions.data_ptr() if actions is not None else None
+        b.action_ld = 0
         if wind is not None:
             b.wind[0], b.wind[1], b.wind[2] = float(wind[0]), float(wind[1]), float(wind[2])
         out_stride = 0

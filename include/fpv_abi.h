@@ -131,7 +131,8 @@ typedef struct fpv_objects { int32_t count; fpv_object_t obj[FPV_MAX_OBJECTS]; }
 typedef struct fpv_buffers {
     float* state;            /* [rows][ld] SoA, 16-byte aligned */
     int64_t ld;              /* row stride in floats, >= n, multiple of 4 */
-    const float* action;     /* [n][4] = roll, pitch, yaw, throttle per drone (components.py:181-186), 16-byte aligned */
+    const float* action;     /* [n][4] = roll, pitch, yaw, throttle per drone (components.py:181-186), 16-byte aligned;
+                                or, when action_ld > 0, SoA [4][action_ld] */
     float* reward;           /* [n] */
     uint8_t* done;           /* [n] 0/1  (Drone.done, components.py:236-240) */
     uint64_t* done_bits;     /* [ceil(n/64)] bit i%64 of word i/64 = done[i]; 8-byte aligned */
@@ -148,6 +149,8 @@ typedef struct fpv_buffers {
                                 fp32 state; combines with stick noise and objects, not with obs_aos */
     float* noise_state;      /* FPV_FLAG_STICK_NOISE: [4][ld] EMA stick-noise state (read-modify-write); else unused */
     float* action_out;       /* [n][4] the action actually applied (after noise and clipping), 16-byte aligned, or NULL */
+    int64_t action_ld;       /* 0: `action` is [n][4]; > 0: `action` is [4][action_ld] (row stride in floats, >= n)
+                                - the layout of a `W[4,D] @ obs[D,n]` GEMM output; fp32 drone kernel */
     const struct fpv_objects* objects; /* HOST pointer, read during the call: the step's object_list, or NULL.
                                 Drone mode, fp32 state; combines with stick noise and pos_comp; not with obs_aos or
                                 FPV_FLAG_GROUND (put a Ground entry in the list instead) */
@@ -159,6 +162,9 @@ typedef struct fpv_buffers {
 typedef struct fpv_env* fpv_handle_t;
 
 int fpv_abi_version(void);
+/* sizeof of the ABI structs as this library was compiled (0 fpv_params_t, 1 fpv_buffers_t, 2 fpv_objects_t):
+ * lets a foreign-language binding verify its struct declarations at load time */
+int fpv_sizeof(int which);
 /* rows of the state matrix for a mode (FPV_DRONE_ROWS / FPV_RACER_ROWS), or FPV_EINVAL */
 int fpv_state_rows(int mode);
 /* bytes each env-step must move at minimum (state R+W, action R, reward+done W) - roofline bookkeeping */

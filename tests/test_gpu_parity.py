@@ -737,3 +737,27 @@ def test_set_params_on_a_live_handle(params_1k):
         a.set_params(heavy.replace(mode=1))
     with pytest.raises(_lib.FpvError, match="dt"):
         a.set_params(heavy.replace(dt=-1.0))
+
+
+def test_soa_action_layout_equals_row_layout(params_1k):
+    """Sticks given as [4, n] (the layout of `W[4,13] @ obs[13,n]`) are consumed in place and give
+    exactly the step of the [n, 4] layout; a closed policy loop therefore needs no transpose kernels."""
+    n, k = 3001, 25
+    rows = torch.from_numpy(sticks.ema_noise(k, range(n), seed=6)).to(DEV)       # [k, n, 4]
+    e1, e2 = _drone_batch(params_1k, n), _drone_batch(params_1k, n)
+    e1.reset(); e2.reset()
+    ld = e2.ld
+    soa = torch.zeros((4, ld), device=DEV)
+    for t in range(k):
+        e1.step(rows[t], return_imu=False)
+        soa[:, :n] = rows[t].t()
+        e2.step(soa[:, :n], return_imu=False)          # a [4, n] view with row stride ld
+    torch.cuda.synchronize()
+    assert torch.equal(e1.state, e2.state) and torch.equal(e1.reward, e2.reward)
+    # closed loop: a linear policy on the zero-copy SoA observation
+    W = torch.randn(4, 13, device=DEV) * 0.02
+    for t in range(50):
+        obs_soa = e2.state[:13, :n]                    # [13, n], no copy
+        e2.step(torch.tanh(W @ obs_soa), return_imu=False)
+    torch.cuda.synchronize()
+    assert bool(torch.isfinite(e2.state).all())
