@@ -71,6 +71,9 @@ static inline int fpv_derive_constants(const fpv_params_t* P, FpvK* K, bool* big
     K->motor_radius = (float)P->motor_radius;
     K->ground_k_m = (float)(P->ground_spring / P->mass);
     K->ground_c_m = (float)(P->ground_damping / P->mass);
+    double arm = 0.0;
+    for (int m = 0; m < 4; ++m) arm = fmax(arm, sqrt(P->motor_xy[m][0] * P->motor_xy[m][0] + P->motor_xy[m][1] * P->motor_xy[m][1]));
+    K->contact_reach = (float)(arm + fmax(P->motor_radius, 0.0) + 1e-3);
     K->noise.tau = (float)P->noise_transition;
     K->noise.omtau = (float)(1.0 - P->noise_transition);
     K->noise.gain = (float)P->noise_gain;

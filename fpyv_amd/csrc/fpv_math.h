@@ -59,6 +59,7 @@ struct FpvK {
     float r_dt_over_I[3];
     float r_pid[3][3];
     float motor_radius, ground_k_m, ground_c_m;   // contact distance; spring and damping already divided by m
+    float contact_reach;    // largest |motor offset| + motor_radius + 1 mm: centre-distance bound for the object cull
     FpvNoiseK noise;
     uint32_t flags;
 };
@@ -330,13 +331,33 @@ struct FpvStepOut {
 struct FpvObject { int32_t type; float x, y, z, radius, height; };      // type: 0 Ground, 1 Cylinder, 2 Target
 struct FpvObjects { int32_t count; FpvObject o[FPV_MAX_OBJECTS]; };
 
+// wave-level "does any lane need this": on the device one ballot, on the host the lane's own flag
+#if defined(__HIP_DEVICE_COMPILE__)
+#define FPV_WAVE_ANY(x) (__builtin_amdgcn_ballot_w64(x) != 0ull)
+#else
+#define FPV_WAVE_ANY(x) (x)
+#endif
+
 FPV_HD bool fpv_collide_objects(const FpvK& K, const FpvObjects& T, const float mx[4], const float my[4],
-                                const float mz[4], float vx, float vy, float vz, float acc[3])
+                                const float mz[4], float cx, float cy, float cz, float vx, float vy, float vz,
+                                float acc[3])
 {
     bool crashed = false;
     acc[0] = acc[1] = acc[2] = 0.0f;
+    const float reach = K.contact_reach;       // arm + motor_radius + 1 mm: no motor can touch beyond this
     for (int o = 0; o < T.count && !crashed; ++o) {
         const FpvObject& ob = T.o[o];
+        // cheap conservative cull on the drone centre; a whole wave with nobody near skips the
+        // sqrt/divide-heavy per-motor pass (culled lanes would get exactly zero force and no crash)
+        bool near;
+        {
+            const float dx = cx - ob.x, dy = cy - ob.y, dz = cz - ob.z;
+            const float rr = ob.radius + reach;
+            if (ob.type == 0) near = cz < reach;
+            else if (ob.type == 1) near = fmaf(dx, dx, dy * dy) < rr * rr && dz > -reach && dz < ob.height + reach;
+            else near = fmaf(dx, dx, fmaf(dy, dy, dz * dz)) < rr * rr;
+        }
+        if (!FPV_WAVE_ANY(near)) continue;
         float dist[4], nx[4], ny[4], nz[4];
 #pragma unroll
         for (int m = 0; m < 4; ++m) {
@@ -435,7 +456,7 @@ FPV_HD FpvStepOut fpv_drone_step_lane(const FpvK& K, FpvDroneState& s, float a0,
             myw[m] = s.py + fmaf(K.motor_x[m], R.r10, K.motor_y[m] * R.r11);
             mzw[m] = s.pz + fmaf(K.motor_x[m], R.r20, K.motor_y[m] * R.r21);
         }
-        const bool crashed = fpv_collide_objects(K, *objs, mxw, myw, mzw, s.vx, s.vy, s.vz, ca);
+        const bool crashed = fpv_collide_objects(K, *objs, mxw, myw, mzw, s.px, s.py, s.pz, s.vx, s.vy, s.vz, ca);
         accx += ca[0]; accy += ca[1]; accz += ca[2];
         done = done || crashed;
     }

@@ -62,7 +62,7 @@ def main():
         envs["kahan1x128"] = ek
         eo = DroneBatch(p, a.n, device=dev, with_accel=False)
         eo.reset()
-        eo._set_objects([Target([0, -6, 3], 0.8), Cylinder([3, 0, 0], 1.0, 5.0), Cylinder([-2, 2.5, 0], 0.6, 1.5), Ground()])
+        world = [Target([0, -6, 3], 0.8), Cylinder([3, 0, 0], 1.0, 5.0), Cylinder([-2, 2.5, 0], 0.6, 1.5), Ground()]
         envs["obj1x128"] = eo
         a.geom = list(a.geom) + ["kahan1x128", "obj1x128"]
     variants = [(g, api) for g in a.geom for api in ("rollout", "step")]
@@ -86,6 +86,13 @@ def main():
                     else:
                         for t in range(span):
                             e.step(None, return_imu=False)
+                elif d.startswith("obj"):
+                    if api == "rollout":
+                        e._set_objects(world)
+                        e.rollout(acts[:span], graph=False)
+                    else:
+                        for t in range(span):
+                            e.step(acts[t], object_list=world, return_imu=False)
                 elif api == "graph":
                     e.rollout(acts[:span], graph=True)
                 elif api == "rollout":
