@@ -13,25 +13,26 @@ from typing import Optional
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, "libfpv_hip.so")
 
-FPV_ABI_VERSION = 1
+FPV_ABI_VERSION = 2
 FPV_OK = 0
 FPV_MODE_DRONE, FPV_MODE_RACER = 0, 1
-FPV_DRONE_ROWS, FPV_RACER_ROWS = 14, 20
+FPV_DRONE_ROWS, FPV_RACER_ROWS = 14, 29
 FPV_FLAG_AUTO_RESET = 1
 FPV_FLAG_GROUND = 2
 FPV_FLAG_FP16_STATE = 4
 FPV_FLAG_STICK_NOISE = 8
-FPV_HALF_PAIR_ROWS = 6
+FPV_HALF_PAIR_ROWS = 5
+FPV_HALF_HALVES = 11          # binary16 values per drone in state_h (5 pair rows + 1 half row)
 FPV_OBS_AOS_DIM = 16
 
 # state rows (fpv_abi.h)
 PX, PY, PZ, VX, VY, VZ, QW, QX, QY, QZ, RX, RY, RZ, THRUST = range(14)
-R_OMEGA, R_IERR, R_LERR, R_FIRST = 10, 13, 16, 19
+R_OMEGA, R_IERR, R_LERR, R_FIRST, R_OMEGA_LO, R_IERR_LO, R_DFILT = 10, 13, 16, 19, 20, 23, 26
 
 # every symbol include/fpv_abi.h declares
 EXPORTS = ("fpv_abi_version", "fpv_sizeof", "fpv_state_rows", "fpv_algorithmic_bytes", "fpv_handle_algorithmic_bytes", "fpv_create", "fpv_destroy",
-           "fpv_reset", "fpv_step", "fpv_rollout", "fpv_rollout_graph", "fpv_set_params", "fpv_set_step_counter", "fpv_set_tuning", "fpv_recommended_ld",
-           "fpv_diag_stream_copy", "fpv_last_error",
+           "fpv_reset", "fpv_step", "fpv_rollout", "fpv_step_n", "fpv_rollout_graph", "fpv_set_params", "fpv_set_step_counter", "fpv_set_tuning", "fpv_recommended_ld",
+           "fpv_diag_stream_copy", "fpv_pid_reset", "fpv_pid_call", "fpv_last_error",
            "fpv_error_name")
 
 
@@ -51,11 +52,21 @@ class FpvParams(C.Structure):
         ("motor_radius", C.c_double), ("ground_spring", C.c_double), ("ground_damping", C.c_double),
         ("noise_transition", C.c_double), ("noise_gain", C.c_double),
         ("noise_seed", C.c_uint64), ("drone_id_offset", C.c_uint64),
+        ("racer_pid_variant", C.c_uint32), ("_reserved0", C.c_uint32),
+        ("pid_integral_clip", C.c_double), ("pid_min_output", C.c_double), ("pid_max_output", C.c_double),
+        ("pid_derivative_transition_rate", C.c_double),
     ]
 
 
 FPV_MAX_OBJECTS = 8
 OBJ_GROUND, OBJ_CYLINDER, OBJ_SPHERE = 0, 1, 2
+FPV_PID_ROWS = 4       # integral, prev_derivative, previous_error, is_first
+
+
+class FpvPidParams(C.Structure):
+    _fields_ = [("struct_size", C.c_uint32), ("_reserved", C.c_uint32), ("kP", C.c_double), ("kI", C.c_double),
+                ("kD", C.c_double), ("dt", C.c_double), ("integral_clip", C.c_double), ("min_output", C.c_double),
+                ("max_output", C.c_double), ("derivative_transition_rate", C.c_double)]
 
 
 class FpvObject(C.Structure):
@@ -88,6 +99,7 @@ class FpvBuffers(C.Structure):
         ("ep_length", C.c_void_p), ("last_return", C.c_void_p), ("last_length", C.c_void_p),
         ("wind", C.c_float * 3), ("rounding_seed", C.c_uint32), ("state_h", C.c_void_p),
         ("pos_comp", C.c_void_p), ("noise_state", C.c_void_p), ("action_out", C.c_void_p), ("action_ld", C.c_int64), ("objects", C.c_void_p), ("obs_aos", C.c_void_p),
+        ("done_bits_stride", C.c_int64),
     ]
 
 
@@ -123,6 +135,11 @@ def pack_params(p, auto_reset: bool = False, fp16_state: bool = False, stick_noi
         for j in range(3):
             s.racer_pid[i][j] = float(p.racer_pid[i][j])
     s.racer_velocity_damping = float(p.racer_velocity_damping)
+    s.racer_pid_variant = int(getattr(p, "racer_pid_variant", 0))
+    s.pid_integral_clip = float(getattr(p, "pid_integral_clip", 1.0))
+    s.pid_min_output = float(getattr(p, "pid_min_output", 0.3))
+    s.pid_max_output = float(getattr(p, "pid_max_output", 1.0))
+    s.pid_derivative_transition_rate = float(getattr(p, "pid_derivative_transition_rate", 0.5))
     s.motor_radius, s.ground_spring, s.ground_damping = float(p.motor_radius), float(p.ground_spring), float(p.ground_damping)
     return s
 
@@ -160,17 +177,20 @@ def lib() -> C.CDLL:
     L.fpv_step.argtypes = [vp, pb, vp]
     L.fpv_rollout.argtypes = [vp, pb, C.c_int, i64, i64, vp]
     L.fpv_rollout_graph.argtypes = [vp, pb, C.c_int, i64, i64, vp]
+    L.fpv_step_n.argtypes = [vp, pb, C.c_int, i64, i64, vp]
     L.fpv_set_params.argtypes = [vp, pp]
     L.fpv_set_tuning.argtypes = [vp, C.c_int, C.c_int]
     L.fpv_set_step_counter.argtypes = [vp, C.c_uint32]
     L.fpv_recommended_ld.argtypes = [i64]
     L.fpv_recommended_ld.restype = i64
     L.fpv_diag_stream_copy.argtypes = [vp, vp, i64, vp]
+    L.fpv_pid_reset.argtypes = [vp, i64, i64, vp, C.c_int, vp]
+    L.fpv_pid_call.argtypes = [C.POINTER(FpvPidParams), vp, i64, i64, vp, vp, C.c_float, vp, vp, C.c_int, vp]
     L.fpv_last_error.restype = C.c_char_p
     L.fpv_error_name.argtypes = [C.c_int]
     L.fpv_error_name.restype = C.c_char_p
     L.fpv_sizeof.argtypes = [C.c_int]
-    for which, struct in ((0, FpvParams), (1, FpvBuffers), (2, FpvObjects)):
+    for which, struct in ((0, FpvParams), (1, FpvBuffers), (2, FpvObjects), (3, FpvPidParams)):
         if L.fpv_sizeof(which) != C.sizeof(struct):
             raise ImportError(f"{struct.__name__}: ctypes declares {C.sizeof(struct)} bytes, libfpv_hip.so has "
                               f"{L.fpv_sizeof(which)} - _lib.py and include/fpv_abi.h are out of step")
@@ -192,5 +212,7 @@ def state_rows(mode: int) -> int:
 
 
 def algorithmic_bytes(mode: int) -> int:
-    """state read + write, action read, reward + done write (fpv_algorithmic_bytes)."""
-    return state_rows(mode) * 8 + 16 + 4 + 1
+    """state read + write, action read, reward + done write (fpv_algorithmic_bytes): the SURVEY 8d
+    figures, 133 B for the drone and 181 B for the 20 base rows of the Racer; a live handle reports
+    what its kernel variant really moves (fpv_handle_algorithmic_bytes)."""
+    return (FPV_DRONE_ROWS if mode == FPV_MODE_DRONE else 20) * 8 + 16 + 4 + 1

@@ -32,6 +32,12 @@ static inline int fpv_derive_constants(const fpv_params_t* P, FpvK* K, bool* big
         if (!(P->racer_mass > 0)) { *why = "racer_mass must be positive"; return FPV_EPARAM; }
         for (int i = 0; i < 3; ++i)
             if (!(P->racer_inertia[i] > 0)) { *why = "racer_inertia must be positive"; return FPV_EPARAM; }
+        if (P->racer_pid_variant > 1) { *why = "racer_pid_variant must be 0 (racer_drone_test.PID) or 1 (components.PID)"; return FPV_EINVAL; }
+        if (P->racer_pid_variant == 1 && (!(P->pid_integral_clip >= 0) || !(P->pid_min_output <= P->pid_max_output)
+                                          || !(P->pid_derivative_transition_rate >= 0 && P->pid_derivative_transition_rate <= 1))) {
+            *why = "components.PID constants: integral_clip >= 0, min_output <= max_output, derivative_transition_rate in [0, 1]";
+            return FPV_EPARAM;
+        }
     }
     const double qn = sqrt(P->init_quat[0] * P->init_quat[0] + P->init_quat[1] * P->init_quat[1] +
                            P->init_quat[2] * P->init_quat[2] + P->init_quat[3] * P->init_quat[3]);
@@ -60,14 +66,31 @@ static inline int fpv_derive_constants(const fpv_params_t* P, FpvK* K, bool* big
     for (int i = 0; i < 4; ++i) K->q0[i] = (float)(P->init_quat[i] / qn);
     K->ceiling = (float)P->ceiling;        // +inf stays +inf
     K->r_dt = (float)P->dt;
-    K->r_inv_dt = (float)(1.0 / P->dt);
     K->r_inv_mass = (float)(1.0 / (P->racer_mass > 0 ? P->racer_mass : 1.0));
     K->r_damp = (float)P->racer_velocity_damping;
     K->r_ang_k = P->racer_omega_dt ? (float)P->dt : 1.0f;
+    K->r_ang_k_d = P->racer_omega_dt ? P->dt : 1.0;
+    // omega per STEP (as written) needs the float64 rate loop; omega*dt is well conditioned in fp32
+    K->r_wide = P->racer_omega_dt ? 0u : 1u;
+    K->r_pid_variant = P->racer_pid_variant;
+    K->rd.dt = P->dt;
+    K->rd.inv_dt = 1.0 / P->dt;
     for (int i = 0; i < 3; ++i) {
-        K->r_dt_over_I[i] = (float)(P->dt / (P->racer_inertia[i] > 0 ? P->racer_inertia[i] : 1.0));
-        for (int j = 0; j < 3; ++j) K->r_pid[i][j] = (float)P->racer_pid[i][j];
+        K->rd.dt_over_I[i] = P->dt / (P->racer_inertia[i] > 0 ? P->racer_inertia[i] : 1.0);
+        for (int j = 0; j < 3; ++j) K->rd.gain[i][j] = P->racer_pid[i][j];
     }
+    K->rd.integral_clip = P->pid_integral_clip;
+    K->rd.min_output = P->pid_min_output;
+    K->rd.max_output = P->pid_max_output;
+    K->rd.d_rate = P->pid_derivative_transition_rate;
+    K->rd.om_d_rate = 1.0 - P->pid_derivative_transition_rate;
+    K->rf.dt = (float)K->rd.dt; K->rf.inv_dt = (float)K->rd.inv_dt;
+    for (int i = 0; i < 3; ++i) {
+        K->rf.dt_over_I[i] = (float)K->rd.dt_over_I[i];
+        for (int j = 0; j < 3; ++j) K->rf.gain[i][j] = (float)K->rd.gain[i][j];
+    }
+    K->rf.integral_clip = (float)K->rd.integral_clip; K->rf.min_output = (float)K->rd.min_output;
+    K->rf.max_output = (float)K->rd.max_output; K->rf.d_rate = (float)K->rd.d_rate; K->rf.om_d_rate = (float)K->rd.om_d_rate;
     K->motor_radius = (float)P->motor_radius;
     K->ground_k_m = (float)(P->ground_spring / P->mass);
     K->ground_c_m = (float)(P->ground_damping / P->mass);

@@ -22,15 +22,17 @@
 
 #include <new>
 #include <string>
+#include <vector>
 #include <type_traits>
 
 #include "../../include/fpv_abi.h"
+#include "fpv_addr.h"
 #include "fpv_derive.h"
 #include "fpv_math.h"
 
 namespace {
 
-constexpr int kBlock = 256;   // 4 wave64 per workgroup
+constexpr int kBlock = 256;   // reset / diag kernels: 4 wave64 per workgroup
 
 struct FpvBufD {
     float* state;
@@ -52,18 +54,21 @@ struct FpvBufD {
     uint32_t step;         // launch index of the handle: Philox counter word
     int64_t action_ld;     // 0: action is [n][4] rows; > 0: action is [4][action_ld] SoA (a GEMM's [4, n] output)
     FpvObjects objs;       // the step's object_list (count 0 = none); only the OBJ instantiation reads it
-    uint16_t* state_h;     // FPV_FLAG_FP16_STATE: [11][ld] binary16 rows (v, q, rates, thrust)
+    uint16_t* state_h;     // FPV_FLAG_FP16_STATE: [5][ld] half2 pair rows + [ld] thrust halves
     uint32_t seed;         // stochastic-rounding seed of this launch
 };
 
-// Row access = uniform 64-bit row base (SGPR pair) + 32-bit byte offset of the lane: lets the
-// compiler use the `global_load_dword v, v_off, s[base]` form instead of 64-bit vector address
-// arithmetic per row (that arithmetic was ~15 % of the kernel's VALU instructions).
-// 4*i < 2^32 because n <= 2^30 (fpv_create).
+// k-step launches (fpv_step_n): step t reads its action at + t*action_stride floats and writes
+// reward/done at + t*out_stride elements, done_bits at + t*bits_stride words (0 = last step only)
+struct FpvRoll { int32_t k; int32_t pad; int64_t action_stride, out_stride, bits_stride; };
+
+// Row access = uniform 64-bit row base (SGPR pair) + 32-bit byte offset of the lane (fpv_addr.h):
+// i * sizeof(T) < 2^32 because n <= 2^28 (fpv_create) and sizeof(T) <= 16.
 template <class T>
 __device__ __forceinline__ T& row_at(T* row_base, uint32_t i)
 {
-    return *reinterpret_cast<T*>(reinterpret_cast<char*>(const_cast<typename std::remove_const<T>::type*>(row_base)) + (uint32_t)(i * (uint32_t)sizeof(T)));
+    static_assert(sizeof(T) <= FPV_MAX_ELEM_BYTES, "lane offsets are 32-bit: element too wide for n <= 2^28");
+    return *reinterpret_cast<T*>(reinterpret_cast<char*>(const_cast<typename std::remove_const<T>::type*>(row_base)) + fpv_lane_offset(i, (uint32_t)sizeof(T)));
 }
 #define ROW(st, r, ld) ((st) + (int64_t)(r) * (ld))
 
@@ -135,6 +140,53 @@ __device__ __forceinline__ void emit_lane_outputs(const FpvBufD& B, uint32_t i, 
     }
 }
 
+// Per-step outputs of a k-step launch (fpv_step_n).  reward/done/done_bits go out every step when their
+// stride is non-zero, otherwise once after the last step (= what k single-step launches leave behind);
+// the episode accumulators live in registers for the k steps and touch memory once.
+struct RollOut {
+    float* rp; uint8_t* dp; unsigned long long* bp;
+    int64_t out_stride, bits_stride;
+    int last_t;
+    bool track, had_done;
+    float ep_r, last_r;
+    int32_t ep_l, last_l;
+    const FpvBufD& B;
+    __device__ __forceinline__ RollOut(const FpvBufD& B_, const FpvRoll& R, uint32_t i, bool live)
+        : rp(B_.reward), dp(B_.done), bp(B_.done_bits), out_stride(R.out_stride), bits_stride(R.bits_stride),
+          last_t(R.k - 1), track(B_.ep_return != nullptr), had_done(false), ep_r(0.0f), last_r(0.0f), ep_l(0), last_l(0), B(B_)
+    {
+        if (track && live) { ep_r = B.ep_return[i]; ep_l = B.ep_length[i]; }
+    }
+    // called by every live lane of the wave in the same iteration (the ballot spans the wave)
+    __device__ __forceinline__ void step(uint32_t i, int t, float reward, bool done)
+    {
+        const bool last = t == last_t;
+        const unsigned long long mask = __ballot(done);
+        if (bp && (bits_stride || last) && (threadIdx.x & 63) == 0) bp[i >> 6] = mask;
+        if (out_stride || last) {
+            if (rp) __builtin_nontemporal_store(reward, &row_at(rp, i));
+            if (dp) __builtin_nontemporal_store((uint8_t)(done ? 1 : 0), &row_at(dp, i));
+        }
+        if (track) {
+            ep_r += reward; ep_l += 1;
+            if (done) { last_r = ep_r; last_l = ep_l; had_done = true; ep_r = 0.0f; ep_l = 0; }
+        }
+        if (rp) rp += out_stride;
+        if (dp) dp += out_stride;
+        if (bp) bp += bits_stride;
+    }
+    __device__ __forceinline__ void finish(uint32_t i)
+    {
+        if (track) {
+            B.ep_return[i] = ep_r; B.ep_length[i] = ep_l;
+            if (had_done) {
+                if (B.last_return) B.last_return[i] = last_r;
+                if (B.last_length) B.last_length[i] = last_l;
+            }
+        }
+    }
+};
+
 // EMA stick noise: read 4 state floats, one Philox4x32-10 block -> 4 normals, write them back,
 // perturb the action.  With no caller action (B.action null) the sticks are the pure noise profile.
 __device__ __forceinline__ float4 apply_stick_noise(const FpvK& K, const FpvBufD& B, uint32_t i, float4 a)
@@ -153,7 +205,7 @@ __device__ __forceinline__ float4 apply_stick_noise(const FpvK& K, const FpvBufD
 template <int BS, int DPL, bool BIG, bool NOISE = false, bool OBJ = false, bool KAHAN = false>
 __global__ __launch_bounds__(BS) void fpv_drone_step_kernel(const FpvK K, const FpvBufD B, const int64_t n)
 {
-    const uint32_t base = blockIdx.x * (uint32_t)(BS * DPL) + threadIdx.x;    // n < 2^30 (fpv_create)
+    const uint32_t base = blockIdx.x * (uint32_t)(BS * DPL) + threadIdx.x;    // n <= 2^28 (fpv_create)
     // one drone per lane: lanes past the end leave at once (a ballot over the remaining lanes still
     // yields the right done bits: exited lanes contribute 0, and a wave whose lane 0 is gone is empty)
     if (DPL == 1 && base >= n) return;
@@ -201,6 +253,69 @@ __global__ __launch_bounds__(BS) void fpv_drone_step_kernel(const FpvK K, const 
         }
         emit_outputs(B, i, live[j], o.reward, o.done);
     }
+}
+
+// k steps of Drone.step in ONE launch (fpv_step_n): the loop `for i in range(time_steps): drone.step(...)`
+// of src/core/simulator.py:83-156 for pre-computed or in-kernel-generated sticks.  The lane keeps its
+// drone (and the noise / Kahan rows) in registers for all k steps; step t+1's action is in flight while
+// step t computes; reward/done leave per step only when asked to.  Per env-step this moves
+// 16 (action) + 5 (reward, done; optional) + 112/k bytes instead of 133, so for k >~ 8 the kernel is
+// bound by the fp32 vector ALUs (~400 instructions per env-step), not by HBM.  The arithmetic per step
+// is the single-step kernel's lane function, called in the same order: results are bit-identical to k
+// fpv_step launches.
+template <int BS, bool BIG, bool NOISE, bool OBJ, bool KAHAN>
+__global__ __launch_bounds__(BS) void fpv_drone_rollout_kernel(const FpvK K, const FpvBufD B, const int64_t n, const FpvRoll R)
+{
+    const uint32_t i = blockIdx.x * (uint32_t)BS + threadIdx.x;
+    if (i >= n) return;
+    FpvDroneState s;
+    const bool has_action = !NOISE || B.action;
+    const float* ap = reinterpret_cast<const float*>(B.action);
+    float4 a_next = has_action ? ld_action_any(reinterpret_cast<const float4*>(ap), B.action_ld, i) : make_float4(0.f, 0.f, 0.f, 0.f);
+    ld_drone(B.state, B.ld, i, s);
+    float ns[4] = {0.f, 0.f, 0.f, 0.f}, kc[6] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+    if (NOISE) {
+#pragma unroll
+        for (int k = 0; k < 4; ++k) ns[k] = row_at(ROW(B.noise_state, k, B.ld), i);
+    }
+    if (KAHAN) {
+#pragma unroll
+        for (int k = 0; k < 6; ++k) kc[k] = row_at(ROW(B.pos_comp, k, B.ld), i);
+    }
+    RollOut out(B, R, i, true);
+    FpvStepOut o;
+    o.done = false; o.reward = 0.0f; o.ax = o.ay = o.az = 0.0f;
+    float av[4] = {0.f, 0.f, 0.f, 0.f};
+    for (int t = 0; t < R.k; ++t) {
+        av[0] = a_next.x; av[1] = a_next.y; av[2] = a_next.z; av[3] = a_next.w;
+        if (has_action && R.action_stride && t + 1 < R.k) {
+            ap += R.action_stride;
+            a_next = ld_action_any(reinterpret_cast<const float4*>(ap), B.action_ld, i);
+        }
+        if (NOISE) fpv_stick_noise(K.noise, B.step + (uint32_t)t, (uint64_t)i, ns, av);
+        o = fpv_drone_step_lane<BIG, OBJ>(K, s, av[0], av[1], av[2], av[3], B.wx, B.wy, B.wz, &B.objs, KAHAN ? kc : nullptr);
+        const bool rst = (K.flags & FPV_FLAG_AUTO_RESET) && o.done;
+        if (KAHAN && rst) {
+#pragma unroll
+            for (int k = 0; k < 6; ++k) kc[k] = 0.0f;
+        }
+        if (rst) fpv_drone_reset_lane(K, s);
+        out.step(i, t, o.reward, o.done);
+    }
+    if (B.accel) {
+        row_at(ROW(B.accel, 0, B.ld), i) = o.ax; row_at(ROW(B.accel, 1, B.ld), i) = o.ay; row_at(ROW(B.accel, 2, B.ld), i) = o.az;
+    }
+    st_drone(B.state, B.ld, i, s);
+    if (NOISE) {
+#pragma unroll
+        for (int k = 0; k < 4; ++k) row_at(ROW(B.noise_state, k, B.ld), i) = ns[k];
+        if (B.action_out) B.action_out[i] = make_float4(av[0], av[1], av[2], av[3]);
+    }
+    if (KAHAN) {
+#pragma unroll
+        for (int k = 0; k < 6; ++k) row_at(ROW(B.pos_comp, k, B.ld), i) = kc[k];
+    }
+    out.finish(i);
 }
 
 // Same step + an array-of-structures observation row per drone, obs_aos[i][16] =
@@ -251,11 +366,18 @@ __global__ __launch_bounds__(BS) void fpv_drone_step_aos_kernel(const FpvK K, co
 }
 
 // fp16-storage variant (BASELINE config 4): position rows fp32; the 11 other values of a drone are
-// binary16, stored as SIX rows of half2 pairs - (vx,vy) (vz,qw) (qx,qy) (qz,rx) (ry,rz) (thrust,0) -
-// so that one lane = one drone still moves nothing narrower than a dword (two-byte accesses waste
-// the memory pipeline: with 11 separate half rows this kernel ran slower than the fp32 one).
-// 3*4 + 6*4 = 36 state bytes each way: 93 algorithmic bytes per env-step instead of 133;
-// arithmetic and the lane function are unchanged.
+// binary16, stored as FIVE rows of half2 pairs - (vx,vy) (vz,qw) (qx,qy) (qz,rx) (ry,rz) - plus one row
+// of single halves for prev_thrust: 3*4 + 5*4 + 2 = 34 state bytes each way, 89 algorithmic bytes per
+// env-step instead of 133.  One lane = one drone still moves nothing narrower than a dword
+// (two-byte accesses waste the memory pipeline: with 11 separate half rows this kernel ran slower than
+// the fp32 one): the even/odd lanes of a drone pair read the SAME dword of the thrust row, and on the
+// way out the even lane fetches its neighbour's half with one DPP quad-permute and stores the dword.
+// Arithmetic and the lane function are unchanged.
+__device__ __forceinline__ const uint32_t* thrust_row_h(const FpvBufD& B)
+{
+    return reinterpret_cast<const uint32_t*>(B.state_h) + (int64_t)FPV_HALF_PAIR_ROWS * B.ld;
+}
+
 __device__ __forceinline__ void ld_drone_h(const FpvBufD& B, uint32_t i, FpvDroneState& s)
 {
     s.px = row_at(ROW(B.state, 0, B.ld), i); s.py = row_at(ROW(B.state, 1, B.ld), i); s.pz = row_at(ROW(B.state, 2, B.ld), i);
@@ -263,31 +385,44 @@ __device__ __forceinline__ void ld_drone_h(const FpvBufD& B, uint32_t i, FpvDron
     uint32_t w[FPV_HALF_PAIR_ROWS];
 #pragma unroll
     for (int k = 0; k < FPV_HALF_PAIR_ROWS; ++k) w[k] = row_at(ROW(sh, k, B.ld), i);
+    const uint32_t tw = row_at(thrust_row_h(B), i >> 1);          // shared with the neighbour lane
     FpvHalfState h;
     fpv_split_pairs(w, h);
+    h.t = (uint16_t)((i & 1u) ? (tw >> 16) : tw);
     fpv_unpack_half(h, s);
 }
 
-__device__ __forceinline__ void st_drone_h(const FpvBufD& B, uint32_t i, const FpvDroneState& s)
+// stores the position and pair rows and returns the new thrust half (the caller completes the pair)
+__device__ __forceinline__ uint32_t st_drone_h(const FpvBufD& B, uint32_t i, uint32_t seed, const FpvDroneState& s)
 {
     row_at(ROW(B.state, 0, B.ld), i) = s.px; row_at(ROW(B.state, 1, B.ld), i) = s.py; row_at(ROW(B.state, 2, B.ld), i) = s.pz;
     FpvHalfState h;
-    fpv_pack_half(s, B.seed, (uint32_t)i, h);
+    fpv_pack_half(s, seed, (uint32_t)i, h);
     uint32_t w[FPV_HALF_PAIR_ROWS];
     fpv_join_pairs(h, w);
     uint32_t* __restrict__ sh = reinterpret_cast<uint32_t*>(B.state_h);
 #pragma unroll
     for (int k = 0; k < FPV_HALF_PAIR_ROWS; ++k) row_at(ROW(sh, k, B.ld), i) = w[k];
+    return h.t;
+}
+
+// EVERY lane of the wave must call this (no early exit before it): lane 2j writes the dword that holds
+// the thrust halves of drones 2j and 2j+1; a dead neighbour (odd n) contributes a zero half.
+__device__ __forceinline__ void st_thrust_pair_h(const FpvBufD& B, uint32_t i, bool live, uint32_t my_half)
+{
+    const uint32_t mine = live ? my_half : 0u;
+    const uint32_t other = (uint32_t)__builtin_amdgcn_update_dpp(0, (int)mine, 0xB1 /* quad_perm [1,0,3,2] */, 0xf, 0xf, true);
+    if (live && !(i & 1u)) row_at(const_cast<uint32_t*>(thrust_row_h(B)), i >> 1) = mine | (other << 16);
 }
 
 template <int BS, bool BIG>
 __global__ __launch_bounds__(BS) void fpv_drone_step_h_kernel(const FpvK K, const FpvBufD B, const int64_t n)
 {
     const uint32_t i = blockIdx.x * (uint32_t)BS + threadIdx.x;
-    if (i >= n) return;                      // see fpv_drone_step_kernel: the ballot stays correct
-    const bool live = true;
+    const bool live = i < n;                 // no early exit: the thrust-pair exchange needs whole lane pairs
     FpvStepOut o;
     o.done = false; o.reward = 0.0f; o.ax = o.ay = o.az = 0.0f;
+    uint32_t th = 0;
     if (live) {
         FpvDroneState s;
         const float4 a = ld_action(B.action, i);
@@ -298,11 +433,54 @@ __global__ __launch_bounds__(BS) void fpv_drone_step_h_kernel(const FpvK K, cons
             row_at(ROW(B.accel, 0, B.ld), i) = o.ax; row_at(ROW(B.accel, 1, B.ld), i) = o.ay; row_at(ROW(B.accel, 2, B.ld), i) = o.az;
         }
         if ((K.flags & FPV_FLAG_AUTO_RESET) && o.done) fpv_drone_reset_lane(K, s);
-        st_drone_h(B, i, s);
+        th = st_drone_h(B, i, B.seed, s);
     }
+    st_thrust_pair_h(B, i, live, th);
     emit_outputs(B, i, live, o.reward, o.done);
 }
 
+// k steps of the fp16-storage kernel in one launch: the state is rounded to binary16 and widened again
+// after EVERY step, in registers, exactly as k single-step launches would do through HBM.
+template <int BS, bool BIG>
+__global__ __launch_bounds__(BS) void fpv_drone_rollout_h_kernel(const FpvK K, const FpvBufD B, const int64_t n, const FpvRoll R)
+{
+    const uint32_t i = blockIdx.x * (uint32_t)BS + threadIdx.x;
+    const bool live = i < n;
+    uint32_t th = 0;
+    FpvStepOut o;
+    o.done = false; o.reward = 0.0f; o.ax = o.ay = o.az = 0.0f;
+    RollOut out(B, R, i, live);
+    if (live) {
+        FpvDroneState s;
+        ld_drone_h(B, i, s);
+        const float* ap = reinterpret_cast<const float*>(B.action);
+        float4 a_next = ld_action(reinterpret_cast<const float4*>(ap), i);
+        FpvHalfState h;
+        for (int t = 0; t < R.k; ++t) {
+            const float4 a = a_next;
+            if (R.action_stride && t + 1 < R.k) { ap += R.action_stride; a_next = ld_action(reinterpret_cast<const float4*>(ap), i); }
+            o = fpv_drone_step_lane<BIG>(K, s, a.x, a.y, a.z, a.w, B.wx, B.wy, B.wz);
+            if ((K.flags & FPV_FLAG_AUTO_RESET) && o.done) fpv_drone_reset_lane(K, s);
+            fpv_pack_half(s, B.seed + (uint32_t)t, (uint32_t)i, h);       // the HBM round trip of a single step, in registers
+            if (t + 1 < R.k) fpv_unpack_half(h, s);
+            out.step(i, t, o.reward, o.done);
+        }
+        if (B.accel) {
+            row_at(ROW(B.accel, 0, B.ld), i) = o.ax; row_at(ROW(B.accel, 1, B.ld), i) = o.ay; row_at(ROW(B.accel, 2, B.ld), i) = o.az;
+        }
+        row_at(ROW(B.state, 0, B.ld), i) = s.px; row_at(ROW(B.state, 1, B.ld), i) = s.py; row_at(ROW(B.state, 2, B.ld), i) = s.pz;
+        uint32_t w[FPV_HALF_PAIR_ROWS];
+        fpv_join_pairs(h, w);
+        uint32_t* __restrict__ sh = reinterpret_cast<uint32_t*>(B.state_h);
+#pragma unroll
+        for (int k = 0; k < FPV_HALF_PAIR_ROWS; ++k) row_at(ROW(sh, k, B.ld), i) = w[k];
+        th = h.t;
+        out.finish(i);
+    }
+    st_thrust_pair_h(B, i, live, th);
+}
+
+template <bool WIDE, bool PIDV>
 __device__ __forceinline__ void ld_racer(const float* __restrict__ st, int64_t ld, uint32_t i, FpvRacerState& s)
 {
     s.px = row_at(ROW(st, FPV_PX, ld), i); s.py = row_at(ROW(st, FPV_PY, ld), i); s.pz = row_at(ROW(st, FPV_PZ, ld), i);
@@ -313,10 +491,14 @@ __device__ __forceinline__ void ld_racer(const float* __restrict__ st, int64_t l
         s.w[k] = row_at(ROW(st, (FPV_R_OMEGA + k), ld), i);
         s.ierr[k] = row_at(ROW(st, (FPV_R_IERR + k), ld), i);
         s.lerr[k] = row_at(ROW(st, (FPV_R_LERR + k), ld), i);
+        s.wlo[k] = WIDE ? row_at(ROW(st, (FPV_R_OMEGA_LO + k), ld), i) : 0.0f;
+        s.ilo[k] = WIDE ? row_at(ROW(st, (FPV_R_IERR_LO + k), ld), i) : 0.0f;
+        s.dflt[k] = PIDV ? row_at(ROW(st, (FPV_R_DFILT + k), ld), i) : 0.0f;
     }
     s.first = row_at(ROW(st, FPV_R_FIRST, ld), i);
 }
 
+template <bool WIDE, bool PIDV>
 __device__ __forceinline__ void st_racer(float* __restrict__ st, int64_t ld, uint32_t i, const FpvRacerState& s)
 {
     row_at(ROW(st, FPV_PX, ld), i) = s.px; row_at(ROW(st, FPV_PY, ld), i) = s.py; row_at(ROW(st, FPV_PZ, ld), i) = s.pz;
@@ -327,27 +509,51 @@ __device__ __forceinline__ void st_racer(float* __restrict__ st, int64_t ld, uin
         row_at(ROW(st, (FPV_R_OMEGA + k), ld), i) = s.w[k];
         row_at(ROW(st, (FPV_R_IERR + k), ld), i) = s.ierr[k];
         row_at(ROW(st, (FPV_R_LERR + k), ld), i) = s.lerr[k];
+        if (WIDE) { row_at(ROW(st, (FPV_R_OMEGA_LO + k), ld), i) = s.wlo[k]; row_at(ROW(st, (FPV_R_IERR_LO + k), ld), i) = s.ilo[k]; }
+        if (PIDV) row_at(ROW(st, (FPV_R_DFILT + k), ld), i) = s.dflt[k];
     }
     row_at(ROW(st, FPV_R_FIRST, ld), i) = s.first;
 }
 
-__global__ __launch_bounds__(kBlock) void fpv_racer_step_kernel(const FpvK K, const FpvBufD B, const int64_t n)
+// Racer.step.  WIDE = as written (omega radians per step: float64 rate loop, six extra (hi, lo) rows);
+// PIDV = components.PID semantics (three extra rows).  The 181-byte variant (neither) is the
+// racer_omega_dt one.
+template <int BS, bool WIDE, bool PIDV>
+__global__ __launch_bounds__(BS) void fpv_racer_step_kernel(const FpvK K, const FpvBufD B, const int64_t n)
 {
-    const uint32_t i = blockIdx.x * (uint32_t)kBlock + threadIdx.x;
+    const uint32_t i = blockIdx.x * (uint32_t)BS + threadIdx.x;
     if (i >= n) return;
-    const bool live = true;
-    float reward = 0.0f;
-    bool done = false;
-    if (live) {
-        FpvRacerState s;
-        const float4 a = ld_action(B.action, i);
-        ld_racer(B.state, B.ld, i, s);
-        reward = fpv_racer_step_lane(K, s, a.x, a.y, a.z, a.w);
-        done = !(fabsf(s.pz) <= K.ceiling);            // the Racer has no ground; build-defined ceiling only
+    FpvRacerState s;
+    const float4 a = ld_action(B.action, i);
+    ld_racer<WIDE, PIDV>(B.state, B.ld, i, s);
+    __builtin_amdgcn_sched_barrier(0);
+    const float reward = fpv_racer_step_lane<WIDE, PIDV ? 1 : 0>(K, s, a.x, a.y, a.z, a.w);
+    const bool done = !(fabsf(s.pz) <= K.ceiling);            // the Racer has no ground; build-defined ceiling only
+    if ((K.flags & FPV_FLAG_AUTO_RESET) && done) fpv_racer_reset_lane(s);
+    st_racer<WIDE, PIDV>(B.state, B.ld, i, s);
+    emit_outputs(B, i, true, reward, done);
+}
+
+template <int BS, bool WIDE, bool PIDV>
+__global__ __launch_bounds__(BS) void fpv_racer_rollout_kernel(const FpvK K, const FpvBufD B, const int64_t n, const FpvRoll R)
+{
+    const uint32_t i = blockIdx.x * (uint32_t)BS + threadIdx.x;
+    if (i >= n) return;
+    FpvRacerState s;
+    ld_racer<WIDE, PIDV>(B.state, B.ld, i, s);
+    RollOut out(B, R, i, true);
+    const float* ap = reinterpret_cast<const float*>(B.action);
+    float4 a_next = ld_action(reinterpret_cast<const float4*>(ap), i);
+    for (int t = 0; t < R.k; ++t) {
+        const float4 a = a_next;
+        if (R.action_stride && t + 1 < R.k) { ap += R.action_stride; a_next = ld_action(reinterpret_cast<const float4*>(ap), i); }
+        const float reward = fpv_racer_step_lane<WIDE, PIDV ? 1 : 0>(K, s, a.x, a.y, a.z, a.w);
+        const bool done = !(fabsf(s.pz) <= K.ceiling);
         if ((K.flags & FPV_FLAG_AUTO_RESET) && done) fpv_racer_reset_lane(s);
-        st_racer(B.state, B.ld, i, s);
+        out.step(i, t, reward, done);
     }
-    emit_outputs(B, i, live, reward, done);
+    st_racer<WIDE, PIDV>(B.state, B.ld, i, s);
+    out.finish(i);
 }
 
 // Drone.reset (components.py:150-169): p, v, R = E(deg2rad(ypr)) with the triple consumed as
@@ -377,12 +583,17 @@ __global__ __launch_bounds__(kBlock) void fpv_reset_kernel(const FpvK K, const F
             s.q.y = fmaf(cy * sp, cr, sy * cp * sr);
             s.q.z = fmaf(sy * cp, cr, -(cy * sp * sr));
         }
-        if (K.flags & FPV_FLAG_FP16_STATE) st_drone_h(B, i, s);
-        else st_drone(B.state, B.ld, i, s);
+        if (K.flags & FPV_FLAG_FP16_STATE) {
+            // masked lanes are independent here, so the thrust half goes out as a 2-byte store (not a hot path)
+            const uint32_t th = st_drone_h(B, (uint32_t)i, B.seed, s);
+            reinterpret_cast<uint16_t*>(const_cast<uint32_t*>(thrust_row_h(B)))[i] = (uint16_t)th;
+        } else {
+            st_drone(B.state, B.ld, i, s);
+        }
     } else {
         FpvRacerState s;
         fpv_racer_reset_lane(s);
-        st_racer(B.state, B.ld, i, s);
+        st_racer<true, true>(B.state, B.ld, i, s);          // all 29 rows, whatever the variant uses
     }
     if (B.done) B.done[i] = 0;
     if (B.ep_return) { B.ep_return[i] = 0.0f; B.ep_length[i] = 0; }
@@ -394,6 +605,33 @@ __global__ __launch_bounds__(kBlock) void fpv_reset_kernel(const FpvK K, const F
 #pragma unroll
         for (int k = 0; k < 6; ++k) row_at(ROW(B.pos_comp, k, B.ld), i) = 0.0f;
     }
+}
+
+// components.PID.__call__ for n drones (components.py:43-54): one lane per drone, four state rows.
+__global__ __launch_bounds__(kBlock) void fpv_pid_kernel(const FpvPidK<float> P, float* __restrict__ st, const int64_t ld,
+                                                         const int64_t n, const float* __restrict__ current,
+                                                         const float* __restrict__ target, const float target_scalar,
+                                                         float* __restrict__ out, float* __restrict__ error_out)
+{
+    const int64_t i = (int64_t)blockIdx.x * kBlock + threadIdx.x;
+    if (i >= n) return;
+    float integ = st[FPV_PID_INTEGRAL * ld + i], dflt = st[FPV_PID_PREV_DERIVATIVE * ld + i];
+    float last = st[FPV_PID_PREV_ERROR * ld + i];
+    const bool first = st[FPV_PID_IS_FIRST * ld + i] != 0.0f;
+    const float cur = current[i], tgt = target ? target[i] : target_scalar;
+    out[i] = fpv_pid_axis<float, 1>(P, 0, cur, tgt, first, integ, last, dflt);
+    if (error_out) error_out[i] = last;                                   // PID.error == previous_error after the call
+    st[FPV_PID_INTEGRAL * ld + i] = integ; st[FPV_PID_PREV_DERIVATIVE * ld + i] = dflt;
+    st[FPV_PID_PREV_ERROR * ld + i] = last; st[FPV_PID_IS_FIRST * ld + i] = 0.0f;
+}
+
+__global__ __launch_bounds__(kBlock) void fpv_pid_reset_kernel(float* __restrict__ st, const int64_t ld, const int64_t n,
+                                                               const uint8_t* __restrict__ mask)
+{
+    const int64_t i = (int64_t)blockIdx.x * kBlock + threadIdx.x;
+    if (i >= n || (mask && !mask[i])) return;
+    st[FPV_PID_INTEGRAL * ld + i] = 0.0f; st[FPV_PID_PREV_DERIVATIVE * ld + i] = 0.0f;
+    st[FPV_PID_PREV_ERROR * ld + i] = 0.0f; st[FPV_PID_IS_FIRST * ld + i] = 1.0f;
 }
 
 // Counter calibration: a copy with the step kernel's access shape (one dword per lane per
@@ -431,10 +669,12 @@ struct fpv_env {
     int dpl;        // drones per lane (1, 2 or 4)
     int block;      // threads per workgroup of the drone step kernel (128 or 256)
     uint32_t launches;   // counts step launches; feeds the stochastic-rounding seed
-    // cached hipGraph of the last fpv_rollout_graph call (launch-bound small batches)
+    // cached hipGraph of the last fpv_rollout_graph call (launch-bound small batches): rebuilt when the
+    // SHAPE key changes, re-pointed node by node when only buffer addresses change
     hipGraph_t graph = nullptr;
     hipGraphExec_t graph_exec = nullptr;
-    std::string graph_key;
+    std::vector<hipGraphNode_t> graph_nodes;
+    std::string graph_shape_key, graph_ptr_key;
     bool big_angle;
 };
 
@@ -462,6 +702,8 @@ int check_buffers(const fpv_env* h, const fpv_buffers_t* b, bool need_action)  /
     if (((uintptr_t)b->state & 15) || ((uintptr_t)b->action & 15))
         return fail(FPV_EALIGN, "state and action must be 16-byte aligned");
     if ((uintptr_t)b->done_bits & 7) return fail(FPV_EALIGN, "done_bits must be 8-byte aligned");
+    if (b->done_bits_stride && (b->done_bits_stride < (h->n + 63) / 64))
+        return fail(FPV_EALIGN, "done_bits_stride must be 0 or >= ceil(n / 64) words");
     if (b->objects && b->objects->count != 0) {
         if (b->objects->count < 0 || b->objects->count > FPV_MAX_OBJECTS) return fail(FPV_EINVAL, "objects.count out of range");
         if (h->mode != FPV_MODE_DRONE || (h->K.flags & (FPV_FLAG_FP16_STATE | FPV_FLAG_GROUND)) || b->obs_aos)
@@ -559,6 +801,51 @@ StepKernel drone_kernel(int block, int dpl, bool noise, bool obj, bool kahan)
     }
 }
 
+StepKernel racer_kernel(int block, bool wide, bool pidv)
+{
+    switch ((block == 256 ? 4 : 0) | (wide ? 2 : 0) | (pidv ? 1 : 0)) {
+        case 0: return fpv_racer_step_kernel<128, false, false>;
+        case 1: return fpv_racer_step_kernel<128, false, true>;
+        case 2: return fpv_racer_step_kernel<128, true, false>;
+        case 3: return fpv_racer_step_kernel<128, true, true>;
+        case 4: return fpv_racer_step_kernel<256, false, false>;
+        case 5: return fpv_racer_step_kernel<256, false, true>;
+        case 6: return fpv_racer_step_kernel<256, true, false>;
+        default: return fpv_racer_step_kernel<256, true, true>;
+    }
+}
+
+// ---- k-step kernels (fpv_step_n): signature (FpvK, FpvBufD, int64_t, FpvRoll); 128-thread workgroups ----
+typedef void (*RollKernel)(const FpvK, const FpvBufD, const int64_t, const FpvRoll);
+
+template <bool BIG>
+RollKernel drone_rollout_kernel(bool noise, bool obj, bool kahan)
+{
+    switch ((noise ? 4 : 0) | (obj ? 2 : 0) | (kahan ? 1 : 0)) {
+        case 0: return fpv_drone_rollout_kernel<128, BIG, false, false, false>;
+        case 1: return fpv_drone_rollout_kernel<128, BIG, false, false, true>;
+        case 2: return fpv_drone_rollout_kernel<128, BIG, false, true, false>;
+        case 3: return fpv_drone_rollout_kernel<128, BIG, false, true, true>;
+        case 4: return fpv_drone_rollout_kernel<128, BIG, true, false, false>;
+        case 5: return fpv_drone_rollout_kernel<128, BIG, true, false, true>;
+        case 6: return fpv_drone_rollout_kernel<128, BIG, true, true, false>;
+        default: return fpv_drone_rollout_kernel<128, BIG, true, true, true>;
+    }
+}
+
+RollKernel choose_rollout_kernel(const fpv_env* h, const FpvBufD& d)
+{
+    const bool big = h->big_angle;
+    if (h->mode != FPV_MODE_DRONE) {
+        const bool wide = h->K.r_wide != 0, pidv = h->K.r_pid_variant != 0;
+        return wide ? (pidv ? fpv_racer_rollout_kernel<128, true, true> : fpv_racer_rollout_kernel<128, true, false>)
+                    : (pidv ? fpv_racer_rollout_kernel<128, false, true> : fpv_racer_rollout_kernel<128, false, false>);
+    }
+    if (h->K.flags & FPV_FLAG_FP16_STATE) return big ? fpv_drone_rollout_h_kernel<128, true> : fpv_drone_rollout_h_kernel<128, false>;
+    const bool noise = (h->K.flags & FPV_FLAG_STICK_NOISE) != 0, obj = d.objs.count > 0, kahan = d.pos_comp != nullptr;
+    return big ? drone_rollout_kernel<true>(noise, obj, kahan) : drone_rollout_kernel<false>(noise, obj, kahan);
+}
+
 KernelChoice choose_kernel(const fpv_env* h, const FpvBufD& d)
 {
     KernelChoice c;
@@ -566,8 +853,7 @@ KernelChoice choose_kernel(const fpv_env* h, const FpvBufD& d)
     int64_t per_block = h->block;
     const bool big = h->big_angle;
     if (h->mode != FPV_MODE_DRONE) {
-        c.block = kBlock; per_block = kBlock;
-        c.func = fpv_racer_step_kernel;
+        c.func = racer_kernel(h->block, h->K.r_wide != 0, h->K.r_pid_variant != 0);
     } else if (h->K.flags & FPV_FLAG_FP16_STATE) {
         c.func = h->block == 256 ? (big ? fpv_drone_step_h_kernel<256, true> : fpv_drone_step_h_kernel<256, false>)
                                  : (big ? fpv_drone_step_h_kernel<128, true> : fpv_drone_step_h_kernel<128, false>);
@@ -608,7 +894,8 @@ int fpv_sizeof(int which)
         case 0: return (int)sizeof(fpv_params_t);
         case 1: return (int)sizeof(fpv_buffers_t);
         case 2: return (int)sizeof(fpv_objects_t);
-        default: return fail(FPV_EINVAL, "fpv_sizeof: 0 = fpv_params_t, 1 = fpv_buffers_t, 2 = fpv_objects_t");
+        case 3: return (int)sizeof(fpv_pid_params_t);
+        default: return fail(FPV_EINVAL, "fpv_sizeof: 0 = fpv_params_t, 1 = fpv_buffers_t, 2 = fpv_objects_t, 3 = fpv_pid_params_t");
     }
 }
 
@@ -621,8 +908,8 @@ int fpv_state_rows(int mode)
 
 int fpv_algorithmic_bytes(int mode)
 {
-    const int rows = fpv_state_rows(mode);
-    if (rows < 0) return rows;
+    if (mode != FPV_MODE_DRONE && mode != FPV_MODE_RACER) return fail(FPV_EINVAL, "unknown mode");
+    const int rows = mode == FPV_MODE_DRONE ? FPV_DRONE_ROWS : 20;   // Racer base rows (181 B); variants: fpv_handle_algorithmic_bytes
     return rows * 4 * 2 + 16 + 4 + 1;   // state read + write, action read, reward + done write
 }
 
@@ -630,7 +917,12 @@ int fpv_handle_algorithmic_bytes(fpv_handle_t h)
 {
     if (!h) return fail(FPV_EINVAL, "null handle");
     if (h->mode == FPV_MODE_DRONE && (h->K.flags & FPV_FLAG_FP16_STATE))
-        return (3 * 4 + FPV_HALF_PAIR_ROWS * 4) * 2 + 16 + 4 + 1;   // 93
+        return (3 * 4 + FPV_HALF_PAIR_ROWS * 4 + 2) * 2 + 16 + 4 + 1;   // 89
+    if (h->mode == FPV_MODE_RACER) {
+        // rows the selected kernel actually moves: 20 base (+6 (hi, lo) rows as written, +3 components.PID)
+        const int rows = 20 + (h->K.r_wide ? 6 : 0) + (h->K.r_pid_variant ? 3 : 0);
+        return rows * 4 * 2 + 16 + 4 + 1;
+    }
     return fpv_algorithmic_bytes(h->mode);
 }
 
@@ -639,7 +931,7 @@ int fpv_create(const fpv_params_t* params, int64_t n, int device, fpv_handle_t* 
     if (!params || !out) return fail(FPV_EINVAL, "null argument");
     *out = nullptr;
     if (n <= 0) return fail(FPV_EINVAL, "n must be positive");
-    if (n > ((int64_t)1 << 30)) return fail(FPV_EINVAL, "n exceeds 2^30 drones per handle (32-bit lane offsets)");
+    if (n > FPV_MAX_DRONES) return fail(FPV_EINVAL, "n exceeds 2^28 drones per handle (32-bit lane byte offsets into 16-byte action rows); split the population over handles");
     int count = 0;
     hipError_t e = hipGetDeviceCount(&count);
     if (e != hipSuccess || count <= 0)
@@ -752,6 +1044,7 @@ int fpv_rollout(fpv_handle_t h, const fpv_buffers_t* b, int k, int64_t action_st
             if (b->reward) d.reward = b->reward + (int64_t)t * out_stride;
             if (b->done) d.done = b->done + (int64_t)t * out_stride;
         }
+        if (b->done_bits) d.done_bits = reinterpret_cast<unsigned long long*>(b->done_bits) + (int64_t)t * b->done_bits_stride;
         if ((rc = launch_step(h, d, (hipStream_t)stream)) != FPV_OK) return rc;
     }
     return FPV_OK;
@@ -767,6 +1060,55 @@ int fpv_diag_stream_copy(float* dst, const float* src, int64_t n_floats, void* s
     return FPV_OK;
 }
 
+int fpv_step_n(fpv_handle_t h, const fpv_buffers_t* b, int k, int64_t action_stride, int64_t out_stride, void* stream)
+{
+    int rc = check_buffers(h, b, true);
+    if (rc != FPV_OK) return rc;
+    if (k < 0) return fail(FPV_EINVAL, "k must be >= 0");
+    if (k == 0) return FPV_OK;
+    if (action_stride % 4) return fail(FPV_EALIGN, "action_stride must keep 16-byte alignment");
+    if (b->obs_aos) return fail(FPV_EINVAL, "fpv_step_n does not write obs_aos rows (a per-step observation is a closed-loop need: use fpv_step)");
+    if ((rc = bind_device(h)) != FPV_OK) return rc;
+    FpvBufD d = to_device_view(b);
+    d.step = h->launches;
+    d.seed = d.seed + h->launches;
+    h->launches += (uint32_t)k;
+    FpvRoll R;
+    R.k = k; R.pad = 0; R.action_stride = action_stride; R.out_stride = out_stride; R.bits_stride = b->done_bits_stride;
+    const RollKernel f = choose_rollout_kernel(h, d);
+    const unsigned grid = (unsigned)((h->n + 127) / 128);
+    hipLaunchKernelGGL(f, dim3(grid), dim3(128), 0, (hipStream_t)stream, h->K, d, h->n, R);
+    const hipError_t e = hipGetLastError();
+    if (e != hipSuccess) return hip_fail(e, "k-step kernel launch");
+    return FPV_OK;
+}
+
+namespace {
+
+void drop_graph(fpv_env* h)
+{
+    if (h->graph_exec) { (void)hipGraphExecDestroy(h->graph_exec); h->graph_exec = nullptr; }
+    if (h->graph) { (void)hipGraphDestroy(h->graph); h->graph = nullptr; }
+    h->graph_nodes.clear();
+    h->graph_shape_key.clear();
+    h->graph_ptr_key.clear();
+}
+
+// step t's device view of a k-step graph
+FpvBufD graph_step_view(const fpv_buffers_t* b, const FpvBufD& d0, int t, int64_t action_stride, int64_t out_stride)
+{
+    FpvBufD d = d0;
+    d.action = reinterpret_cast<const float4*>(b->action + (int64_t)t * action_stride);
+    if (out_stride) {
+        if (b->reward) d.reward = b->reward + (int64_t)t * out_stride;
+        if (b->done) d.done = b->done + (int64_t)t * out_stride;
+    }
+    if (b->done_bits) d.done_bits = reinterpret_cast<unsigned long long*>(b->done_bits) + (int64_t)t * b->done_bits_stride;
+    return d;
+}
+
+}  // namespace
+
 int fpv_rollout_graph(fpv_handle_t h, const fpv_buffers_t* b, int k, int64_t action_stride, int64_t out_stride,
                       void* stream)
 {
@@ -776,29 +1118,29 @@ int fpv_rollout_graph(fpv_handle_t h, const fpv_buffers_t* b, int k, int64_t act
     if (action_stride % 4) return fail(FPV_EALIGN, "action_stride must keep 16-byte alignment");
     if (h->K.flags & (FPV_FLAG_STICK_NOISE | FPV_FLAG_FP16_STATE))
         return fail(FPV_EINVAL, "fpv_rollout_graph replays frozen kernel arguments; stick noise and fp16 state need the "
-                                "per-launch step index - use fpv_rollout");
+                                "per-launch step index - use fpv_step_n or fpv_rollout");
     if ((rc = bind_device(h)) != FPV_OK) return rc;
-    // the graph is valid for exactly these arguments
-    FpvBufD d0 = to_device_view(b);
-    std::string key(reinterpret_cast<const char*>(&d0), sizeof(d0));
-    key.append(reinterpret_cast<const char*>(&h->K), sizeof(h->K));
-    const int64_t meta[6] = {k, action_stride, out_stride, h->dpl, h->block, h->n};
-    key.append(reinterpret_cast<const char*>(meta), sizeof(meta));
-    if (!h->graph_exec || key != h->graph_key) {
-        if (h->graph_exec) { (void)hipGraphExecDestroy(h->graph_exec); h->graph_exec = nullptr; }
-        if (h->graph) { (void)hipGraphDestroy(h->graph); h->graph = nullptr; }
+    const FpvBufD d0 = to_device_view(b);
+    // SHAPE of the graph: everything that selects kernels, grids and non-pointer arguments
+    const KernelChoice c0 = choose_kernel(h, d0);
+    std::string shape(reinterpret_cast<const char*>(&h->K), sizeof(h->K));
+    const int64_t meta[9] = {k, action_stride, out_stride, h->dpl, h->block, h->n, b->ld, b->action_ld, b->done_bits_stride};
+    shape.append(reinterpret_cast<const char*>(meta), sizeof(meta));
+    shape.append(reinterpret_cast<const char*>(&c0.func), sizeof(c0.func));
+    shape.append(reinterpret_cast<const char*>(&d0.objs), sizeof(d0.objs));
+    const float wind[3] = {d0.wx, d0.wy, d0.wz};
+    shape.append(reinterpret_cast<const char*>(wind), sizeof(wind));
+    // everything else in the view is a buffer address
+    const std::string ptrs(reinterpret_cast<const char*>(&d0), sizeof(d0));
+    FpvK K = h->K;
+    int64_t n = h->n;
+    if (!h->graph_exec || shape != h->graph_shape_key) {
+        drop_graph(h);
         hipError_t e = hipGraphCreate(&h->graph, 0);
-        if (e != hipSuccess) return hip_fail(e, "hipGraphCreate");
+        if (e != hipSuccess) { drop_graph(h); return hip_fail(e, "hipGraphCreate"); }
         hipGraphNode_t prev = nullptr;
-        FpvK K = h->K;
-        int64_t n = h->n;
         for (int t = 0; t < k; ++t) {
-            FpvBufD d = d0;
-            d.action = reinterpret_cast<const float4*>(b->action + (int64_t)t * action_stride);
-            if (out_stride) {
-                if (b->reward) d.reward = b->reward + (int64_t)t * out_stride;
-                if (b->done) d.done = b->done + (int64_t)t * out_stride;
-            }
+            FpvBufD d = graph_step_view(b, d0, t, action_stride, out_stride);
             const KernelChoice c = choose_kernel(h, d);
             void* args[3] = {&K, &d, &n};                 // copied by hipGraphAddKernelNode
             hipKernelNodeParams np;
@@ -808,16 +1150,86 @@ int fpv_rollout_graph(fpv_handle_t h, const fpv_buffers_t* b, int k, int64_t act
             np.sharedMemBytes = 0; np.kernelParams = args; np.extra = nullptr;
             hipGraphNode_t node;
             e = hipGraphAddKernelNode(&node, h->graph, prev ? &prev : nullptr, prev ? 1 : 0, &np);
-            if (e != hipSuccess) return hip_fail(e, "hipGraphAddKernelNode");
+            if (e != hipSuccess) { drop_graph(h); return hip_fail(e, "hipGraphAddKernelNode"); }
+            h->graph_nodes.push_back(node);
             prev = node;
         }
         e = hipGraphInstantiate(&h->graph_exec, h->graph, nullptr, nullptr, 0);
-        if (e != hipSuccess) return hip_fail(e, "hipGraphInstantiate");
-        h->graph_key = key;
+        if (e != hipSuccess) { drop_graph(h); return hip_fail(e, "hipGraphInstantiate"); }
+        h->graph_shape_key = shape;
+        h->graph_ptr_key = ptrs;
+    } else if (ptrs != h->graph_ptr_key) {
+        // same shape, new buffers (e.g. a fresh actions tensor every call): patch the node arguments
+        for (int t = 0; t < k; ++t) {
+            FpvBufD d = graph_step_view(b, d0, t, action_stride, out_stride);
+            const KernelChoice c = choose_kernel(h, d);
+            void* args[3] = {&K, &d, &n};
+            hipKernelNodeParams np;
+            memset(&np, 0, sizeof(np));
+            np.func = reinterpret_cast<void*>(c.func);
+            np.gridDim = dim3(c.grid); np.blockDim = dim3(c.block);
+            np.sharedMemBytes = 0; np.kernelParams = args; np.extra = nullptr;
+            const hipError_t e = hipGraphExecKernelNodeSetParams(h->graph_exec, h->graph_nodes[(size_t)t], &np);
+            if (e != hipSuccess) { drop_graph(h); return hip_fail(e, "hipGraphExecKernelNodeSetParams"); }
+        }
+        h->graph_ptr_key = ptrs;
     }
     const hipError_t e = hipGraphLaunch(h->graph_exec, (hipStream_t)stream);
     if (e != hipSuccess) return hip_fail(e, "hipGraphLaunch");
     h->launches += (uint32_t)k;
+    return FPV_OK;
+}
+
+namespace {
+int bind_device_index(int device)
+{
+    int count = 0;
+    hipError_t e = hipGetDeviceCount(&count);
+    if (e != hipSuccess || count <= 0)
+        return fail(FPV_ENODEV, std::string("no HIP device available: ") + (e != hipSuccess ? hipGetErrorString(e) : "device count is 0"));
+    if (device < 0 || device >= count) return fail(FPV_ENODEV, "device index out of range");
+    int cur = -1;
+    if ((e = hipGetDevice(&cur)) != hipSuccess) return hip_fail(e, "hipGetDevice");
+    if (cur != device && (e = hipSetDevice(device)) != hipSuccess) return hip_fail(e, "hipSetDevice");
+    return FPV_OK;
+}
+}  // namespace
+
+int fpv_pid_reset(float* pid_state, int64_t ld, int64_t n, const uint8_t* mask, int device, void* stream)
+{
+    if (!pid_state) return fail(FPV_EINVAL, "pid_state is null");
+    if (n <= 0 || ld < n) return fail(FPV_EINVAL, "need 0 < n <= ld");
+    const int rc = bind_device_index(device);
+    if (rc != FPV_OK) return rc;
+    hipLaunchKernelGGL(fpv_pid_reset_kernel, dim3((unsigned)((n + kBlock - 1) / kBlock)), dim3(kBlock), 0, (hipStream_t)stream,
+                       pid_state, ld, n, mask);
+    const hipError_t e = hipGetLastError();
+    if (e != hipSuccess) return hip_fail(e, "pid reset kernel launch");
+    return FPV_OK;
+}
+
+int fpv_pid_call(const fpv_pid_params_t* params, float* pid_state, int64_t ld, int64_t n, const float* current,
+                 const float* target, float target_scalar, float* out, float* error_out, int device, void* stream)
+{
+    if (!params || !pid_state || !current || !out) return fail(FPV_EINVAL, "null argument");
+    if (params->struct_size != sizeof(fpv_pid_params_t)) return fail(FPV_EINVAL, "fpv_pid_params_t.struct_size does not match this library");
+    if (n <= 0 || ld < n) return fail(FPV_EINVAL, "need 0 < n <= ld");
+    if (!(params->dt > 0)) return fail(FPV_EPARAM, "dt must be positive");
+    if (!(params->integral_clip >= 0) || !(params->min_output <= params->max_output)
+        || !(params->derivative_transition_rate >= 0 && params->derivative_transition_rate <= 1))
+        return fail(FPV_EPARAM, "components.PID constants: integral_clip >= 0, min_output <= max_output, derivative_transition_rate in [0, 1]");
+    const int rc = bind_device_index(device);
+    if (rc != FPV_OK) return rc;
+    FpvPidK<float> P;
+    memset(&P, 0, sizeof(P));
+    P.dt = (float)params->dt; P.inv_dt = (float)(1.0 / params->dt);
+    P.gain[0][0] = (float)params->kP; P.gain[0][1] = (float)params->kI; P.gain[0][2] = (float)params->kD;
+    P.integral_clip = (float)params->integral_clip; P.min_output = (float)params->min_output; P.max_output = (float)params->max_output;
+    P.d_rate = (float)params->derivative_transition_rate; P.om_d_rate = (float)(1.0 - params->derivative_transition_rate);
+    hipLaunchKernelGGL(fpv_pid_kernel, dim3((unsigned)((n + kBlock - 1) / kBlock)), dim3(kBlock), 0, (hipStream_t)stream,
+                       P, pid_state, ld, n, current, target, target_scalar, out, error_out);
+    const hipError_t e = hipGetLastError();
+    if (e != hipSuccess) return hip_fail(e, "pid kernel launch");
     return FPV_OK;
 }
 

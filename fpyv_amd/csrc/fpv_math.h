@@ -39,6 +39,14 @@ struct FpvNoiseK {           // uniform constants of the stick-noise generator
     uint32_t id_lo, id_hi;   // global id of this shard's drone 0
 };
 
+// Constants of one rate loop in arithmetic type T (the Racer as written runs it in float64).
+template <class T> struct FpvPidK {
+    T dt, inv_dt;
+    T dt_over_I[3];
+    T gain[3][3];                                            // [axis][kP, kI, kD]
+    T integral_clip, min_output, max_output, d_rate, om_d_rate;   // components.PID (pid_variant 1) only
+};
+
 // Uniform per-launch constants (kernel argument -> SGPRs).  Derived in double on the host.
 struct FpvK {
     float dt;
@@ -55,13 +63,17 @@ struct FpvK {
     float ceiling;
     float goal[3];
     // Racer
-    float r_dt, r_inv_dt, r_inv_mass, r_damp, r_ang_k;
-    float r_dt_over_I[3];
-    float r_pid[3][3];
+    float r_dt, r_inv_mass, r_damp, r_ang_k;
+    FpvPidK<float> rf;      // rate-loop constants, fp32
     float motor_radius, ground_k_m, ground_c_m;   // contact distance; spring and damping already divided by m
     float contact_reach;    // largest |motor offset| + motor_radius + 1 mm: centre-distance bound for the object cull
     FpvNoiseK noise;
     uint32_t flags;
+    uint32_t r_wide;        // Racer: attitude increment in float64 (Racer.step as written: angle = omega per step)
+    uint32_t r_pid_variant; // 0: racer_drone_test.PID.step, 1: components.PID.__call__
+    uint32_t _pad0;
+    double r_ang_k_d;       // r_ang_k in double (the racer_omega_dt variant multiplies by the exact dt)
+    FpvPidK<double> rd;     // rate-loop constants in float64 (Racer as written)
 };
 
 struct FpvQuat { float w, x, y, z; };
@@ -215,24 +227,23 @@ FPV_HD uint32_t fpv_mix32(uint32_t x)
 
 struct FpvHalfState { uint16_t v[3], q[4], r[3], t; };   // the 11 binary16 values of one drone
 
-// storage order: six half2 rows (low half first): (vx,vy) (vz,qw) (qx,qy) (qz,rx) (ry,rz) (thrust,0)
-FPV_HD void fpv_split_pairs(const uint32_t w[6], FpvHalfState& h)
+// storage order: FIVE half2 rows (low half first): (vx,vy) (vz,qw) (qx,qy) (qz,rx) (ry,rz), then ONE row of
+// single halves for prev_thrust (89 state+io bytes per env-step); h.t is moved separately
+FPV_HD void fpv_split_pairs(const uint32_t w[5], FpvHalfState& h)
 {
     h.v[0] = (uint16_t)w[0]; h.v[1] = (uint16_t)(w[0] >> 16);
     h.v[2] = (uint16_t)w[1]; h.q[0] = (uint16_t)(w[1] >> 16);
     h.q[1] = (uint16_t)w[2]; h.q[2] = (uint16_t)(w[2] >> 16);
     h.q[3] = (uint16_t)w[3]; h.r[0] = (uint16_t)(w[3] >> 16);
     h.r[1] = (uint16_t)w[4]; h.r[2] = (uint16_t)(w[4] >> 16);
-    h.t = (uint16_t)w[5];
 }
-FPV_HD void fpv_join_pairs(const FpvHalfState& h, uint32_t w[6])
+FPV_HD void fpv_join_pairs(const FpvHalfState& h, uint32_t w[5])
 {
     w[0] = (uint32_t)h.v[0] | ((uint32_t)h.v[1] << 16);
     w[1] = (uint32_t)h.v[2] | ((uint32_t)h.q[0] << 16);
     w[2] = (uint32_t)h.q[1] | ((uint32_t)h.q[2] << 16);
     w[3] = (uint32_t)h.q[3] | ((uint32_t)h.r[0] << 16);
     w[4] = (uint32_t)h.r[1] | ((uint32_t)h.r[2] << 16);
-    w[5] = (uint32_t)h.t;
 }
 
 FPV_HD void fpv_unpack_half(const FpvHalfState& h, FpvDroneState& s)
@@ -526,47 +537,151 @@ FPV_HD void fpv_drone_reset_lane(const FpvK& K, FpvDroneState& s)
     s.thrust = 0.0f;
 }
 
+// sin and cos of an UNBOUNDED angle in float64, the same instruction sequence on the host and on
+// gfx950 (explicit fma, no library call): three-part Cody-Waite reduction by pi/2 (each part has
+// 33 significant bits, so k * part is exact for |k| < 2^20, i.e. |x| < 1.6e6 rad) and the Taylor
+// polynomials to x^15 / x^16 (truncation < 5e-17 on |r| <= pi/4).  Used by the Racer as written,
+// whose per-step angle is omega in RADIANS PER STEP (racer_drone_test.py:99): tens of radians, the
+// same value step after step, so any fp32 rounding of the increment repeats coherently.
+FPV_HD void fpv_sincos_wide(double x, double* s, double* c)
+{
+    const double k = rint(x * 0.6366197723675814);                 // 2/pi
+    double r = fma(-k, 1.57079632673412561417e+00, x);              // pi/2, bits 1..33
+    r = fma(-k, 6.07710050630396597660e-11, r);                     //       bits 34..66
+    r = fma(-k, 2.02226624871116645580e-21, r);                     //       bits 67..99
+    const double r2 = r * r;
+    double ps = fma(r2, -7.647163731819816e-13, 1.6059043836821613e-10);     // -1/15!, 1/13!
+    ps = fma(ps, r2, -2.505210838544172e-08);                                   // -1/11!
+    ps = fma(ps, r2, 2.7557319223985893e-06);                                    //  1/9!
+    ps = fma(ps, r2, -1.984126984126984e-04);                                   // -1/7!
+    ps = fma(ps, r2, 8.333333333333333e-03);                                    //  1/5!
+    ps = fma(ps, r2, -1.6666666666666666e-01);                                   // -1/3!
+    const double sr = fma(r * r2, ps, r);
+    double pc = fma(r2, 4.779477332387385e-14, -1.1470745597729725e-11);     //  1/16!, -1/14!
+    pc = fma(pc, r2, 2.08767569878681e-09);                                    //  1/12!
+    pc = fma(pc, r2, -2.755731922398589e-07);                                   // -1/10!
+    pc = fma(pc, r2, 2.48015873015873e-05);                                    //  1/8!
+    pc = fma(pc, r2, -1.388888888888889e-03);                                   // -1/6!
+    pc = fma(pc, r2, 4.1666666666666664e-02);                                    //  1/4!
+    pc = fma(pc, r2, -0.5);
+    const double cr = fma(r2, pc, 1.0);
+    const int q = (int)((long long)k & 3);
+    const double ss = (q & 1) ? cr : sr, cs = (q & 1) ? sr : cr;
+    *s = (q & 2) ? -ss : ss;
+    *c = ((q + 1) & 2) ? -cs : cs;
+}
+
 // ------------------------------------------------------------------------------------------------
 // Racer: rate PID -> torque -> omega -> attitude; thrust along body z, damped velocity.
-//   PID.step   tests/racer_drone_test.py:22-32
-//   Racer.step tests/racer_drone_test.py:95-103
+//   PID.step            tests/racer_drone_test.py:22-32          (pid_variant 0)
+//   PID.__call__        src/utils/components.py:43-54            (pid_variant 1: leaky clipped integral,
+//                                                                 clipped + low-passed derivative, clipped output)
+//   Racer.step          tests/racer_drone_test.py:95-103
 // ------------------------------------------------------------------------------------------------
 struct FpvRacerState {
     float px, py, pz, vx, vy, vz;
     FpvQuat q;
     float w[3], ierr[3], lerr[3];
     float first;
+    float wlo[3], ilo[3];   // low words of omega and of the PID integral (Racer as written only; rows FPV_R_OMEGA_LO.., FPV_R_IERR_LO..)
+    float dflt[3];          // components.PID prev_derivative (pid_variant 1 only; rows FPV_R_DFILT..)
 };
 
+FPV_HD float fpv_fma_t(float a, float b, float c) { return fmaf(a, b, c); }
+FPV_HD double fpv_fma_t(double a, double b, double c) { return fma(a, b, c); }
+FPV_HD float fpv_clip_t(float x, float lo, float hi) { return fminf(fmaxf(x, lo), hi); }     // np.clip
+FPV_HD double fpv_clip_t(double x, double lo, double hi) { return fmin(fmax(x, lo), hi); }
+
+// One axis of the rate loop in arithmetic type T (float, or double for the Racer as written).
+// Returns the torque; advances integral / last error / filtered derivative.
+template <class T, int PIDV>
+FPV_HD T fpv_pid_axis(const FpvPidK<T>& P, int i, T actual, T desired, bool first, T& integ, T& last, T& dflt)
+{
+    if (PIDV == 0) {                                                        // racer_drone_test.py:22-32
+        const T err = desired - actual;                                     // :23
+        integ = fpv_fma_t(err, P.dt, integ);                                // :25
+        const T derr = first ? (T)0 : (err - last) * P.inv_dt;              // :26-29
+        last = err;                                                         // :31
+        return fpv_fma_t(P.gain[i][0], err, fpv_fma_t(P.gain[i][1], integ, P.gain[i][2] * derr));   // :32
+    } else {                                                                // components.py:43-54
+        const T err = actual - desired;                                     // :44  current - target
+        integ = fpv_clip_t(fpv_fma_t((T)0.99, integ, err * P.dt), -P.integral_clip, P.integral_clip);   // :46
+        T d = fpv_clip_t(first ? (T)0 : (err - last) * P.inv_dt, (T)-1, (T)1);                           // :48
+        d = fpv_fma_t(P.om_d_rate, dflt, P.d_rate * d);                     // :49
+        dflt = d;                                                           // :50
+        last = err;                                                         // :53
+        return fpv_clip_t(fpv_fma_t(P.gain[i][0], err, fpv_fma_t(P.gain[i][1], integ, P.gain[i][2] * d)),
+                          P.min_output, P.max_output);                      // :54
+    }
+}
+
+// WIDE: the rate loop, omega and the attitude increment in float64 (state rows stay fp32; omega and
+// the PID integral are fp32 (hi, lo) pairs).  Needed for Racer.step AS WRITTEN, which turns the
+// attitude by omega RADIANS per step (racer_drone_test.py:99): an error d in omega is d radians of
+// attitude EVERY step, an fp32 ulp of omega ~ 1 is already 1.2e-7 rad, fp32 gains are off by 6e-8
+// relative, and with omega constant the increment quaternion is the same every step so its fp32
+// rounding would add up coherently (6e-5 over 1000 steps).  In float64 only the final rounding of q
+// to fp32 remains, which is incoherent: measured 7e-7 on the reference captures G7/G8 over the whole
+// 1000-step trajectory.  The racer_omega_dt variant (angle = omega*dt) is well conditioned in fp32.
+template <bool WIDE, int PIDV = 0>
 FPV_HD float fpv_racer_step_lane(const FpvK& K, FpvRacerState& s, float a0, float a1, float a2, float a3)
 {
     const float act[3] = {a0, a1, a2};
+    const bool first = s.first != 0.0f;
+    if (WIDE) {
+        double ang[3];
 #pragma unroll
-    for (int i = 0; i < 3; ++i) {
-        const float err = act[i] - s.w[i];                                  // :23
-        s.ierr[i] = fmaf(err, K.r_dt, s.ierr[i]);                           // :25
-        const float derr = (s.first != 0.0f) ? 0.0f : (err - s.lerr[i]) * K.r_inv_dt;   // :26-29
-        s.lerr[i] = err;                                                    // :31
-        const float tq = fmaf(K.r_pid[i][0], err, fmaf(K.r_pid[i][1], s.ierr[i], K.r_pid[i][2] * derr));
-        s.w[i] = fmaf(tq, K.r_dt_over_I[i], s.w[i]);                        // :98
+        for (int i = 0; i < 3; ++i) {
+            const double w = (double)s.w[i] + (double)s.wlo[i];
+            double integ = (double)s.ierr[i] + (double)s.ilo[i], last = (double)s.lerr[i], df = (double)s.dflt[i];
+            const double tq = fpv_pid_axis<double, PIDV>(K.rd, i, w, (double)act[i], first, integ, last, df);
+            const double wn = fma(tq, K.rd.dt_over_I[i], w);                // :98
+            s.ierr[i] = (float)integ; s.ilo[i] = (float)(integ - (double)s.ierr[i]);
+            s.lerr[i] = (float)last; s.dflt[i] = (float)df;
+            s.w[i] = (float)wn; s.wlo[i] = (float)(wn - (double)s.w[i]);
+            ang[i] = 0.5 * wn * K.r_ang_k_d;
+        }
+        // :99  q <- q (x) qx(a) (x) qy(b) (x) qz(c)   (intrinsic "XYZ"), angle = omega * r_ang_k
+        double sa, ca, sb, cb, sc, cc;
+        fpv_sincos_wide(ang[0], &sa, &ca);
+        fpv_sincos_wide(ang[1], &sb, &cb);
+        fpv_sincos_wide(ang[2], &sc, &cc);
+        const double w1 = ca * cb, x1 = sa * cb, y1 = ca * sb, z1 = sa * sb;
+        const double dw = fma(w1, cc, -z1 * sc), dx = fma(x1, cc, y1 * sc);
+        const double dy = fma(y1, cc, -x1 * sc), dz = fma(z1, cc, w1 * sc);
+        const double qw = s.q.w, qx = s.q.x, qy = s.q.y, qz = s.q.z;
+        const double nw = fma(qw, dw, fma(-qx, dx, fma(-qy, dy, -qz * dz)));
+        const double nx = fma(qw, dx, fma(qx, dw, fma(qy, dz, -qz * dy)));
+        const double ny = fma(qw, dy, fma(-qx, dz, fma(qy, dw, qz * dx)));
+        const double nz = fma(qw, dz, fma(qx, dy, fma(-qy, dx, qz * dw)));
+        // |n|^2 = 1 + e with |e| ~ 1e-7 (the fp32 storage of q): 1/sqrt(1+e) = 1 - e/2 + 3e^2/8
+        const double e = fma(nw, nw, fma(nx, nx, fma(ny, ny, fma(nz, nz, -1.0))));
+        const double k = fma(0.375 * e, e, -0.5 * e);
+        s.q.w = (float)fma(k, nw, nw); s.q.x = (float)fma(k, nx, nx);
+        s.q.y = (float)fma(k, ny, ny); s.q.z = (float)fma(k, nz, nz);
+    } else {
+#pragma unroll
+        for (int i = 0; i < 3; ++i) {
+            const float tq = fpv_pid_axis<float, PIDV>(K.rf, i, s.w[i], act[i], first, s.ierr[i], s.lerr[i], s.dflt[i]);
+            s.w[i] = fmaf(tq, K.rf.dt_over_I[i], s.w[i]);                   // :98
+        }
+        float sa, ca, sb, cb, sc, cc;
+        fpv_sincos_full(0.5f * s.w[0] * K.r_ang_k, &sa, &ca);
+        fpv_sincos_full(0.5f * s.w[1] * K.r_ang_k, &sb, &cb);
+        fpv_sincos_full(0.5f * s.w[2] * K.r_ang_k, &sc, &cc);
+        // qx*qy = (ca cb, sa cb, ca sb, sa sb); then * qz
+        const float w1 = ca * cb, x1 = sa * cb, y1 = ca * sb, z1 = sa * sb;
+        const float dw = fmaf(w1, cc, -z1 * sc), dx = fmaf(x1, cc, y1 * sc);
+        const float dy = fmaf(y1, cc, -x1 * sc), dz = fmaf(z1, cc, w1 * sc);
+        FpvQuat n;
+        n.w = fmaf(s.q.w, dw, fmaf(-s.q.x, dx, fmaf(-s.q.y, dy, -s.q.z * dz)));
+        n.x = fmaf(s.q.w, dx, fmaf(s.q.x, dw, fmaf(s.q.y, dz, -s.q.z * dy)));
+        n.y = fmaf(s.q.w, dy, fmaf(-s.q.x, dz, fmaf(s.q.y, dw, s.q.z * dx)));
+        n.z = fmaf(s.q.w, dz, fmaf(s.q.x, dy, fmaf(-s.q.y, dx, s.q.z * dw)));
+        const float inv = 1.0f / sqrtf(fmaf(n.w, n.w, fmaf(n.x, n.x, fmaf(n.y, n.y, n.z * n.z))));
+        s.q.w = n.w * inv; s.q.x = n.x * inv; s.q.y = n.y * inv; s.q.z = n.z * inv;
     }
     s.first = 0.0f;
-    // :99  q <- q (x) qx(a) (x) qy(b) (x) qz(c)   (intrinsic "XYZ"), angle = omega * r_ang_k
-    float sa, ca, sb, cb, sc, cc;
-    fpv_sincos_full(0.5f * s.w[0] * K.r_ang_k, &sa, &ca);
-    fpv_sincos_full(0.5f * s.w[1] * K.r_ang_k, &sb, &cb);
-    fpv_sincos_full(0.5f * s.w[2] * K.r_ang_k, &sc, &cc);
-    // qx*qy = (ca cb, sa cb, ca sb, sa sb); then * qz
-    const float w1 = ca * cb, x1 = sa * cb, y1 = ca * sb, z1 = sa * sb;
-    const float dw = fmaf(w1, cc, -z1 * sc), dx = fmaf(x1, cc, y1 * sc);
-    const float dy = fmaf(y1, cc, -x1 * sc), dz = fmaf(z1, cc, w1 * sc);
-    FpvQuat n;
-    n.w = fmaf(s.q.w, dw, fmaf(-s.q.x, dx, fmaf(-s.q.y, dy, -s.q.z * dz)));
-    n.x = fmaf(s.q.w, dx, fmaf(s.q.x, dw, fmaf(s.q.y, dz, -s.q.z * dy)));
-    n.y = fmaf(s.q.w, dy, fmaf(-s.q.x, dz, fmaf(s.q.y, dw, s.q.z * dx)));
-    n.z = fmaf(s.q.w, dz, fmaf(s.q.x, dy, fmaf(-s.q.y, dx, s.q.z * dw)));
-    const float inv = 1.0f / sqrtf(fmaf(n.w, n.w, fmaf(n.x, n.x, fmaf(n.y, n.y, n.z * n.z))));
-    s.q.w = n.w * inv; s.q.x = n.x * inv; s.q.y = n.y * inv; s.q.z = n.z * inv;
     // :100-103 force along the NEW body z, damped velocity, v-then-p
     const FpvRot R = fpv_rot(s.q);
     const float f = a3 * K.r_inv_mass * K.r_dt;
@@ -583,6 +698,6 @@ FPV_HD void fpv_racer_reset_lane(FpvRacerState& s)
     s.px = s.py = s.pz = s.vx = s.vy = s.vz = 0.0f;
     s.q.w = 1.0f; s.q.x = s.q.y = s.q.z = 0.0f;
 #pragma unroll
-    for (int i = 0; i < 3; ++i) { s.w[i] = 0.0f; s.ierr[i] = 0.0f; s.lerr[i] = 0.0f; }
+    for (int i = 0; i < 3; ++i) { s.w[i] = 0.0f; s.ierr[i] = 0.0f; s.lerr[i] = 0.0f; s.wlo[i] = 0.0f; s.ilo[i] = 0.0f; s.dflt[i] = 0.0f; }
     s.first = 1.0f;
 }

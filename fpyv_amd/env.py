@@ -62,10 +62,10 @@ class _Batch:
         _lib.check(self._L.fpv_create(C.byref(self._cparams), self.n, dev_index, C.byref(self._handle)))
         f32 = dict(dtype=torch.float32, device=self.device)
         if self.fp16_state:
-            # BASELINE config 4: position rows fp32; v, q, rates, thrust as binary16 in six rows of
-            # half2 pairs (vx,vy) (vz,qw) (qx,qy) (qz,rx) (ry,rz) (thrust,0): 93 B per env-step
+            # BASELINE config 4: position rows fp32; v, q, rates, thrust as binary16: five rows of half2 pairs
+            # (vx,vy) (vz,qw) (qx,qy) (qz,rx) (ry,rz) and one row of thrust halves: 89 B per env-step
             self.state = torch.zeros((3, self.ld), **f32)
-            self.state_h = torch.zeros((_lib.FPV_HALF_PAIR_ROWS, self.ld, 2), dtype=torch.float16, device=self.device)
+            self.state_h = torch.zeros(_lib.FPV_HALF_HALVES * self.ld, dtype=torch.float16, device=self.device)
         else:
             self.state = torch.zeros((self.rows, self.ld), **f32)
             self.state_h = None
@@ -89,6 +89,7 @@ class _Batch:
         # optional row-major [num_envs, 16] observation written by the kernel through an LDS transpose
         self.obs_aos = (torch.zeros((self.n, _lib.FPV_OBS_AOS_DIM), **f32) if with_obs_aos else None)
         self._bcast_action = None
+        self._done_bits_keep = None
         self._ashape = torch.Size((self.n, 4))
         self._steps_launched = 0        # mirrors the handle's launch counter (fpv_set_step_counter)
         self._buf = _lib.FpvBuffers()
@@ -120,9 +121,15 @@ class _Batch:
         if r0 < 3:
             parts.append(self.state[r0:min(r1, 3), :self.n])
         if r1 > 3:
-            flat = self.state_h[:, :self.n].permute(0, 2, 1).reshape(2 * _lib.FPV_HALF_PAIR_ROWS, self.n)   # value r-3 = row
-            parts.append(flat[max(r0, 3) - 3:r1 - 3].float())
+            parts.append(self.half_rows()[max(r0, 3) - 3:r1 - 3, :self.n].float())
         return torch.cat(parts, dim=0).t()
+
+    def half_rows(self) -> torch.Tensor:
+        """[11, ld] binary16 values of the fp16 storage, row r-3 = state value r (vx .. thrust): a copy
+        assembled from the five half2 pair rows and the thrust row of `state_h`."""
+        ld, npair = self.ld, _lib.FPV_HALF_PAIR_ROWS
+        pairs = self.state_h[:2 * npair * ld].view(npair, ld, 2).permute(0, 2, 1).reshape(2 * npair, ld)
+        return torch.cat([pairs, self.state_h[2 * npair * ld:].view(1, ld)], dim=0)
 
     def algorithmic_bytes(self) -> int:
         return int(self._L.fpv_handle_algorithmic_bytes(self._handle))
@@ -262,14 +269,41 @@ class _Batch:
             _lib.check(rc)
         self._steps_launched = (self._steps_launched + 1) & 0xFFFFFFFF
 
+    def set_done_bits_target(self, target: Any = None, stride_words: int = 0) -> None:
+        """Where the kernel writes the bit-packed done mask (one wave ballot per 64 drones):
+        an int64 tensor of at least ceil(num_envs / 64) words or a raw device address; None restores the
+        batch's own `done_bits` tensor (or switches the mask off when the batch was built without one).
+        `stride_words` > 0 makes a k-step `rollout` write step t's mask at target + t * stride_words words
+        (e.g. the rows of a [k, words] bucket that a collective ships afterwards); 0 = each step overwrites."""
+        words = _round_up(self.n, 64) // 64
+        if target is None:
+            self._done_bits_keep = None
+            self._buf.done_bits = self.done_bits.data_ptr() if self.done_bits is not None else None
+        elif torch.is_tensor(target):
+            if target.dtype != torch.int64 or not target.is_contiguous() or target.device != self.state.device:
+                raise ValueError("done-bits target must be a contiguous int64 tensor on the env's device")
+            if target.numel() < words:
+                raise ValueError(f"done-bits target needs at least {words} words")
+            self._done_bits_keep = target
+            self._buf.done_bits = target.data_ptr()
+        else:
+            self._done_bits_keep = None
+            self._buf.done_bits = int(target)
+        if stride_words and stride_words < words:
+            raise ValueError(f"stride_words must be 0 or >= {words}")
+        self._buf.done_bits_stride = int(stride_words)
+
     def rollout(self, actions: Optional[torch.Tensor], wind: Optional[Sequence[float]] = None,
                 rewards: Optional[torch.Tensor] = None, dones: Optional[torch.Tensor] = None,
-                steps: Optional[int] = None, graph: Optional[bool] = None) -> None:
-        """k steps back to back without returning to Python: actions [k, num_envs, 4] (one batch
-        per step) or [num_envs, 4] with `rewards`/`dones` of shape [k, num_envs] (or `steps`) giving
-        k; actions=None with stick_noise=True runs `steps` steps of pure in-kernel noise sticks.
-        graph=True replays the launches from a hipGraph cached in the handle (fpv_rollout_graph);
-        the default (None) does so for launch-bound batches (<= 2^17 drones) when the handle allows it."""
+                steps: Optional[int] = None, graph: Optional[bool] = None, fused: Optional[bool] = None) -> None:
+        """k steps without returning to Python: actions [k, num_envs, 4] (one batch per step) or
+        [num_envs, 4] with `rewards`/`dones` of shape [k, num_envs] (or `steps`) giving k; actions=None
+        with stick_noise=True runs `steps` steps of pure in-kernel noise sticks.
+
+        fused (default): ONE launch of the k-step kernel (fpv_step_n) - the drone stays in registers for
+        the k steps; results are bit-identical to k single steps.  fused=False issues k single-step
+        launches from one C call (fpv_rollout); graph=True replays those launches from a hipGraph cached
+        in the handle (fpv_rollout_graph)."""
         b = self._buf
         if actions is None:
             if not self.stick_noise or steps is None:
@@ -300,9 +334,17 @@ class _Batch:
             b.reward = rewards.data_ptr() if rewards is not None else None
             b.done = dones.data_ptr() if dones is not None else None
         try:
-            if graph is None:
-                graph = (self.n <= (1 << 17) and actions is not None and not self.stick_noise and not self.fp16_state)
-            fn = self._L.fpv_rollout_graph if graph else self._L.fpv_rollout     # graph: cached hipGraph replay
+            if graph:
+                fn = self._L.fpv_rollout_graph
+            elif fused is None or fused:
+                if self.obs_aos is not None:
+                    if fused:
+                        raise ValueError("the fused k-step kernel does not write obs_aos rows; use fused=False")
+                    fn = self._L.fpv_rollout
+                else:
+                    fn = self._L.fpv_step_n
+            else:
+                fn = self._L.fpv_rollout
             _lib.check(fn(self._handle, C.byref(b), int(k), stride, out_stride, self._stream()))
             self._steps_launched = (self._steps_launched + int(k)) & 0xFFFFFFFF
         finally:
@@ -333,6 +375,23 @@ class _Batch:
         return self.done_u8.bool()
 
 
+def as_drone_params(params: Any, mode: int, default_fps: Optional[float] = None) -> DroneParams:
+    """DroneParams | params.yaml-shaped dict (what the reference passes to Drone(), components.py:73) |
+    path of such a YAML | None (packaged defaults) -> DroneParams in the requested mode."""
+    if params is None:
+        p = load_params(fps=default_fps)
+    elif isinstance(params, DroneParams):
+        p = params
+    elif isinstance(params, dict):
+        from .params import params_from_dict
+        p = params_from_dict(params)
+    elif isinstance(params, (str, bytes)) or hasattr(params, "__fspath__"):
+        p = load_params(params)
+    else:
+        raise TypeError("params must be a DroneParams, a params.yaml-shaped dict, a YAML path or None")
+    return p if p.mode == mode else p.replace(mode=mode)
+
+
 def quat_to_matrix(q: torch.Tensor) -> torch.Tensor:
     """(w,x,y,z) [...,4] -> rotation matrices [...,3,3]; a view helper for API parity, not on the
     step path (/root/reference/src/utils/helper_functions.py:100-117)."""
@@ -356,13 +415,16 @@ def euler_zyx_matrix(angles: torch.Tensor) -> torch.Tensor:
 class DroneBatch(_Batch):
     """N reference `Drone`s stepped by one HIP kernel (mode "drone")."""
 
-    def __init__(self, params: Optional[DroneParams] = None, num_envs: int = 1, device: Any = "cuda:0", **kw):
-        params = params if params is not None else load_params()
-        if params.mode != MODE_DRONE:
-            params = params.replace(mode=MODE_DRONE)
+    def __init__(self, params: Any = None, num_envs: int = 1, device: Any = "cuda:0", **kw):
+        """`params` is what the reference's `Drone(params)` takes (components.py:73) - the nested dict read
+        from config/params.yaml (it is NOT modified; the reference mutates it, :143-144) - or the path of
+        such a YAML file, or a ready DroneParams; None loads the packaged defaults.  Sections the stepper
+        does not use (camera, point_and_shoot, joystick paths, ...) are ignored."""
+        params = as_drone_params(params, mode=MODE_DRONE)
         kw.setdefault("with_accel", True)
         super().__init__(params, num_envs, device, **kw)
         self.dt = params.dt
+        self.max_rates = params.max_rates                      # components.py:87
 
     def reset(self, position=None, velocity=None, ypr=None, mask=None) -> None:
         """Drone.reset: `ypr` is consumed as (roll, pitch, yaw) in degrees, like the reference
@@ -402,10 +464,8 @@ class DroneBatch(_Batch):
 class RacerBatch(_Batch):
     """N reference `Racer`s (rate PID -> torque -> omega -> attitude), mode "racer"."""
 
-    def __init__(self, params: Optional[DroneParams] = None, num_envs: int = 1, device: Any = "cuda:0", **kw):
-        params = params if params is not None else load_params(fps=1000)
-        if params.mode != MODE_RACER:
-            params = params.replace(mode=MODE_RACER)
+    def __init__(self, params: Any = None, num_envs: int = 1, device: Any = "cuda:0", **kw):
+        params = as_drone_params(params, mode=MODE_RACER, default_fps=1000)
         super().__init__(params, num_envs, device, **kw)
 
     def reset(self, mask=None) -> None:

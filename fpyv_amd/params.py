@@ -125,6 +125,12 @@ class DroneParams:
     racer_pid: np.ndarray = dataclasses.field(default_factory=lambda: np.zeros((3, 3)))
     racer_velocity_damping: float = 0.9
     racer_omega_dt: bool = False    # False = rotate by omega per step as the reference writes it
+    # rate-loop semantics: 0 = racer_drone_test.PID.step (:22-32), 1 = components.PID.__call__ (components.py:43-54)
+    racer_pid_variant: int = 0
+    pid_integral_clip: float = 1.0                 # components.py:16 defaults
+    pid_min_output: float = 0.3
+    pid_max_output: float = 1.0
+    pid_derivative_transition_rate: float = 0.5
     # ground plane in object_list (components.py:198-214, :121; Ground.calculate_distance = z, :674-677)
     ground: bool = False
     motor_radius: float = 0.1
@@ -221,6 +227,11 @@ def params_from_dict(cfg: Dict[str, Any], yaml_dir: str = _DATA_DIR, mode: Any =
         racer_pid=np.asarray([pid["roll"], pid["pitch"], pid["yaw"]], dtype=np.float64),
         racer_velocity_damping=float(racer.get("velocity_damping", 0.9)),
         racer_omega_dt=bool(racer.get("omega_dt", False)),
+        racer_pid_variant=int(racer.get("pid_variant", 0)),
+        pid_integral_clip=float(racer.get("integral_clip", 1.0)),
+        pid_min_output=float(racer.get("min_output", 0.3)),
+        pid_max_output=float(racer.get("max_output", 1.0)),
+        pid_derivative_transition_rate=float(racer.get("derivative_transition_rate", 0.5)),
         ground=bool(st.get("ground", False)),
         motor_radius=float(st.get("motor_radius", 0.1)),
         ground_spring=float(st.get("ground_spring", 100.0)),

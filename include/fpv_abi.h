@@ -26,7 +26,7 @@
 extern "C" {
 #endif
 
-#define FPV_ABI_VERSION 1
+#define FPV_ABI_VERSION 2
 
 enum {
     FPV_OK = 0,
@@ -56,7 +56,13 @@ enum {
     FPV_R_IERR = 13,                     /* rows 13..15 PID i_error                      */
     FPV_R_LERR = 16,                     /* rows 16..18 PID last_error                   */
     FPV_R_FIRST = 19,                    /* 1.0 until the first PID step                 */
-    FPV_RACER_ROWS = 20
+    FPV_R_OMEGA_LO = 20,                 /* rows 20..22 low words of angular_velocity: Racer.step AS WRITTEN turns by
+                                            omega RADIANS per step (racer_drone_test.py:99), so omega is carried as an
+                                            fp32 (hi, lo) pair; unused (never read or written) with racer_omega_dt = 1 */
+    FPV_R_IERR_LO = 23,                  /* rows 23..25 low words of the PID i_error, same reason                */
+    FPV_R_DFILT = 26,                    /* rows 26..28 prev_derivative of components.PID (components.py:50); only
+                                            touched with racer_pid_variant = 1                                   */
+    FPV_RACER_ROWS = 29
 };
 
 enum {
@@ -72,9 +78,12 @@ enum {
                                    fp32; arithmetic stays fp32 (BASELINE config 4) */
 };
 /* state_h under FPV_FLAG_FP16_STATE: FPV_HALF_PAIR_ROWS rows of ld half2 pairs (low half first):
- * (vx,vy) (vz,qw) (qx,qy) (qz,rx) (ry,rz) (thrust,0) - i.e. value r (FPV_VX..FPV_THRUST) of drone i is
- * half ((r-3) & 1) of pair state_h[((r-3) >> 1) * ld + i]. */
-#define FPV_HALF_PAIR_ROWS 6
+ * (vx,vy) (vz,qw) (qx,qy) (qz,rx) (ry,rz) - i.e. value r (FPV_VX..FPV_RZ) of drone i is half ((r-3) & 1) of pair
+ * state_h[((r-3) >> 1) * ld + i] - followed by ONE row of ld single halves holding prev_thrust:
+ * (FPV_HALF_PAIR_ROWS * 2 + 1) * ld halves in all, 22 bytes per drone.  The kernel never issues a 2-byte access:
+ * the two lanes of an even/odd drone pair share the dword of the thrust row and exchange their halves in registers. */
+#define FPV_HALF_PAIR_ROWS 5
+#define FPV_HALF_ROWS_TOTAL_HALVES 11    /* halves per drone in state_h */
 #define FPV_OBS_AOS_DIM 16
 
 /* Host-side description of one drone type; doubles, narrowed to fp32 by fpv_create.
@@ -113,6 +122,16 @@ typedef struct fpv_params {
     double noise_gain;                /* sticks += noise_gain * x_s */
     uint64_t noise_seed;              /* Philox key */
     uint64_t drone_id_offset;         /* global id of this handle's drone 0 (shard offset): streams are keyed by global id */
+    /* FPV_MODE_RACER rate loop semantics.  0: PID.step of tests/racer_drone_test.py:22-32 (error = desired - actual,
+     * plain integral, raw derivative); 1: PID.__call__ of src/utils/components.py:43-54 (error = current - target,
+     * integral <- clip(0.99*integral + error*dt, +-integral_clip), derivative clipped to +-1 then low-passed with
+     * derivative_transition_rate, output clipped to [min_output, max_output]); gains come from racer_pid either way */
+    uint32_t racer_pid_variant;
+    uint32_t _reserved0;
+    double pid_integral_clip;         /* components.py:16 defaults: 1 */
+    double pid_min_output;            /*                            0.3 */
+    double pid_max_output;            /*                            1 */
+    double pid_derivative_transition_rate;   /*                     0.5 */
 } fpv_params_t;
 
 /* Analytic collision objects = the reference's object_list (components.py:198-214) in list order.
@@ -143,7 +162,8 @@ typedef struct fpv_buffers {
     int32_t* last_length;    /* [n] */
     float wind[3];           /* wind_velocity_vector of this step (kinematics.py:35: ADDED to v) */
     uint32_t rounding_seed;  /* FPV_FLAG_FP16_STATE: mixed with the handle's launch counter for the stochastic rounding */
-    uint16_t* state_h;       /* FPV_FLAG_FP16_STATE: [FPV_HALF_PAIR_ROWS][ld] half2 pairs (4 bytes each), 8-byte aligned; else unused */
+    uint16_t* state_h;       /* FPV_FLAG_FP16_STATE: [FPV_HALF_PAIR_ROWS][ld] half2 pairs (4 bytes each) + [ld] thrust halves,
+                                8-byte aligned; else unused */
     float* pos_comp;         /* [6][ld] Kahan compensation of the p and v accumulations, or NULL (plain fp32 sums).
                                 Keeps p, v within ~1 ulp over 10^4+ steps (config 1); +48 B per env-step; drone mode,
                                 fp32 state; combines with stick noise and objects, not with obs_aos */
@@ -157,23 +177,28 @@ typedef struct fpv_buffers {
     float* obs_aos;          /* [n][FPV_OBS_AOS_DIM] row-major observation per drone, 16-byte aligned, or NULL:
                                 p3, v3, q4 (wxyz), prev_rates3, R_new@acc 3 - the values Drone.step returns
                                 (components.py:247-248) gathered in one row; drone mode, fp32 state only */
+    int64_t done_bits_stride;/* fpv_rollout / fpv_step_n: step t writes its bit mask at done_bits + t*done_bits_stride
+                                words (>= ceil(n/64)); 0 = every step overwrites the same mask */
 } fpv_buffers_t;
 
 typedef struct fpv_env* fpv_handle_t;
 
 int fpv_abi_version(void);
-/* sizeof of the ABI structs as this library was compiled (0 fpv_params_t, 1 fpv_buffers_t, 2 fpv_objects_t):
+/* sizeof of the ABI structs as this library was compiled (0 fpv_params_t, 1 fpv_buffers_t, 2 fpv_objects_t,
+ * 3 fpv_pid_params_t):
  * lets a foreign-language binding verify its struct declarations at load time */
 int fpv_sizeof(int which);
 /* rows of the state matrix for a mode (FPV_DRONE_ROWS / FPV_RACER_ROWS), or FPV_EINVAL */
 int fpv_state_rows(int mode);
 /* bytes each env-step must move at minimum (state R+W, action R, reward+done W) - roofline bookkeeping */
 int fpv_algorithmic_bytes(int mode);
-/* same for a live handle (accounts for FPV_FLAG_FP16_STATE: 3*4 + 6*4 bytes of state each way = 93 B) */
+/* same for a live handle: FPV_FLAG_FP16_STATE moves 3*4 + 5*4 + 2 = 34 bytes of state each way = 89 B; the Racer as
+ * written adds its six (hi, lo) rows (229 B), components.PID its three derivative rows (+24 B) */
 int fpv_handle_algorithmic_bytes(fpv_handle_t h);
 
 /* Replaces Drone.__init__'s physics set-up (components.py:86-142) / Racer.__init__ (:68-83).
- * Validates and narrows the parameters; binds to `device`.  No device allocation. */
+ * Validates and narrows the parameters; binds to `device`.  No device allocation.
+ * n <= 2^28 drones per handle (32-bit lane byte offsets into 16-byte action rows). */
 int fpv_create(const fpv_params_t* params, int64_t n, int device, fpv_handle_t* out);
 void fpv_destroy(fpv_handle_t h);
 
@@ -193,14 +218,26 @@ int fpv_step(fpv_handle_t h, const fpv_buffers_t* b, void* stream);
 int fpv_rollout(fpv_handle_t h, const fpv_buffers_t* b, int k, int64_t action_stride,
                 int64_t out_stride, void* stream);
 
+/* The same k steps as fpv_rollout - bit for bit - in ONE launch: each lane keeps its drone's state (and
+ * noise / Kahan / episode accumulators) in registers for the k steps, streams step t's action from
+ * action + t*action_stride while step t-1 computes, and writes reward/done (and done_bits) per step only
+ * when the strides are non-zero, otherwise after the last step.  This is the open-loop / in-kernel-noise
+ * loop `for i in range(time_steps): drone.step(...)` of src/core/simulator.py:83-156 without the
+ * 112-byte state round trip per step: (16 + 5 + 112/k) B per env-step instead of 133 B.
+ * Supported: drone mode (fp32 or fp16 state; stick noise, objects, Kahan rows in any combination) and
+ * racer mode; obs_aos is refused (an observation row per step is a closed-loop need: use fpv_step). */
+int fpv_step_n(fpv_handle_t h, const fpv_buffers_t* b, int k, int64_t action_stride,
+               int64_t out_stride, void* stream);
+
 /* The step index that keys the stick-noise stream (and the stochastic rounding) counts launches of a
  * handle from 0; set it to resume / replay a run. */
 int fpv_set_step_counter(fpv_handle_t h, uint32_t step);
 
-/* Same k steps as fpv_rollout, replayed from a hipGraph that is built on the first call with a given
- * set of arguments and cached in the handle: for small, launch-bound batches (a 4096-drone step is
- * ~2 us of kernel behind ~4 us of launch).  Frozen arguments mean no per-launch step index, so handles
- * with FPV_FLAG_STICK_NOISE or FPV_FLAG_FP16_STATE are refused (use fpv_rollout). */
+/* Same k steps as fpv_rollout, replayed from a hipGraph cached in the handle: for small, launch-bound
+ * batches (a 4096-drone step is ~2 us of kernel behind ~4 us of launch).  The graph is rebuilt only when
+ * its SHAPE changes (k, strides, launch geometry, parameters, which optional buffers are present); new
+ * buffer addresses alone are patched into the instantiated graph.  Frozen arguments mean no per-launch
+ * step index, so handles with FPV_FLAG_STICK_NOISE or FPV_FLAG_FP16_STATE are refused (use fpv_step_n). */
 int fpv_rollout_graph(fpv_handle_t h, const fpv_buffers_t* b, int k, int64_t action_stride,
                       int64_t out_stride, void* stream);
 
@@ -219,6 +256,29 @@ int64_t fpv_recommended_ld(int64_t n);
 /* Diagnostics only: dst[i] = src[i] for n_floats fp32 values with the step kernel's access shape
  * (one dword per lane); a known-byte-count launch for calibrating rocprofv3 byte counters. */
 int fpv_diag_stream_copy(float* dst, const float* src, int64_t n_floats, void* stream);
+
+/* ---- components.PID for N drones at once (src/utils/components.py:15-54) --------------------------------
+ * The reference's guidance PID (Drone.force_multiplier_pid, components.py:145,:288): leaky clipped integral,
+ * clipped and low-passed derivative, clipped output.  One lane per drone, state as SoA rows
+ * pid_state[FPV_PID_ROWS][ld] (fp32, caller-owned).  The same lane function is the racer_pid_variant = 1 rate
+ * loop of FPV_MODE_RACER. */
+enum { FPV_PID_INTEGRAL = 0, FPV_PID_PREV_DERIVATIVE, FPV_PID_PREV_ERROR, FPV_PID_IS_FIRST, FPV_PID_ROWS };
+typedef struct fpv_pid_params {
+    uint32_t struct_size;             /* = sizeof(fpv_pid_params_t) */
+    uint32_t _reserved;
+    double kP, kI, kD, dt;            /* PID.__init__ (components.py:16-20) */
+    double integral_clip;             /* default 1   */
+    double min_output;                /* default 0.3 */
+    double max_output;                /* default 1   */
+    double derivative_transition_rate;/* default 0.5 */
+} fpv_pid_params_t;
+/* PID.reset (components.py:35-41) for the lanes whose mask byte is non-zero (mask NULL = all) */
+int fpv_pid_reset(float* pid_state, int64_t ld, int64_t n, const uint8_t* mask, int device, void* stream);
+/* PID.__call__(current, target) (components.py:43-54) per drone: out[i] = clip(kP e + kI I + kD D, min, max) with
+ * e = current[i] - target, target = target[i] or, when `target` is NULL, target_scalar.  Also writes, when given,
+ * error_out[i] (PID.error).  pid_state rows hold integral, prev_derivative, previous_error, is_first. */
+int fpv_pid_call(const fpv_pid_params_t* params, float* pid_state, int64_t ld, int64_t n, const float* current,
+                 const float* target, float target_scalar, float* out, float* error_out, int device, void* stream);
 
 const char* fpv_last_error(void);
 const char* fpv_error_name(int code);

@@ -258,6 +258,20 @@ static void matrix_to_quat_xyzw(const double M[9], double q[4])
     for (int i = 0; i < 4; ++i) q[i] /= nrm;
 }
 
+/* src/utils/components.py:43-54 (PID.__call__), np.clip(x, lo, hi) = min(max(x, lo), hi) */
+double fpvo_pid_call(const double k[8], double st[4], double current, double target)
+{
+    const double kP = k[0], kI = k[1], kD = k[2], dt = k[3], iclip = k[4], omin = k[5], omax = k[6], dtr = k[7];
+    const double error = current - target;                                                  /* :44 */
+    st[0] = clipd(0.99 * st[0] + error * dt, -iclip, iclip);                                /* :46 */
+    double derivative = clipd((1 - (st[3] != 0.0)) * (error - st[2]) / dt, -1, 1);          /* :48 */
+    derivative = (1 - dtr) * st[1] + dtr * derivative;                                      /* :49 */
+    st[1] = derivative;                                                                     /* :50 */
+    st[3] = 0.0;                                                                            /* :52 */
+    st[2] = error;                                                                          /* :53 */
+    return clipd(kP * error + kI * st[0] + kD * derivative, omin, omax);                    /* :54 */
+}
+
 /* tests/racer_drone_test.py:95-103 (Racer.step) with PID.step of :22-32 */
 void fpvo_racer_step(const fpvo_params* P, double* s, const double action[4])
 {
@@ -270,7 +284,17 @@ void fpvo_racer_step(const fpvo_params* P, double* s, const double action[4])
     double* first = s + 19;
     const double dt = P->dt;
 
+    double* dflt = s + 20;
     double torque[3];
+    if (P->racer_pid_variant == 1) {                    /* components.PID.__call__(current = omega, target = action) */
+        for (int i = 0; i < 3; ++i) {
+            const double k[8] = {P->racer_pid[i][0], P->racer_pid[i][1], P->racer_pid[i][2], dt, P->pid_integral_clip,
+                                 P->pid_min_output, P->pid_max_output, P->pid_derivative_transition_rate};
+            double st[4] = {ierr[i], dflt[i], lerr[i], *first};
+            torque[i] = fpvo_pid_call(k, st, w[i], action[i]);
+            ierr[i] = st[0]; dflt[i] = st[1]; lerr[i] = st[2];
+        }
+    } else
     for (int i = 0; i < 3; ++i) {                       /* :22-32 */
         const double err = action[i] - w[i];
         ierr[i] += err * dt;

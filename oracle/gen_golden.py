@@ -96,7 +96,12 @@ def stack(cases):
     return {k: np.stack([c[k] for c in cases]) for k in cases[0]}
 
 
+ONLY = [a for a in sys.argv[1:] if not a.startswith("-")]      # e.g. `gen_golden.py g11 g12`: write only these files
+
+
 def save(name, **arrs):
+    if ONLY and not any(name.startswith(o) for o in ONLY):
+        return
     path = os.path.join(OUT, name + ".npz")
     np.savez_compressed(path, **arrs)
     print(f"{name:28s} {os.path.getsize(path) / 1024:8.1f} KiB")
@@ -282,6 +287,83 @@ def main():
     save("g8_racer_pid_thrust", dt=1e-3, actions=a[:, None, :],
          pid=np.array([pid_full[k] for k in ("roll", "pitch", "yaw")], float),
          **stack([run_racer(a, pid_full)]))
+
+    # ---- G11: components.PID (components.py:15-54) on seeded (current, target) sequences that reach the
+    # integral clip, the 0.99 leak, the +-1 derivative clip, the derivative low-pass and both output clips ----
+    from utils.components import PID as CPID
+    rng = np.random.default_rng(11)
+    T = 600
+    tt = np.arange(T) * 1e-3
+    cur = np.stack([
+        6.0 + 4.0 * np.sin(2 * np.pi * 1.5 * tt) + 0.05 * rng.standard_normal(T),          # like dist2target around keep_distance
+        np.where(tt < 0.3, 3.0, -2.0) + 0.002 * rng.standard_normal(T),                    # step change: derivative spike, clip
+        0.3 * rng.standard_normal(T).cumsum() * 0.05,                                      # random walk
+        np.full(T, 1.0),                                                                   # constant error: integral -> clip/leak equilibrium
+    ]).astype(np.float32).astype(np.float64)
+    tgt = np.stack([np.full(T, 6.0), np.zeros(T), 0.2 * np.sin(2 * np.pi * 3 * tt), np.zeros(T)]).astype(np.float32).astype(np.float64)
+    gains = np.array([   # kP, kI, kD, dt, integral_clip, min_output, max_output, derivative_transition_rate
+        [0.1, 2.0, 0.05, 1e-3, 100.0, 1.5250993389208143, 81.30229036293663, 0.2],         # params.yaml force_multiplier_pid as Drone builds it (:143-145)
+        [0.8, 5.0, 0.3, 1e-3, 0.05, -1.0, 1.0, 0.5],                                       # tight integral clip, symmetric output clip
+        [-2.0, -0.5, -0.01, 1e-3, 1.0, -5.0, 5.0, 0.9],                                    # negative gains (a stabilising rate loop)
+        [1.0, 30.0, 0.0, 1e-2, 0.2, 0.3, 1.0, 0.5],                                        # class defaults for the clips, dt = 10 ms
+    ])
+    outs, integ, der, err = (np.zeros((4, T)) for _ in range(4))
+    for c in range(4):
+        kP, kI, kD, dt_, ic, lo, hi, dtr = gains[c]
+        pid = CPID(kP, kI, kD, dt_, integral_clip=ic, min_output=lo, max_output=hi, derivative_transition_rate=dtr)
+        pid.reset()
+        for t in range(T):
+            outs[c, t] = pid(cur[c, t], tgt[c, t])
+            integ[c, t], der[c, t], err[c, t] = pid.integral, pid.derivative, pid.error
+    save("g11_components_pid", gains=gains, current=cur, target=tgt, out=outs, integral=integ, derivative=der, error=err)
+
+    # ---- G12: Racer.step (racer_drone_test.py:95-103) with components.PID objects in its `pid` dict: the
+    # harness only adapts the call shape (`.step(actual, desired)` -> `pid(actual, desired)`); both classes
+    # run the reference's own code ----
+    class _AsRacerPid:
+        def __init__(self, pid):
+            self.pid = pid
+
+        def reset(self):
+            self.pid.reset()
+
+        def step(self, actual_value, desired_value):
+            return self.pid(actual_value, desired_value)
+
+        i_error = property(lambda self: self.pid.integral)
+
+    pid12 = np.array([[-0.004, -0.02, -1e-4], [-0.003, -0.01, -2e-4], [-0.002, -0.005, 0.0]])
+    clip12 = dict(integral_clip=0.05, min_output=-0.004, max_output=0.006, derivative_transition_rate=0.3)
+    t = np.arange(1000) * 1e-3
+    a = np.stack([3 * np.sin(2 * np.pi * t), 2 * np.cos(2 * np.pi * 0.5 * t), 0.5 * np.ones_like(t),
+                  4 + np.sin(2 * np.pi * 2 * t)], axis=1).astype(np.float32)
+
+    def run_racer_cpid(actions, stride=10):
+        T = actions.shape[0]
+        env = racer_mod.Racer(prop_size_inch=5, pid_values={"roll": [0, 0, 0], "pitch": [0, 0, 0], "yaw": [0, 0, 0]})
+        env.pid = {k: _AsRacerPid(CPID(*pid12[i], racer_mod.dt, **clip12)) for i, k in enumerate(("roll", "pitch", "yaw"))}
+        env.reset()
+        rec = {k: [] for k in ("omega", "quat_xyzw", "matrix", "position", "velocity", "i_error", "prev_derivative")}
+        snaps = sorted(set(list(range(stride, T + 1, stride)) + [T]))
+        with contextlib.redirect_stdout(io.StringIO()):
+            for t_ in range(T):
+                env.step(action=[float(x) for x in actions[t_]])
+                if t_ + 1 in snaps:
+                    rec["omega"].append(np.array(env.angular_velocity, float))
+                    rec["quat_xyzw"].append(env.orientation.as_quat())
+                    rec["matrix"].append(env.orientation.as_matrix())
+                    rec["position"].append(env.position.copy())
+                    rec["velocity"].append(env.linear_velocity.copy())
+                    rec["i_error"].append(np.array([v.pid.integral for v in env.pid.values()], float))
+                    rec["prev_derivative"].append(np.array([v.pid.prev_derivative for v in env.pid.values()], float))
+        out = {k: np.asarray(v) for k, v in rec.items()}
+        out["snap_steps"] = np.asarray(snaps)
+        out["inertia"] = np.asarray(env.I, float)
+        return out
+
+    save("g12_racer_components_pid", dt=1e-3, actions=a[:, None, :], pid=pid12,
+         clips=np.array([clip12["integral_clip"], clip12["min_output"], clip12["max_output"], clip12["derivative_transition_rate"]]),
+         **stack([run_racer_cpid(a)]))
 
     leftovers = [r for r, ds, _ in os.walk(REF) if "__pycache__" in ds]
     assert not leftovers, f"bytecode written into the reference mount: {leftovers}"

@@ -9,6 +9,7 @@
 #include <stdint.h>
 #include <string.h>
 
+#include "../fpyv_amd/csrc/fpv_addr.h"
 #include "../fpyv_amd/csrc/fpv_derive.h"
 #include "../fpyv_amd/csrc/fpv_math.h"
 
@@ -83,10 +84,15 @@ int fpvl_run(const fpv_params_t* P, int64_t n, int steps, float* st, int64_t ld,
                 s.lerr[k] = st[(FPV_R_LERR + k) * ld + i];
             }
             s.first = st[FPV_R_FIRST * ld + i];
+            for (int k = 0; k < 3; ++k) { s.wlo[k] = st[(FPV_R_OMEGA_LO + k) * ld + i]; s.ilo[k] = st[(FPV_R_IERR_LO + k) * ld + i]; s.dflt[k] = st[(FPV_R_DFILT + k) * ld + i]; }
             float r = 0;
             for (int t = 0; t < steps; ++t) {
                 const float* a = actions + ((per_step ? (int64_t)t * n : 0) + i) * 4;
-                r = fpv_racer_step_lane(K, s, a[0], a[1], a[2], a[3]);
+                if (K.r_pid_variant)
+                    r = K.r_wide ? fpv_racer_step_lane<true, 1>(K, s, a[0], a[1], a[2], a[3]) : fpv_racer_step_lane<false, 1>(K, s, a[0], a[1], a[2], a[3]);
+                else
+                    r = K.r_wide ? fpv_racer_step_lane<true, 0>(K, s, a[0], a[1], a[2], a[3]) : fpv_racer_step_lane<false, 0>(K, s, a[0], a[1], a[2], a[3]);
+                if ((K.flags & FPV_FLAG_AUTO_RESET) && !(fabsf(s.pz) <= K.ceiling)) fpv_racer_reset_lane(s);
             }
             st[FPV_PX * ld + i] = s.px; st[FPV_PY * ld + i] = s.py; st[FPV_PZ * ld + i] = s.pz;
             st[FPV_VX * ld + i] = s.vx; st[FPV_VY * ld + i] = s.vy; st[FPV_VZ * ld + i] = s.vz;
@@ -97,6 +103,8 @@ int fpvl_run(const fpv_params_t* P, int64_t n, int steps, float* st, int64_t ld,
                 st[(FPV_R_LERR + k) * ld + i] = s.lerr[k];
             }
             st[FPV_R_FIRST * ld + i] = s.first;
+            if (K.r_wide) { for (int k = 0; k < 3; ++k) { st[(FPV_R_OMEGA_LO + k) * ld + i] = s.wlo[k]; st[(FPV_R_IERR_LO + k) * ld + i] = s.ilo[k]; } }
+            if (K.r_pid_variant) { for (int k = 0; k < 3; ++k) st[(FPV_R_DFILT + k) * ld + i] = s.dflt[k]; }
             if (reward) reward[i] = r;
             if (done) done[i] = 0;
         }
@@ -106,8 +114,9 @@ int fpvl_run(const fpv_params_t* P, int64_t n, int steps, float* st, int64_t ld,
 
 }  // extern "C"
 
-// fp16-storage variant: pos [3][ld] fp32, sh [6][ld] half2 pairs (uint32); every step goes through the same
-// unpack -> step -> pack (stochastic rounding keyed by seed0 + t) as fpv_drone_step_h_kernel.
+// fp16-storage variant: pos [3][ld] fp32, sh = [5][ld] half2 pairs (uint32) followed by [ld] thrust halves;
+// every step goes through the same unpack -> step -> pack (stochastic rounding keyed by seed0 + t) as
+// fpv_drone_step_h_kernel.
 extern "C" int fpvl_run_h(const fpv_params_t* P, int64_t n, int steps, float* pos, uint32_t* sh, int64_t ld,
                           const float* actions, int per_step, const float wind[3], uint32_t seed0,
                           uint8_t* done, float* reward)
@@ -117,15 +126,17 @@ extern "C" int fpvl_run_h(const fpv_params_t* P, int64_t n, int steps, float* po
     const char* why = "";
     const int rc = fpv_derive_constants(P, &K, &big, &why);
     if (rc != FPV_OK) return rc;
+    uint16_t* thrust = reinterpret_cast<uint16_t*>(sh + FPV_HALF_PAIR_ROWS * ld);
     for (int64_t i = 0; i < n; ++i) {
         FpvStepOut o = {0, 0, 0, 0, false};
         for (int t = 0; t < steps; ++t) {
             FpvDroneState s;
             FpvHalfState h;
             s.px = pos[0 * ld + i]; s.py = pos[1 * ld + i]; s.pz = pos[2 * ld + i];
-            uint32_t w[6];
-            for (int k = 0; k < 6; ++k) w[k] = sh[k * ld + i];
+            uint32_t w[FPV_HALF_PAIR_ROWS];
+            for (int k = 0; k < FPV_HALF_PAIR_ROWS; ++k) w[k] = sh[k * ld + i];
             fpv_split_pairs(w, h);
+            h.t = thrust[i];
             fpv_unpack_half(h, s);
             const float* a = actions + ((per_step ? (int64_t)t * n : 0) + i) * 4;
             o = big ? fpv_drone_step_lane<true>(K, s, a[0], a[1], a[2], a[3], wind[0], wind[1], wind[2])
@@ -134,7 +145,8 @@ extern "C" int fpvl_run_h(const fpv_params_t* P, int64_t n, int steps, float* po
             fpv_pack_half(s, seed0 + (uint32_t)t, (uint32_t)i, h);
             pos[0 * ld + i] = s.px; pos[1 * ld + i] = s.py; pos[2 * ld + i] = s.pz;
             fpv_join_pairs(h, w);
-            for (int k = 0; k < 6; ++k) sh[k * ld + i] = w[k];
+            for (int k = 0; k < FPV_HALF_PAIR_ROWS; ++k) sh[k * ld + i] = w[k];
+            thrust[i] = h.t;
         }
         if (done) done[i] = o.done ? 1 : 0;
         if (reward) reward[i] = o.reward;
@@ -169,4 +181,25 @@ extern "C" int fpvl_stick_noise(const fpv_params_t* P, int64_t n, int steps, flo
 extern "C" void fpvl_philox(const uint32_t ctr[4], const uint32_t key[2], uint32_t out[4])
 {
     fpv_philox4x32_10(ctr[0], ctr[1], ctr[2], ctr[3], key[0], key[1], out);
+}
+
+// lane addressing (fpyv_amd/csrc/fpv_addr.h) exposed for the unit test of the 2^28-drone limit
+extern "C" uint32_t fpvl_lane_offset(uint32_t i, uint32_t elem_bytes) { return fpv_lane_offset(i, elem_bytes); }
+extern "C" int64_t fpvl_max_drones(void) { return FPV_MAX_DRONES; }
+extern "C" void fpvl_sincos_wide(double x, double* s, double* c) { fpv_sincos_wide(x, s, c); }
+
+// components.PID in the kernel's fp32 arithmetic over a sequence: k[8] = kP, kI, kD, dt, integral_clip,
+// min_output, max_output, derivative_transition_rate; st[4] = integral, prev_derivative, previous_error, is_first
+extern "C" void fpvl_pid_run(const double k[8], float st[4], int T, const float* current, const float* target, float* out)
+{
+    FpvPidK<float> P;
+    memset(&P, 0, sizeof(P));
+    P.dt = (float)k[3]; P.inv_dt = (float)(1.0 / k[3]);
+    P.gain[0][0] = (float)k[0]; P.gain[0][1] = (float)k[1]; P.gain[0][2] = (float)k[2];
+    P.integral_clip = (float)k[4]; P.min_output = (float)k[5]; P.max_output = (float)k[6];
+    P.d_rate = (float)k[7]; P.om_d_rate = (float)(1.0 - k[7]);
+    for (int t = 0; t < T; ++t) {
+        out[t] = fpv_pid_axis<float, 1>(P, 0, current[t], target[t], st[3] != 0.0f, st[0], st[2], st[1]);
+        st[3] = 0.0f;
+    }
 }

@@ -94,9 +94,9 @@ def run(p, state: np.ndarray, actions: np.ndarray, steps: Optional[int] = None, 
 
 def run_h(p, pos: np.ndarray, sh: np.ndarray, actions: np.ndarray, steps: Optional[int] = None,
           wind=(0.0, 0.0, 0.0), seed0: int = 0, n: Optional[int] = None, auto_reset: bool = False):
-    """fp16-storage variant: pos [3, ld] float32 and sh [6, ld, 2] uint16 (binary16 bits in the half2
-    pair-row layout of fpv_abi.h), advanced in place exactly like fpv_drone_step_h_kernel.
-    Returns (done [n], reward [n])."""
+    """fp16-storage variant: pos [3, ld] float32 and sh [11 * ld] uint16 (binary16 bits in the layout of
+    fpv_abi.h: five half2 pair rows, then one row of thrust halves), advanced in place exactly like
+    fpv_drone_step_h_kernel.  Returns (done [n], reward [n])."""
     L = lib()
     if not hasattr(L, "_h_ready"):
         L.fpvl_run_h.argtypes = [C.POINTER(abi.FpvParams), C.c_int64, C.c_int, C.POINTER(C.c_float),
@@ -110,7 +110,7 @@ def run_h(p, pos: np.ndarray, sh: np.ndarray, actions: np.ndarray, steps: Option
         L._h_ready = True
     assert pos.dtype == np.float32 and sh.dtype == np.uint16 and pos.flags.c_contiguous and sh.flags.c_contiguous
     ld = pos.shape[1]
-    assert sh.shape == (6, ld, 2)
+    assert sh.shape == (abi.FPV_HALF_HALVES * ld,)
     actions = np.ascontiguousarray(actions, dtype=np.float32)
     per_step = actions.ndim == 3
     n = n if n is not None else actions.shape[-2]
@@ -129,18 +129,21 @@ def run_h(p, pos: np.ndarray, sh: np.ndarray, actions: np.ndarray, steps: Option
 
 
 def split_half(state: np.ndarray):
-    """[14, ld] fp32 SoA -> (pos [3, ld] fp32, sh [6, ld, 2] uint16 pair rows) with round-to-nearest
-    halves (a freshly reset state is exactly representable, so the rounding mode does not matter)."""
+    """[14, ld] fp32 SoA -> (pos [3, ld] fp32, sh [11 * ld] uint16) with round-to-nearest halves (a freshly
+    reset state is exactly representable, so the rounding mode does not matter)."""
     ld = state.shape[1]
-    h = np.zeros((12, ld), dtype=np.float16)
-    h[:11] = state[3:14].astype(np.float16)
-    sh = np.ascontiguousarray(h.reshape(6, 2, ld).transpose(0, 2, 1)).view(np.uint16)
-    return np.ascontiguousarray(state[0:3]), sh
+    h = state[3:14].astype(np.float16)                     # value r-3 = row: vx vy vz qw qx qy qz rx ry rz thrust
+    pairs = np.ascontiguousarray(h[:10].reshape(5, 2, ld).transpose(0, 2, 1))      # [5, ld, 2]
+    sh = np.concatenate([pairs.reshape(-1), h[10]]).view(np.uint16)
+    return np.ascontiguousarray(state[0:3]), np.ascontiguousarray(sh)
 
 
 def join_half(pos: np.ndarray, sh: np.ndarray) -> np.ndarray:
-    h = sh.view(np.float16).transpose(0, 2, 1).reshape(12, -1)[:11]
-    return np.concatenate([pos, h.astype(np.float32)], axis=0)
+    """inverse of split_half: -> [14, ld] fp32"""
+    ld = pos.shape[1]
+    sh = np.asarray(sh).reshape(-1).view(np.float16)
+    pairs = sh[:10 * ld].reshape(5, ld, 2).transpose(0, 2, 1).reshape(10, ld)
+    return np.concatenate([pos, pairs.astype(np.float32), sh[10 * ld:11 * ld].astype(np.float32)[None]], axis=0)
 
 
 def stick_noise(p, n: int, steps: int, noise_seed: int = 0, drone_id_offset: int = 0, base_actions=None,
@@ -167,3 +170,19 @@ def philox(ctr, key):
     out = (C.c_uint32 * 4)()
     L.fpvl_philox((C.c_uint32 * 4)(*ctr), (C.c_uint32 * 2)(*key), out)
     return [int(x) for x in out]
+
+
+def pid_run(gains, current: np.ndarray, target: np.ndarray):
+    """components.PID in the kernel's fp32 arithmetic (fpv_pid_axis<float, 1>) over a sequence.
+    Returns (out [T] fp32, state [4] fp32 = integral, prev_derivative, previous_error, is_first)."""
+    L = lib()
+    L.fpvl_pid_run.argtypes = [C.POINTER(C.c_double), C.POINTER(C.c_float), C.c_int, C.POINTER(C.c_float),
+                               C.POINTER(C.c_float), C.POINTER(C.c_float)]
+    k = np.ascontiguousarray(gains, dtype=np.float64)
+    cur = np.ascontiguousarray(current, dtype=np.float32)
+    tgt = np.ascontiguousarray(target, dtype=np.float32)
+    st = np.array([0, 0, 0, 1], dtype=np.float32)
+    out = np.zeros(len(cur), dtype=np.float32)
+    fp = lambda a: a.ctypes.data_as(C.POINTER(C.c_float))  # noqa: E731
+    L.fpvl_pid_run(k.ctypes.data_as(C.POINTER(C.c_double)), fp(st), len(cur), fp(cur), fp(tgt), fp(out))
+    return out, st

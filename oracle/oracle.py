@@ -17,7 +17,7 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 _BUILD = os.path.join(_HERE, "_build")
 
 DRONE_STATE = 19
-RACER_STATE = 20
+RACER_STATE = 23
 
 
 class OracleObject(C.Structure):
@@ -39,6 +39,9 @@ class OracleParams(C.Structure):
         ("racer_omega_dt", C.c_int32), ("ground", C.c_int32),
         ("motor_radius", C.c_double), ("ground_spring", C.c_double), ("ground_damping", C.c_double),
         ("n_objects", C.c_int32), ("_pad2", C.c_int32), ("objects", OracleObject * 8),
+        ("racer_pid_variant", C.c_int32), ("_pad3", C.c_int32),
+        ("pid_integral_clip", C.c_double), ("pid_min_output", C.c_double), ("pid_max_output", C.c_double),
+        ("pid_derivative_transition_rate", C.c_double),
     ]
 
 
@@ -68,6 +71,8 @@ def lib() -> C.CDLL:
         L.fpvo_quat_wxyz_to_matrix.argtypes = [dp, dp]
         L.fpvo_euler_zyx_matrix.argtypes = [C.c_double, C.c_double, C.c_double, dp]
         L.fpvo_max_threads.restype = C.c_int
+        L.fpvo_pid_call.argtypes = [dp, dp, C.c_double, C.c_double]
+        L.fpvo_pid_call.restype = C.c_double
         _libs[name] = L
     return _libs[name]
 
@@ -92,6 +97,11 @@ def pack_params(p) -> OracleParams:
     o.racer_omega_dt = int(bool(p.racer_omega_dt))
     o.ground = int(bool(getattr(p, "ground", False)))
     o.motor_radius, o.ground_spring, o.ground_damping = p.motor_radius, p.ground_spring, p.ground_damping
+    o.racer_pid_variant = int(getattr(p, "racer_pid_variant", 0))
+    o.pid_integral_clip = float(getattr(p, "pid_integral_clip", 1.0))
+    o.pid_min_output = float(getattr(p, "pid_min_output", 0.3))
+    o.pid_max_output = float(getattr(p, "pid_max_output", 1.0))
+    o.pid_derivative_transition_rate = float(getattr(p, "pid_derivative_transition_rate", 0.5))
     objs = list(getattr(p, "objects", ()) or ())
     o.n_objects = len(objs)
     for k, ob in enumerate(objs):      # (type, x, y, z, radius, height)
@@ -185,6 +195,20 @@ def racer_run(p, state: np.ndarray, actions: np.ndarray, steps: Optional[int] = 
     op = pack_params(p)
     lib().fpvo_racer_step_batch(C.byref(op), n, steps, _dp(state), _dp(actions), int(per_step), threads)
     return state
+
+
+def pid_run(gains, current: np.ndarray, target: np.ndarray):
+    """components.PID over a sequence: gains = (kP, kI, kD, dt, integral_clip, min_output, max_output,
+    derivative_transition_rate).  Returns (out, integral, derivative, error) per call."""
+    k = np.asarray(gains, dtype=np.float64)
+    st = np.array([0.0, 0.0, 0.0, 1.0])
+    T = len(current)
+    out, integ, der, err = (np.zeros(T) for _ in range(4))
+    L = lib()
+    for t in range(T):
+        out[t] = L.fpvo_pid_call(_dp(k), _dp(st), float(current[t]), float(target[t]))
+        integ[t], der[t], err[t] = st[0], st[1], st[2]
+    return out, integ, der, err
 
 
 def max_threads() -> int:

@@ -36,8 +36,9 @@ def test_struct_sizes_match_the_c_side():
     h = C.c_void_p()
     rc = L.fpv_create(C.byref(p), 16, 0, C.byref(h))
     assert rc < 0 and not h.value
-    assert L.fpv_state_rows(0) == 14 and L.fpv_state_rows(1) == 20 and L.fpv_state_rows(7) == -1
-    assert L.fpv_algorithmic_bytes(0) == 133 and L.fpv_algorithmic_bytes(1) == 181
+    assert L.fpv_state_rows(0) == 14 and L.fpv_state_rows(1) == 29 and L.fpv_state_rows(7) == -1
+    assert L.fpv_state_rows(1) == _lib.FPV_RACER_ROWS
+    assert L.fpv_algorithmic_bytes(0) == 133 and L.fpv_algorithmic_bytes(1) == 181     # SURVEY 8d figures
     assert _lib.algorithmic_bytes(0) == 133 and _lib.algorithmic_bytes(1) == 181
 
 
@@ -59,6 +60,29 @@ def test_no_gpu_means_loud_failure_not_cpu_fallback():
         DroneBatch(load_params(fps=1000), 8, device="cpu")
 
 
+def test_lane_offsets_fit_32_bits_up_to_the_drone_limit():
+    """The widest lane-addressed element is the 16-byte action row: 16 * i must not wrap below the
+    per-handle limit, fpv_create must refuse anything above it (this check needs no device), and the
+    arithmetic at i = 2^28 + 1 shows why."""
+    from oracle import lane_model
+    Lm = lane_model.lib()
+    Lm.fpvl_lane_offset.restype = C.c_uint32
+    Lm.fpvl_lane_offset.argtypes = [C.c_uint32, C.c_uint32]
+    Lm.fpvl_max_drones.restype = C.c_int64
+    limit = Lm.fpvl_max_drones()
+    assert limit == 1 << 28
+    for elem in (1, 2, 4, 8, 16):
+        for i in (0, 1, 12345, limit - 1):
+            assert Lm.fpvl_lane_offset(i, elem) == i * elem                     # exact below the limit
+    assert Lm.fpvl_lane_offset(limit + 1, 16) != (limit + 1) * 16              # would wrap: hence the limit
+    assert Lm.fpvl_lane_offset(limit + 1, 16) == 16
+    L = _lib.lib()
+    p = _lib.pack_params(load_params(fps=1000))
+    h = C.c_void_p()
+    rc = L.fpv_create(C.byref(p), limit + 1, 0, C.byref(h))
+    assert rc == -1 and b"2^28" in L.fpv_last_error() and not h.value
+
+
 def test_product_never_imports_the_oracle():
     """oracle/ is test infrastructure: nothing under fpyv_amd/ or include/ may reference it."""
     bad = []
@@ -72,13 +96,27 @@ def test_product_never_imports_the_oracle():
     assert not bad, bad
 
 
-def test_components_module_mirrors_reference_names():
+def test_components_module_mirrors_reference_names_and_constructor_signatures():
+    """fpyv_amd.components takes the reference's own constructor calls (components.py:646, :686-694,
+    :754-763, :73; simulator.py:53-58): positional rendering arguments are accepted and ignored."""
+    import numpy as np
     import fpyv_amd.components as c
     from fpyv_amd.env import DroneBatch, RacerBatch
+    from fpyv_amd.objects import to_rows
     assert c.Drone is DroneBatch and c.Racer is RacerBatch
-    assert c.Ground().as_row()[0] == 0 and c.Cylinder([1, 2, 0], 0.5, 2.0).as_row() == (1, 1.0, 2.0, 0.0, 0.5, 2.0)
-    t = c.Target([0, 0, 3], 0.8, path={"radius": 2.0, "resolution": 8})
+    g = c.Ground(size=60, resolution=50, random=True)                                   # params.yaml:6-9
+    assert g.as_row()[0] == 0 and c.Ground(60, 4).as_row() == g.as_row() and c.Ground().as_row() == g.as_row()
+    cyl = c.Cylinder(np.array([1, 2, 0]), 0.5, 2.0, 10, 25, random=True)                # generators.py:33-37
+    assert cyl.as_row() == (1, 1.0, 2.0, 0.0, 0.5, 2.0) and c.Cylinder([1, 2, 0], 0.5, 2.0).as_row() == cyl.as_row()
+    t = c.Target(np.array([0, 0, 3.0]), 0.8, 5, {"radius": 2.0, "resolution": 8})       # generators.py:22-25
     t.update()
     assert t.as_row()[:4] == (2, 2.0, 0.0, 3.0)          # first path point: centre + (radius, 0, 0)
+    assert c.Target([0, 0, 3], 0.8, path={"radius": 2.0, "resolution": 8}).radius == 0.8
     with pytest.raises(AssertionError):
-        c.Cylinder([0, 0, 0], -1.0, 2.0)                  # components.py:688
+        c.Cylinder([0, 0, 0], -1.0, 2.0, 4, 2)            # components.py:688
+    # Gate and Trail entries of an object_list never collide in the reference (components.py:202): skipped
+    gate = c.Gate(np.zeros(3), np.eye(3), 5.0, shape="circle", resolution=17)
+    trail = c.Trail(10)
+    rows = to_rows([t, gate, cyl, trail, g])
+    assert [r[0] for r in rows] == [2, 1, 0]
+    assert c.PID is not None

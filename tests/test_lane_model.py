@@ -91,20 +91,68 @@ def test_auto_reset_and_ceiling(params_1k):
     assert np.all(np.abs(s[2, :n]) <= 10.5 + 0.1)
 
 
-@pytest.mark.parametrize("name,tol", [("g7_racer_main", 2e-3), ("g8_racer_pid_thrust", 2e-3)])
-def test_racer_fp32(params_1k, name, tol):
-    """Racer as written rotates by omega [rad] per STEP (quirk Q7, racer_drone_test.py:99): tens of
-    radians per step, so an fp32 ulp of omega is ~4e-6 rad of attitude per step and the 1e-5 bound
-    of the Drone path does not transfer; the tolerance here is the measured fp32 conditioning."""
-    g = load_golden(name)
-    p = params_1k.replace(mode=1, racer_pid=g["pid"])
-    acts = g["actions"]
+def _racer_trajectory_errors(p, g, rows=29):
+    """Replay a Racer golden on the lane model, comparing at EVERY snapshot (not only the last)."""
     s = lane_model.initial_state(p, 1)
-    lane_model.run(p, s, acts)
-    np.testing.assert_allclose(s[10:13, 0], g["omega"][0, -1], rtol=1e-5, atol=1e-5)
-    np.testing.assert_allclose(s[0:3, 0], g["position"][0, -1], rtol=tol, atol=tol)
-    M = oracle.quat_to_matrix(s[6:10, 0].astype(np.float64))[0]
-    assert np.abs(M - g["matrix"][0, -1]).max() < tol
+    assert s.shape[0] == rows
+    prev, worst = 0, dict(quat=0.0, pos=0.0, omega=0.0)
+    for k, t in enumerate(np.asarray(g["snap_steps"]).reshape(-1)):
+        lane_model.run(p, s, g["actions"][prev:int(t)])
+        prev = int(t)
+        q = s[6:10, 0].astype(np.float64)
+        x, y, z, w = g["quat_xyzw"][0, k]
+        qr = np.array([w, x, y, z])
+        q *= np.sign(q @ qr)
+        pr = g["position"][0, k]
+        worst["quat"] = max(worst["quat"], np.abs(q - qr).max())
+        worst["pos"] = max(worst["pos"], np.abs(s[0:3, 0] - pr).max() / max(np.abs(pr).max(), 1e-3))
+        worst["omega"] = max(worst["omega"], np.abs(s[10:13, 0].astype(np.float64) + s[20:23, 0] - g["omega"][0, k]).max())
+    return worst
+
+
+@pytest.mark.parametrize("name", ["g7_racer_main", "g8_racer_pid_thrust"])
+def test_racer_as_written_within_1e5_over_the_whole_trajectory(params_1k, name):
+    """Racer.step as written rotates by omega [rad] per STEP (quirk Q7, racer_drone_test.py:99): the rate
+    loop, omega and the attitude increment are therefore carried in float64 with fp32 (hi, lo) state rows
+    (fpv_racer_step_lane<WIDE>).  Against the reference captures G7/G8 this holds the north-star bar
+    1e-5 at every snapshot of the 1000 steps (measured 7e-7); plain fp32 held only 2e-3."""
+    g = load_golden(name)
+    worst = _racer_trajectory_errors(params_1k.replace(mode=1, racer_pid=g["pid"]), g)
+    assert worst["quat"] < REL_TOL and worst["pos"] < REL_TOL and worst["omega"] < 1e-8, worst
+
+
+def test_racer_with_components_pid_fp32_state(params_1k):
+    """racer_pid_variant = 1 (components.PID.__call__, a16) inside the as-written Racer, vs capture G12."""
+    from test_oracle_golden import _cpid_params
+    g = load_golden("g12_racer_components_pid")
+    worst = _racer_trajectory_errors(_cpid_params(params_1k, g), g)
+    assert worst["quat"] < REL_TOL and worst["pos"] < REL_TOL, worst
+
+
+def test_components_pid_fp32_arithmetic():
+    """The kernel's fp32 PID (fpv_pid_axis<float, 1>) against the reference class outputs of G11.  The
+    derivative term divides an fp32 error difference by dt = 1e-3, so an output carries up to
+    |kD| * 1e3 * ulp(error) of rounding: 2e-5 absolute covers every case of the fixture."""
+    g = load_golden("g11_components_pid")
+    for c in range(g["gains"].shape[0]):
+        out, st = lane_model.pid_run(g["gains"][c], g["current"][c], g["target"][c])
+        np.testing.assert_allclose(out, g["out"][c], rtol=1e-5, atol=2e-5)
+        np.testing.assert_allclose(st[0], g["integral"][c][-1], rtol=1e-5, atol=1e-7)
+        assert st[3] == 0.0
+
+
+def test_sincos_wide_matches_libm_to_1e15():
+    import ctypes as C
+    L = lane_model.lib()
+    L.fpvl_sincos_wide.argtypes = [C.c_double, C.POINTER(C.c_double), C.POINTER(C.c_double)]
+    rng = np.random.default_rng(0)
+    xs = np.concatenate([rng.uniform(-1e3, 1e3, 4000), rng.uniform(-1e6, 1e6, 2000), [0.0, -15.0, 40.0, 25.0, 1e-9, np.pi / 4, -np.pi / 2]])
+    s, c = C.c_double(), C.c_double()
+    worst = 0.0
+    for x in xs:
+        L.fpvl_sincos_wide(float(x), C.byref(s), C.byref(c))
+        worst = max(worst, abs(s.value - np.sin(x)), abs(c.value - np.cos(x)))
+    assert worst < 2e-15, worst
 
 
 def test_racer_omega_dt_variant_is_well_conditioned(params_1k):
@@ -147,7 +195,7 @@ FP16_TOL = dict(pos_rel=2e-2, vel_rel=4e-2, quat_abs=1.5e-2)
 
 def test_fp16_conversions_match_ieee_and_stochastic_rounding_is_unbiased():
     L = lane_model.lib()
-    lane_model.run_h(load_params_1k(), np.zeros((3, 64), np.float32), np.zeros((6, 64, 2), np.uint16),
+    lane_model.run_h(load_params_1k(), np.zeros((3, 64), np.float32), np.zeros(11 * 64, np.uint16),
                      np.zeros((1, 4), np.float32), steps=0, n=1)          # sets argtypes
     rng = np.random.default_rng(0)
     xs = rng.standard_normal(5000).astype(np.float32) * np.float32(10.0) ** rng.integers(-9, 5, 5000).astype(np.float32)

@@ -149,3 +149,48 @@ def test_object_list_collisions_match_reference(params_1k):
         assert np.abs(s[:, 0:6] - g["state"][:, t]).max() < 1e-11, t
         assert np.abs(s[:, 6:15] - g["R"][:, t].reshape(n, 9)).max() < 1e-12
     assert g["done"][1].any() and g["done"][5].any() and not g["done"][0].any()
+
+
+def _cpid_params(p, g):
+    return p.replace(mode=1, racer_pid=g["pid"], racer_pid_variant=1, pid_integral_clip=float(g["clips"][0]),
+                     pid_min_output=float(g["clips"][1]), pid_max_output=float(g["clips"][2]),
+                     pid_derivative_transition_rate=float(g["clips"][3]))
+
+
+def test_components_pid_matches_reference_class():
+    """a16: PID.__call__ (/root/reference/src/utils/components.py:43-54) on the seeded sequences of G11,
+    which reach the integral clip, the 0.99 leak, the +-1 derivative clip, the derivative low-pass
+    and both output clips (asserted here so the fixture cannot silently lose its coverage)."""
+    g = load_golden("g11_components_pid")
+    for c in range(g["gains"].shape[0]):
+        out, integ, der, err = oracle.pid_run(g["gains"][c], g["current"][c], g["target"][c])
+        for got, key in ((out, "out"), (integ, "integral"), (der, "derivative"), (err, "error")):
+            assert np.abs(got - g[key][c]).max() <= TOL * max(1.0, np.abs(g[key][c]).max()), (c, key)
+    gains = g["gains"]
+    assert (np.abs(g["integral"][1]) >= gains[1, 4] - 1e-15).any(), "integral clip not reached"
+    assert (g["out"][1] <= gains[1, 5]).any() and (g["out"][1] >= gains[1, 6]).any(), "output clips not reached"
+    raw_d = np.abs(np.diff(g["error"][1])).max() / gains[1, 3]
+    assert raw_d > 1.0, "derivative clip not exercised"
+    assert ((g["out"][2] > gains[2, 5]) & (g["out"][2] < gains[2, 6])).all(), "case 2 must stay unclipped"
+    # leak: with a constant error e the integral settles at e*dt/(1-0.99) unless clipped first
+    assert abs(g["integral"][3][-1] - min(1.0 * gains[3, 3] / 0.01, gains[3, 4])) < 1e-6
+
+
+def test_racer_with_components_pid_matches_reference():
+    """Racer.step with components.PID objects in its pid dict (both classes are the reference's own code,
+    the harness adapts the call shape): the oracle's racer_pid_variant = 1."""
+    g = load_golden("g12_racer_components_pid")
+    p = _cpid_params(load_params_1k(), g)
+    ref = oracle.racer_initial_state(1)
+    prev = 0
+    for k, t in enumerate(np.asarray(g["snap_steps"]).reshape(-1)):
+        oracle.racer_run(p, ref, g["actions"][prev:int(t)].astype(np.float64))
+        prev = int(t)
+        for sl, key in ((slice(0, 3), "position"), (slice(3, 6), "velocity"), (slice(6, 10), "quat_xyzw"),
+                        (slice(10, 13), "omega"), (slice(13, 16), "i_error"), (slice(20, 23), "prev_derivative")):
+            assert np.abs(ref[0, sl] - g[key][0, k]).max() < TOL, (k, key)
+
+
+def load_params_1k():
+    from fpyv_amd import load_params
+    return load_params(fps=1000)
