@@ -2,22 +2,27 @@
 """Headline benchmark: env-steps/s of the fused HIP stepper at 2^20 drones per GPU, dt = 1 ms.
 
     python bench.py --gpus 1 --steps 200 --warmup 20
+    python bench.py --gpus 8 ...                      # spawns its own 8 ranks (one process per GPU)
     python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 \
-        --master-port P bench.py --gpus N --steps K --warmup W
+        --master-port P bench.py --gpus N --steps K --warmup W          # or under torchrun
 
 Workload = BASELINE.json configs[2]: 1 048 576 drones per GPU, fp32, EMA-smoothed Gaussian stick
 noise (the profile of /root/reference/tests/noise_smooth_test.py:6-12) generated on the device
 BEFORE the timed region into a ring of action batches, so every timed step reads a different
-16.8 MB action batch from HBM.  A "step" is one pass of the hot path = one kernel launch through
-the C ABI (fpv_step / fpv_rollout) that advances every drone of the shard by one Drone.step.
+16.8 MB action batch from HBM.  A "step" is one pass of the hot path over the batch: with
+`--api step` (the headline) one kernel launch through the C ABI per step (fpv_step: what a closed
+policy loop pays); with `--api rollout` the k-step kernel (fpv_step_n) advances a whole ring span per
+launch with the drones held in registers (open-loop sticks: 21 + 112/k bytes per env-step).
 With N > 1 GPUs the drones are sharded contiguously (weak scaling: 2^20 per GPU) and each step's
-bit-packed done mask is all-gathered over RCCL, asynchronously and double-buffered.
+bit-packed done mask is all-gathered over RCCL, asynchronously, bucketed and double-buffered.
 
 Prints ONE JSON line on rank 0 (see the driver contract) with `roofline` and `cpu_baseline`.
 """
 import argparse
+import hashlib
 import json
 import os
+import subprocess
 import sys
 import time
 
@@ -25,13 +30,26 @@ REPO = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, REPO)
 
 HBM_PEAK_GBS = 8000.0   # MI355X HBM3E peak, /opt/skills/guides/MI355X_MICROARCH.md "HBM3E peak BW"
+VALU_PEAK_GINST = 256 * 4 * 32 * 2.4   # lane-instructions/ns: 256 CUs x 4 SIMD-32 x 2.4 GHz (same guide)
+KERNEL_SOURCES = [os.path.join(REPO, "fpyv_amd", "csrc", f) for f in ("fpv_hip.hip", "fpv_math.h", "fpv_addr.h", "fpv_derive.h")]
+
+
+def kernel_source_hash():
+    h = hashlib.sha256()
+    for p in KERNEL_SOURCES:
+        with open(p, "rb") as f:
+            h.update(f.read())
+    return h.hexdigest()[:16]
 
 
 def cpu_baseline(params, seconds_budget=12.0):
     """The float64 C oracle (a port of Drone.step; the reference itself is Python and cannot
-    travel) timed on this host: all cores via OpenMP, on a bounded sample of the same workload."""
+    travel) timed on this host: all cores via OpenMP, each thread walking its own contiguous tile of
+    drones time-outer (state stays in L1/L2), built -O3 -march=native for THIS host; on a bounded
+    sample of the same workload."""
     import numpy as np
     from oracle import oracle
+    L = oracle.lib(native=True)
     threads = oracle.max_threads()
     n, chunk = 1 << 18, 32
     x = np.random.default_rng(1234).standard_normal((chunk, n, 4))
@@ -42,27 +60,71 @@ def cpu_baseline(params, seconds_budget=12.0):
         acts[t] = s
     del x
     st = oracle.drone_initial_state(n, params.init_position, params.init_velocity, params.init_orientation_deg)
-    oracle.drone_run(params, st, acts[:2], threads=threads)          # warm-up (thread pool, page faults)
+    oracle.drone_run(params, st, acts[:2], threads=threads, native=True)          # warm-up (thread pool, page faults)
     steps_done, t0 = 0, time.perf_counter()
     while True:
-        oracle.drone_run(params, st, acts, threads=threads)
+        oracle.drone_run(params, st, acts, threads=threads, native=True)
         steps_done += acts.shape[0]
         el = time.perf_counter() - t0
         if el > seconds_budget:
             break
     all_cores = n * steps_done / el
-    st1 = oracle.drone_initial_state(n // 8, params.init_position, params.init_velocity, params.init_orientation_deg)
+    n1 = n // 16
+    st1 = oracle.drone_initial_state(n1, params.init_position, params.init_velocity, params.init_orientation_deg)
+    a1 = np.ascontiguousarray(acts[:, :n1])
+    oracle.drone_run(params, st1, a1[:2], threads=1, native=True)
     t0 = time.perf_counter()
-    oracle.drone_run(params, st1, acts[:, : n // 8].copy(), threads=1)
-    one_core = (n // 8) * acts.shape[0] / (time.perf_counter() - t0)
+    reps = 4
+    for _ in range(reps):
+        oracle.drone_run(params, st1, a1, threads=1, native=True)
+    one_core = n1 * a1.shape[0] * reps / (time.perf_counter() - t0)
+    del L
     return {"value": all_cores, "unit": "env-steps/s", "cores": threads, "kind": "port",
             "sample": f"{n} drones x {steps_done} steps of EMA-noise sticks, float64 C restatement of Drone.step "
-                      f"(oracle/fpv_oracle.c), OpenMP over drones; 1-thread rate {one_core:.3e} env-steps/s; "
-                      f"reference's own Python Drone.step, timed in the build container only (it cannot travel): 2.7e3-4.0e3 env-steps/s on one core (profiles/r01_reference_python_timing.json)",
-            "one_thread_value": one_core, "host_cpus": os.cpu_count()}
+                      f"(oracle/fpv_oracle.c, gcc -O3 -march=native -fno-tree-vectorize), OpenMP: {threads} threads each walking a contiguous "
+                      f"drone tile time-outer; 1-thread rate {one_core:.3e} env-steps/s (speed-up {all_cores / one_core:.1f}x on "
+                      f"{os.cpu_count()} logical CPUs); reference's own Python Drone.step, timed in the build container only "
+                      f"(it cannot travel): 2.7e3-4.0e3 env-steps/s on one core (profiles/r01_reference_python_timing.json)",
+            "one_thread_value": one_core, "host_cpus": os.cpu_count(), "threads_used": threads}
 
 
-def main():
+def spawn_ranks(n_ranks, argv, port=None, python=sys.executable):
+    """`bench.py --gpus N` outside torchrun: start N fresh child processes (one rank per GPU) BEFORE this
+    process touches the GPU, forward rank 0's stdout (the one JSON line), return the worst exit code.
+    Never re-execs: the parent only waits."""
+    import socket
+    if port is None:
+        with socket.socket() as s:
+            s.bind(("127.0.0.1", 0))
+            port = s.getsockname()[1]
+    procs = []
+    for r in range(n_ranks):
+        env = dict(os.environ, RANK=str(r), LOCAL_RANK=str(r), WORLD_SIZE=str(n_ranks), LOCAL_WORLD_SIZE=str(n_ranks),
+                   MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), HSA_ENABLE_IPC_MODE_LEGACY="0")
+        procs.append(subprocess.Popen([python, os.path.abspath(__file__)] + list(argv), env=env,
+                                      stdout=(None if r == 0 else subprocess.DEVNULL)))
+    rc = 0
+    for p in procs:
+        rc = max(rc, abs(p.wait()))
+    return rc
+
+
+class stdout_to_stderr:
+    """The driver reads exactly ONE JSON line on stdout; RCCL and gloo print banners there when the first
+    communicator comes up, so fd 1 points at stderr while that happens."""
+
+    def __enter__(self):
+        sys.stdout.flush()
+        self.saved = os.dup(1)
+        os.dup2(2, 1)
+
+    def __exit__(self, *exc):
+        sys.stdout.flush()
+        os.dup2(self.saved, 1)
+        os.close(self.saved)
+
+
+def parse_args(argv=None):
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=20000)
@@ -73,13 +135,18 @@ def main():
     ap.add_argument("--drones-per-gpu", type=int, default=1 << 20)
     ap.add_argument("--ring", type=int, default=32, help="distinct pre-generated action batches")
     ap.add_argument("--dpl", type=int, default=0, help="drones per lane (0 = library default)")
-    ap.add_argument("--api", choices=["rollout", "step"], default="step",
-                    help="rollout: K launches from one C call; step: one Python env.step() per launch")
+    ap.add_argument("--api", choices=["rollout", "step", "rollout-launches"], default="step",
+                    help="step (headline): one Python env.step() = one launch per step; rollout: the k-step kernel "
+                         "(fpv_step_n), one launch per ring span; rollout-launches: k single-step launches from one C call")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-beyond-mall", action="store_true",
+                    help="skip the extra short run at 2^23 drones (state 470 MB > the 256 MiB Infinity Cache)")
     ap.add_argument("--ceiling", type=float, default=100.0, help="auto-reset when |z| exceeds this (m)")
     ap.add_argument("--no-auto-reset", action="store_true")
     ap.add_argument("--fp16-state", action="store_true",
                     help="BASELINE configs[3]: v,q,rates,thrust stored as binary16 (89 B/env-step); not the headline")
+    ap.add_argument("--racer", choices=["written", "omega_dt"], default=None,
+                    help="time the Racer.step kernel instead (mode B; not the headline)")
     ap.add_argument("--no-gather", action="store_true", help="skip the done-mask all-gather (N > 1)")
     ap.add_argument("--gather-block", type=int, default=64,
                     help="steps of done masks bucketed into one all-gather (N > 1)")
@@ -88,49 +155,112 @@ def main():
                          "episode bookkeeping (+16 B per env-step), so it is off for the headline numbers")
     ap.add_argument("--force-dist", action="store_true",
                     help="rehearsal: run the RCCL process group + all-gather path even with one rank")
-    args = ap.parse_args()
+    ap.add_argument("--stub-step", action="store_true",
+                    help="TEST ONLY (tests/test_bench_spawn.py): no GPU, gloo, a no-op step - exercises the spawn, rendezvous, "
+                         "barrier, max-over-ranks and JSON plumbing; the line it prints is marked data=stub and measures nothing")
+    return ap.parse_args(argv)
 
+
+def run_stub(args, world, rank):
+    """The N-rank plumbing on CPU tensors over gloo with a no-op step (see --stub-step)."""
     import torch
     import torch.distributed as dist
-    from fpyv_amd import load_params, sticks
     from fpyv_amd.dist import DoneGather
-    from fpyv_amd.env import DroneBatch
+    if world > 1:
+        with stdout_to_stderr():                 # gloo, like RCCL, announces itself on stdout
+            dist.init_process_group(backend="gloo")
+            dist.barrier()
+    words = (args.drones_per_gpu + 63) // 64
+    gather = DoneGather((words,), torch.int64, "cpu", block=args.gather_block) if world > 1 else None
+    if world > 1:
+        dist.barrier()
+    t0 = time.perf_counter()
+    for t in range(args.steps):
+        if gather is not None:
+            gather.row(t).fill_(rank * 1000 + t)
+            gather.step_done(t)
+    if gather is not None:
+        gather.flush(args.steps - 1)
+        gather.drain()
+        dist.barrier()
+    elapsed = time.perf_counter() - t0
+    if world > 1:
+        tt = torch.tensor([elapsed], dtype=torch.float64)
+        dist.all_reduce(tt, op=dist.ReduceOp.MAX)
+        elapsed = float(tt.item())
+        last = gather.result((args.steps - 1) // args.gather_block)
+        ok = all(int(last[r, (args.steps - 1) % args.gather_block, 0]) == r * 1000 + args.steps - 1 for r in range(world))
+    else:
+        ok = True
+    if rank == 0:
+        print(json.dumps({"metric": "stub", "value": 0.0, "unit": "env-steps/s", "n_gpus": world, "steps": args.steps,
+                          "warmup": args.warmup, "data": "stub", "gather_ok": bool(ok), "ms_per_step": elapsed * 1e3 / max(args.steps, 1)}),
+              flush=True)
+    if world > 1:
+        dist.barrier()
+        dist.destroy_process_group()
+    return 0 if ok else 1
+
+
+def main(argv=None):
+    args = parse_args(argv)
+    in_rank = "WORLD_SIZE" in os.environ and "RANK" in os.environ
+    if args.gpus > 1 and not in_rank:
+        # self-launch: nothing in this process has touched the GPU yet (device_count() does not initialise it)
+        if not args.stub_step:
+            import torch
+            have = torch.cuda.device_count()
+            if have < args.gpus:
+                raise SystemExit(f"bench.py --gpus {args.gpus} needs {args.gpus} GPUs on this node, found {have}; "
+                                 f"run with --gpus {max(have, 1)} (or --force-dist to rehearse the collective path on one GPU)")
+        raise SystemExit(spawn_ranks(args.gpus, sys.argv[1:] if argv is None else argv))
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     if world != args.gpus:
-        raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}; launch with torch.distributed.run")
+        raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}")
+    if args.stub_step:
+        raise SystemExit(run_stub(args, world, rank))
+
+    import torch
+    import torch.distributed as dist
+    from fpyv_amd import load_params, sticks
+    from fpyv_amd.dist import DoneGather
+    from fpyv_amd.env import DroneBatch, RacerBatch
+
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs a GPU: the stepper has no CPU path")
+    if torch.cuda.device_count() <= local_rank:
+        raise SystemExit(f"rank {rank} needs GPU {local_rank}, this node has {torch.cuda.device_count()}")
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
     multi = world > 1 or args.force_dist
     if multi:
         if "MASTER_ADDR" not in os.environ:
             os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT="29517", RANK="0", WORLD_SIZE="1")
-        # RCCL prints a version banner on STDOUT when the first communicator comes up; the driver reads
-        # exactly one JSON line there, so route fd 1 to stderr until the communicator exists
-        sys.stdout.flush()
-        saved_fd = os.dup(1)
-        os.dup2(2, 1)
-        try:
+        with stdout_to_stderr():
             dist.init_process_group(backend="nccl", device_id=dev)
             warm = torch.zeros(1, device=dev)
             dist.all_reduce(warm)
             torch.cuda.synchronize()
-        finally:
-            sys.stdout.flush()
-            os.dup2(saved_fd, 1)
-            os.close(saved_fd)
 
     n = args.drones_per_gpu
     # dt = 1 ms; lanes that hit the ground or leave |z| <= ceiling are re-initialised in-kernel
     # (BASELINE configs[4] semantics; costs no extra bytes), so a long run stays a flight workload
     params = load_params(fps=1000, ceiling=args.ceiling)
-    env = DroneBatch(params, n, device=dev, auto_reset=not args.no_auto_reset, with_accel=False,
-                     with_done_bits=multi, fp16_state=args.fp16_state,
-                     track_episodes=bool(multi and args.gather_returns))
+
+    def make_env(n_drones, with_bits):
+        if args.racer:
+            pid = [[0.004, 0.02, 1e-6], [0.003, 0.01, 2e-6], [0.002, 0.005, 0.0]]
+            import numpy as np
+            rp = params.replace(mode=1, racer_pid=np.asarray(pid), racer_omega_dt=(args.racer == "omega_dt"), ceiling=args.ceiling)
+            return RacerBatch(rp, n_drones, device=dev, auto_reset=not args.no_auto_reset, with_done_bits=with_bits)
+        return DroneBatch(params, n_drones, device=dev, auto_reset=not args.no_auto_reset, with_accel=False,
+                          with_done_bits=with_bits, fp16_state=args.fp16_state,
+                          track_episodes=bool(multi and args.gather_returns))
+
+    env = make_env(n, multi)
     if args.dpl:
         env.set_tuning(args.dpl)
     env.reset()
@@ -141,33 +271,45 @@ def main():
     actions = sticks.ema_noise_device(ring, n, dev, seed=1234 + rank)
 
     gather = None
+    words = (n + 63) // 64
     if multi and not args.no_gather:
-        gather = DoneGather((env.done_bits.numel(),), torch.int64, dev, block=args.gather_block)
+        gather = DoneGather((words,), torch.int64, dev, block=args.gather_block)
     returns_all, returns_work = None, None
     if gather is not None and args.gather_returns:
         returns_all = torch.zeros(dist.get_world_size() * n, dtype=torch.float32, device=dev)
 
-    def run(k, t_base):
-        """k steps = k launches.  Without the gather: whole ring spans go through fpv_rollout."""
-        if gather is None and args.api == "rollout":
-            t = t_base
-            while t < t_base + k:
-                r0 = t % ring
-                span = min(ring - r0, t_base + k - t)
-                env.rollout(actions[r0:r0 + span])
-                t += span
-        else:
+    launches = [0]
+
+    def run_on(e, acts, k, t_base, g):
+        """k steps.  api=step: k launches; api=rollout: one k-step-kernel launch per ring span (and per gather bucket)."""
+        nonlocal returns_work
+        rlen = acts.shape[0]
+        if args.api == "step":
             for t in range(t_base, t_base + k):
-                if gather is not None:
-                    env._buf.done_bits = gather.row_ptr(t)
-                env.step(actions[t % ring], return_imu=False)
-                if gather is not None:
-                    gather.step_done(t)
+                if g is not None:
+                    e.set_done_bits_target(g.row_ptr(t))
+                e.step(acts[t % rlen], return_imu=False)
+                launches[0] += 1
+                if g is not None:
+                    g.step_done(t)
                     if returns_all is not None and (t + 1) % args.gather_block == 0:
-                        nonlocal returns_work
                         if returns_work is not None:
                             returns_work.wait()
-                        returns_work = dist.all_gather_into_tensor(returns_all, env.last_return, async_op=True)
+                        returns_work = dist.all_gather_into_tensor(returns_all, e.last_return, async_op=True)
+            return
+        fused = args.api == "rollout"
+        t = t_base
+        while t < t_base + k:
+            r0 = t % rlen
+            span = min(rlen - r0, t_base + k - t)
+            if g is not None:                       # a span never crosses a gather bucket: the bucket rows are the mask rows
+                span = min(span, g.block - t % g.block)
+                e.set_done_bits_target(g.row_ptr(t), stride_words=words)
+            e.rollout(acts[r0:r0 + span], fused=fused)
+            launches[0] += 1 if fused else span
+            t += span
+            if g is not None and t % g.block == 0:
+                g.step_done(t - 1)
 
     def fence():
         torch.cuda.synchronize()
@@ -176,19 +318,20 @@ def main():
             torch.cuda.synchronize()
 
     if args.preheat_s > 0:
-        scratch = DroneBatch(params, n, device=dev, with_accel=False, fp16_state=args.fp16_state)
+        scratch = make_env(n, False)
         scratch.reset()
         t_end = time.perf_counter() + args.preheat_s
         while time.perf_counter() < t_end:
-            scratch.rollout(actions)
+            scratch.rollout(actions, fused=False)
             torch.cuda.synchronize()
         del scratch
-    run(args.warmup, 0)
+    run_on(env, actions, args.warmup, 0, gather)
     fence()
+    launches[0] = 0
     ev0, ev1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
     t0 = time.perf_counter()
     ev0.record()                      # torch's current stream == the stream the kernels are launched on
-    run(args.steps, args.warmup)
+    run_on(env, actions, args.steps, args.warmup, gather)
     ev1.record()
     if gather is not None:
         gather.flush(args.warmup + args.steps - 1)
@@ -198,6 +341,7 @@ def main():
     fence()
     elapsed = time.perf_counter() - t0
     dev_ms = ev0.elapsed_time(ev1)
+    n_launches = launches[0]
 
     if multi:
         t = torch.tensor([elapsed], dtype=torch.float64, device=dev)
@@ -206,15 +350,52 @@ def main():
 
     assert bool(torch.isfinite(env.state).all()), "non-finite state after the benchmark"
 
+    # the same kernel with its state far outside the 256 MiB Infinity Cache (2^23 drones: 470 MB of state):
+    # what a GPU-filling population sees; the 2^20-drone state (59 MB) lives in that cache between steps
+    beyond = None
+    if rank == 0 and world == 1 and not args.no_beyond_mall and args.api == "step":
+        nb = 1 << 23
+        big = make_env(nb, False)
+        big.reset()
+        acts_b = sticks.ema_noise_device(4, nb, dev, seed=99)
+        run_on(big, acts_b, 20, 0, None)
+        torch.cuda.synchronize()
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        kb = 300
+        e0.record()
+        run_on(big, acts_b, kb, 20, None)
+        e1.record()
+        torch.cuda.synchronize()
+        us = e0.elapsed_time(e1) * 1e3 / kb
+        gbs = big.algorithmic_bytes() * nb / (us * 1e-6) / 1e9
+        beyond = {"drones": nb, "state_MB": round(big.state.numel() * 4 / 1e6 + (big.state_h.numel() * 2 / 1e6 if big.state_h is not None else 0)),
+                  "avg_launch_us": us, "achieved": gbs, "frac": gbs / HBM_PEAK_GBS, "env_steps_per_s": nb / (us * 1e-6)}
+        del big, acts_b
+
     if rank == 0:
-        bytes_per_step = env.algorithmic_bytes()                             # 133 B fp32 / 89 B fp16 state
-        kernel_s = dev_ms * 1e-3 / args.steps                                # avg launch-to-launch on the stream
-        achieved = bytes_per_step * n / kernel_s / 1e9
+        state_bytes = env.algorithmic_bytes()                                # 133 B fp32 / 89 B fp16 state
+        kernel_s = dev_ms * 1e-3 / n_launches                                # avg launch-to-launch on the stream
+        steps_per_launch = args.steps / n_launches
+        if args.api == "rollout":
+            # k-step kernel: the state (and nothing else) is amortised over the k steps of a launch
+            io = 16 + 0                                                      # action read; reward/done only after the last step
+            rw_state = state_bytes - 21
+            bytes_per_step = io + (rw_state + 5) / steps_per_launch
+        else:
+            bytes_per_step = state_bytes
+        achieved = bytes_per_step * n * steps_per_launch / kernel_s / 1e9
         traffic, traffic_src = None, None
         tp = os.path.join(REPO, "profiles", "pmc_traffic.json")
-        if os.path.isfile(tp) and not args.fp16_state:
+        if os.path.isfile(tp) and not args.fp16_state and not args.racer and args.api == "step" and n == (1 << 20):
             tj = json.load(open(tp))
-            traffic, traffic_src = tj.get("hbm_bytes_per_launch"), tj.get("source")
+            if tj.get("kernel_source_sha256_16") == kernel_source_hash():
+                traffic, traffic_src = tj.get("hbm_bytes_per_launch"), tj.get("source")
+            else:
+                traffic_src = "stale: profiles/pmc_traffic.json was measured on different kernel sources (re-run tools/pmc_probe.py)"
+        kernel = ("fpv_racer_step_kernel" if args.racer else "fpv_drone_step_h_kernel" if args.fp16_state else "fpv_drone_step_kernel")
+        if args.api == "rollout":
+            kernel = kernel.replace("_step_", "_rollout_")
+        cfg_name = ("Racer.step (" + args.racer + "), " if args.racer else "configs[3]: fp16 state / fp32 integrator, " if args.fp16_state else "configs[2]: ")
         out = {
             "metric": "env-steps/sec at N=1.05M drones, dt=1ms; 1/2/4/8 GPU + CPU ref",
             "value": n * world * args.steps / elapsed,
@@ -224,19 +405,30 @@ def main():
             "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
             "dtype": "f32", "data": "synthetic",
             "state_storage": "f16(v,q,rates,thrust)+f32(p)" if args.fp16_state else "f32",
-            "config": {"workload": ("configs[3]: fp16 state / fp32 integrator, " if args.fp16_state else "configs[2]: ")
-                       + "1.05M drones/GPU, EMA-noise sticks (noise_smooth_test profile), fp32 math, dt=1ms, "
+            "config": {"workload": cfg_name
+                       + f"{n} drones/GPU, EMA-noise sticks (noise_smooth_test profile), fp32 math, dt=1ms, "
                        + ("no auto-reset" if args.no_auto_reset else f"in-kernel auto-reset on ground contact or |z|>{args.ceiling:g} m"),
                        "drones_per_gpu": n, "global_drones": n * world, "action_ring": ring, "api": args.api,
+                       "steps_per_launch": steps_per_launch,
                        "parallelism": f"shard{world}" + ("+allgather(done_bits x" + str(args.gather_block) + " steps"
                                                               + (", last_return" if args.gather_returns else "") + ")" if gather is not None else ""),
                        "drones_per_lane": args.dpl or "default"},
             "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": achieved / HBM_PEAK_GBS, "traffic": traffic, "traffic_source": traffic_src,
-                         "kernel": "fpv_drone_step_h_kernel" if args.fp16_state else "fpv_drone_step_kernel", "algorithmic_bytes_per_env_step": bytes_per_step,
+                         "kernel": kernel, "algorithmic_bytes_per_env_step": bytes_per_step,
                          "avg_launch_us": kernel_s * 1e6,
+                         "cache_note": "at 2^20 drones the 59 MB state is re-read from the 256 MiB Infinity Cache (MALL) every step; "
+                                       "only the action stream and reward/done cross HBM - `beyond_mall` is the same kernel at 2^23 drones",
+                         "frac_beyond_mall": beyond["frac"] if beyond else None, "beyond_mall": beyond,
                          "note": "avg = HIP-event time over the timed region / launches (includes inter-launch gaps)"},
         }
+        if args.api == "rollout":
+            # the k-step kernel is bound by the fp32 vector ALUs, not HBM: ~400 VALU instructions per env-step
+            inst = 400.0
+            out["roofline"]["valu"] = {"assumed_valu_inst_per_env_step": inst,
+                                       "achieved_Glane_inst_per_s": inst * n * steps_per_launch / kernel_s / 1e9,
+                                       "peak_Glane_inst_per_s": VALU_PEAK_GINST,
+                                       "frac": inst * n * steps_per_launch / kernel_s / 1e9 / VALU_PEAK_GINST}
         if not args.no_cpu_baseline and world == 1:
             out["cpu_baseline"] = cpu_baseline(params)
         print(json.dumps(out), flush=True)

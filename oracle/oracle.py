@@ -55,11 +55,15 @@ def build(force: bool = False) -> None:
 _libs = {}
 
 
-def lib() -> C.CDLL:
-    """Portable x86-64 build (gcc -O2, no -march: it must run on whatever CPU the GPU box has)."""
-    name = "libfpv_oracle.so"
+def lib(native: bool = False) -> C.CDLL:
+    """Portable x86-64 build (gcc -O2, no -march: it must run on whatever CPU the GPU box has), or - for
+    bench.py's cpu_baseline leg only - the same source built -O3 -march=native on the host that runs it."""
+    name = "libfpv_oracle_native.so" if native else "libfpv_oracle.so"
     if name not in _libs:
-        build()
+        if native:
+            subprocess.run(["make", "-C", _HERE, "-B", "native"], check=True, stdout=subprocess.DEVNULL)
+        else:
+            build()
         L = C.CDLL(os.path.join(_BUILD, name))
         dp, u8p = C.POINTER(C.c_double), C.POINTER(C.c_uint8)
         L.fpvo_drone_step_batch.argtypes = [C.POINTER(OracleParams), C.c_int64, C.c_int, dp, dp, C.c_int,
@@ -154,7 +158,7 @@ def drone_initial_state(n: int, position, velocity, ypr_deg) -> np.ndarray:
 
 
 def drone_run(p, state: np.ndarray, actions: np.ndarray, steps: Optional[int] = None,
-              wind=(0.0, 0.0, 0.0), threads: int = 1
+              wind=(0.0, 0.0, 0.0), threads: int = 1, native: bool = False
               ) -> Tuple[np.ndarray, np.ndarray, np.ndarray]:
     """Advance `state` [n,19] in place.  actions: [steps,n,4] (one batch per step) or [n,4]
     (held for `steps` steps).  Returns (state, accel [n,3], done [n]) after the last step."""
@@ -171,7 +175,7 @@ def drone_run(p, state: np.ndarray, actions: np.ndarray, steps: Optional[int] = 
     done = np.zeros(n, dtype=np.uint8)
     w = np.asarray(wind, dtype=np.float64)
     op = pack_params(p)
-    lib().fpvo_drone_step_batch(C.byref(op), n, steps, _dp(state), _dp(actions), int(per_step), _dp(w),
+    lib(native).fpvo_drone_step_batch(C.byref(op), n, steps, _dp(state), _dp(actions), int(per_step), _dp(w),
                                     _dp(accel), done.ctypes.data_as(C.POINTER(C.c_uint8)), threads)
     return state, accel, done
 

@@ -12,7 +12,8 @@ from fpyv_amd import _lib, load_params, sticks
 from oracle import lane_model, oracle
 from parity import REL_TOL, assert_parity, soa_vs_oracle
 
-pytestmark = pytest.mark.gpu
+pytestmark = [pytest.mark.gpu,
+              pytest.mark.skipif(not torch.cuda.is_available(), reason="needs a GPU: the stepper has no CPU path")]
 DEV = "cuda:0"
 
 
@@ -270,20 +271,84 @@ def test_broadcast_action_and_numpy_action(params_1k):
     assert torch.equal(env.state, env2.state)
 
 
-@pytest.mark.parametrize("name,tol", [("g7_racer_main", 2e-3), ("g8_racer_pid_thrust", 2e-3)])
-def test_racer_vs_reference_capture(params_1k, name, tol):
+def _racer_replay(p, g):
+    """Replay a Racer golden through RacerBatch, comparing at every snapshot; returns the worst errors."""
     from fpyv_amd.env import RacerBatch
-    g = load_golden(name)
-    p = params_1k.replace(mode=1, racer_pid=g["pid"])
     env = RacerBatch(p, 1, device=DEV)
     env.reset()
-    env.rollout(torch.from_numpy(g["actions"]).to(DEV))
-    torch.cuda.synchronize()
+    acts = torch.from_numpy(g["actions"]).to(DEV)
+    prev, worst = 0, dict(quat=0.0, pos=0.0, omega=0.0)
+    for k, t in enumerate(np.asarray(g["snap_steps"]).reshape(-1)):
+        env.rollout(acts[prev:int(t)].contiguous())
+        prev = int(t)
+        s = env.state.cpu().numpy()
+        q = s[6:10, 0].astype(np.float64)
+        x, y, z, w = g["quat_xyzw"][0, k]
+        qr = np.array([w, x, y, z])
+        q *= np.sign(q @ qr)
+        pr = g["position"][0, k]
+        worst["quat"] = max(worst["quat"], np.abs(q - qr).max())
+        worst["pos"] = max(worst["pos"], np.abs(s[0:3, 0] - pr).max() / max(np.abs(pr).max(), 1e-3))
+        worst["omega"] = max(worst["omega"], np.abs(s[10:13, 0].astype(np.float64) + s[20:23, 0] - g["omega"][0, k]).max())
+    return env, worst
+
+
+@pytest.mark.parametrize("name", ["g7_racer_main", "g8_racer_pid_thrust"])
+def test_racer_vs_reference_capture(params_1k, name):
+    """Racer.step AS WRITTEN (omega radians per step) against the reference captures at the north-star bar,
+    1e-5 on position and quaternion, at every snapshot of the 1000 steps: the rate loop and the attitude
+    increment run in float64 with (hi, lo) state rows (229 B per env-step)."""
+    g = load_golden(name)
+    p = params_1k.replace(mode=1, racer_pid=g["pid"])
+    env, worst = _racer_replay(p, g)
+    assert env.algorithmic_bytes() == 229 and env.state.shape[0] == 29
+    assert worst["quat"] < REL_TOL and worst["pos"] < REL_TOL and worst["omega"] < 1e-8, worst
+    model = lane_model.initial_state(p, 1)
+    lane_model.run(p, model, g["actions"])
+    assert np.array_equal(env.state.cpu().numpy()[:, :1].view(np.uint32), model[:, :1].view(np.uint32)), \
+        "kernel != lane model (bitwise; the float64 rate loop is library-free: same fma sequence on both sides)"
+
+
+def test_racer_with_components_pid_vs_reference_capture(params_1k):
+    """a16 as the Racer's rate loop (racer_pid_variant = 1) against capture G12."""
+    from test_oracle_golden import _cpid_params
+    g = load_golden("g12_racer_components_pid")
+    p = _cpid_params(params_1k, g)
+    env, worst = _racer_replay(p, g)
+    assert env.algorithmic_bytes() == 229 + 24
+    assert worst["quat"] < REL_TOL and worst["pos"] < REL_TOL, worst
     s = env.state.cpu().numpy()
-    np.testing.assert_allclose(s[10:13, 0], g["omega"][0, -1], rtol=1e-5, atol=1e-5)
-    np.testing.assert_allclose(s[0:3, 0], g["position"][0, -1], rtol=tol, atol=tol)
-    M = oracle.quat_to_matrix(s[6:10, 0].astype(np.float64))[0]
-    assert np.abs(M - g["matrix"][0, -1]).max() < tol      # tolerance: see tests/test_lane_model.py::test_racer_fp32
+    np.testing.assert_allclose(s[26:29, 0], g["prev_derivative"][0, -1], rtol=1e-5, atol=1e-7)
+    np.testing.assert_allclose(s[13:16, 0].astype(np.float64) + s[23:26, 0], g["i_error"][0, -1], rtol=1e-6, atol=1e-9)
+
+
+def test_components_pid_kernel_vs_reference_class():
+    """a16 standalone: fpyv_amd.components.PID (N controllers per launch) against the reference class's
+    outputs on the seeded sequences of G11, all four gain sets side by side in one batch of 4 x 64
+    controllers; bitwise against the host build of the same fp32 arithmetic."""
+    from fpyv_amd.components import PID
+    g = load_golden("g11_components_pid")
+    T = g["current"].shape[1]
+    for c in range(g["gains"].shape[0]):
+        kP, kI, kD, dt, ic, lo, hi, dtr = g["gains"][c]
+        pid = PID(kP, kI, kD, dt, integral_clip=ic, min_output=lo, max_output=hi, derivative_transition_rate=dtr,
+                  num_envs=64, device=DEV)
+        cur = torch.from_numpy(g["current"][c]).float().to(DEV)
+        tgt = torch.from_numpy(g["target"][c]).float().to(DEV)
+        outs = torch.zeros((T, 64), device=DEV)
+        for t in range(T):
+            outs[t] = pid(cur[t].expand(64), tgt[t].expand(64) if c % 2 else float(tgt[t]))
+        torch.cuda.synchronize()
+        o = outs.cpu().numpy()
+        assert np.all(o == o[:, :1]), "every lane runs the same controller"
+        np.testing.assert_allclose(o[:, 0], g["out"][c], rtol=1e-5, atol=2e-5)
+        np.testing.assert_allclose(pid.integral.cpu().numpy(), g["integral"][c][-1], rtol=1e-5, atol=1e-7)
+        np.testing.assert_allclose(pid.error.cpu().numpy(), g["error"][c][-1], rtol=1e-6, atol=1e-7)
+        want, st = lane_model.pid_run(g["gains"][c], g["current"][c], g["target"][c])
+        assert np.array_equal(o[:, 0].view(np.uint32), want.view(np.uint32)), "kernel != lane model (bitwise)"
+        pid.reset(mask=torch.arange(64, device=DEV) % 2 == 0)
+        torch.cuda.synchronize()
+        assert float(pid.integral[0]) == 0.0 and float(pid.state[3, 0]) == 1.0 and float(pid.state[3, 1]) == 0.0
 
 
 def test_racer_omega_dt_batch_vs_oracle(params_1k):
@@ -399,17 +464,20 @@ def test_fp16_state_bitwise_vs_lane_model_and_restated_tolerance(params_1k):
     acts = g["actions"]
     T, n = acts.shape[:2]
     env = _drone_batch(params_1k, n, fp16_state=True, rounding_seed=5, with_accel=False)
-    assert env.algorithmic_bytes() == 93 and env.state.shape[0] == 3 and env.state_h.dtype == torch.float16
+    assert env.algorithmic_bytes() == 89 and env.state.shape[0] == 3 and env.state_h.dtype == torch.float16
     env.reset()
     env.rollout(torch.from_numpy(acts).to(DEV))
     torch.cuda.synchronize()
     pos, sh = lane_model.split_half(lane_model.initial_state(params_1k, n))
     lane_model.run_h(params_1k, pos, sh, acts, seed0=5)
     assert np.array_equal(env.state.cpu().numpy()[:, :n].view(np.uint32), pos[:, :n].view(np.uint32))
-    assert np.array_equal(env.state_h.cpu().numpy()[:, :n].view(np.uint16), sh[:, :n])     # [6, n, 2] pair rows
+    ld = env.ld
+    got_h, want_h = env.state_h.cpu().numpy().view(np.uint16), sh
+    assert np.array_equal(got_h[:10 * ld].reshape(5, ld, 2)[:, :n], want_h[:10 * ld].reshape(5, ld, 2)[:, :n])   # pair rows
+    assert np.array_equal(got_h[10 * ld:10 * ld + n], want_h[10 * ld:10 * ld + n])                              # thrust halves
     ref = oracle.drone_initial_state(n, params_1k.init_position, params_1k.init_velocity, [0, 0, 0])
     oracle.drone_run(params_1k, ref, acts.astype(np.float64))
-    got = lane_model.join_half(env.state.cpu().numpy(), env.state_h.cpu().numpy().view(np.uint16))
+    got = lane_model.join_half(env.state.cpu().numpy(), got_h)
     err = soa_vs_oracle(got, ref, n)
     for k, tol in FP16_TOL.items():
         assert err[k] <= tol, (k, err[k])
@@ -516,7 +584,7 @@ def test_config5_shard_invariance_8M(params_1k):
     whole.reset()
     whole.rollout(None, steps=steps)
     torch.cuda.synchronize()
-    assert int(whole.done_u8.sum()) >= 0
+    assert int(whole.done_u8.sum()) > 0, "the scenario must end episodes in the last step too"
     g_state, g_done, g_bits = whole.state[:, :n_total].clone(), whole.done_u8.clone(), whole.done_bits.clone()
     any_reset = bool((g_state[13] == 0).any())               # freshly reset lanes have prev_thrust == 0
     del whole
@@ -761,3 +829,244 @@ def test_soa_action_layout_equals_row_layout(params_1k):
         e2.step(torch.tanh(W @ obs_soa), return_imu=False)
     torch.cuda.synchronize()
     assert bool(torch.isfinite(e2.state).all())
+
+
+# ---- fpv_step_n: k steps in ONE launch, bit-identical to k single steps ---------------------------------
+def _clone_batch_state(dst, src):
+    for name in ("state", "state_h", "noise_state", "pos_comp", "ep_return", "ep_length", "last_return", "last_length"):
+        a, b = getattr(dst, name, None), getattr(src, name, None)
+        if a is not None:
+            a.copy_(b)
+
+
+def test_step_n_fuzz_bitwise_equal_to_single_steps(params_1k):
+    """The fused k-step kernel against k launches of the single-step kernel, over auto-reset, in-kernel
+    noise (with and without a base action), ground flag | object list, Kahan rows, held vs per-step
+    actions, per-step vs last-step outputs, per-step done-bit rows, episode bookkeeping and ragged n:
+    every buffer must come out bit for bit the same."""
+    from fpyv_amd.env import DroneBatch
+    rng = np.random.default_rng(77)
+    objs = ((2, 0.3, -0.2, 0.9, 0.35, 0.0), (1, 1.2, 0.4, 0.0, 0.5, 1.1), (0, 0, 0, 0, 0, 0))
+    base = params_1k.replace(init_position=np.array([0.0, 0.0, 0.55]), ceiling=1.6, noise_gain=0.7)
+    for case in range(32):
+        auto, kahan, noise, track = bool(case & 1), bool(case & 2), bool(case & 4), bool(case & 8)
+        world = ("none", "flag", "list")[case % 3]
+        held = (case % 5) == 0
+        per_step_out = (case % 4) != 3
+        n = int(rng.integers(1, 900))
+        k = int(rng.integers(1, 48))
+        p = base.replace(ground=(world == "flag"))
+        kw = dict(auto_reset=auto, kahan_position=kahan, stick_noise=noise, noise_seed=case, with_done_bits=True,
+                  track_episodes=track, with_action_out=noise, drone_id_offset=1000 * case)
+        a, b = _drone_batch(p, n, **kw), _drone_batch(p, n, **kw)
+        pos = np.concatenate([rng.uniform(-0.5, 0.5, (n, 2)), rng.uniform(0.3, 1.2, (n, 1))], axis=1).astype(np.float32)
+        a.reset(position=pos, velocity=[0.5, 0, 0])
+        _clone_batch_state(b, a)
+        acts = rng.uniform(-1, 1, (1 if held else k, n, 4)).astype(np.float32)
+        acts[..., 3] = rng.uniform(-1, -0.3, acts.shape[:2])
+        act_t = torch.from_numpy(acts).to(DEV)
+        no_action = noise and (case % 7) == 4
+        words = (n + 63) // 64
+        ra, rb = torch.zeros((k, n), device=DEV), torch.zeros((k, n), device=DEV)
+        da, db = (torch.zeros((k, n), dtype=torch.uint8, device=DEV) for _ in range(2))
+        ba, bb = (torch.zeros((k, words), dtype=torch.int64, device=DEV) for _ in range(2))
+        wind = (0.3, -0.2, 0.1)
+        a._set_objects(objs if world == "list" else ())
+        b._set_objects(objs if world == "list" else ())
+        a.set_done_bits_target(ba, stride_words=words)
+        b.set_done_bits_target(bb, stride_words=words)
+        arg = None if no_action else (act_t[0].contiguous() if held else act_t)
+        out = dict(rewards=ra, dones=da) if per_step_out else {}
+        out_b = dict(rewards=rb, dones=db) if per_step_out else {}
+        a.rollout(arg, wind=wind, steps=k, fused=False, **out)
+        b.rollout(arg, wind=wind, steps=k, fused=True, **out_b)
+        torch.cuda.synchronize()
+        tag = f"case {case}: auto={auto} kahan={kahan} noise={noise} track={track} world={world} held={held} n={n} k={k}"
+        for name in ("state", "reward", "done_u8", "accel", "noise_state", "pos_comp", "action_out", "ep_return",
+                     "ep_length", "last_return", "last_length"):
+            x, y = getattr(a, name, None), getattr(b, name, None)
+            if x is not None:
+                assert torch.equal(x, y), f"{tag}: {name}"
+        assert torch.equal(ra, rb) and torch.equal(da, db) and torch.equal(ba, bb), tag
+        assert a.state_dict()["step_counter"] == b.state_dict()["step_counter"] == k
+        if per_step_out and auto:
+            unpacked = ((bb.cpu().numpy().view(np.uint64)[:, :, None] >> np.arange(64, dtype=np.uint64)) & np.uint64(1))
+            assert np.array_equal(unpacked.reshape(k, -1)[:, :n].astype(np.uint8), db.cpu().numpy()), tag
+
+
+@pytest.mark.parametrize("kind", ["fp16", "racer", "racer_written", "racer_cpid"])
+def test_step_n_other_modes_bitwise(params_1k, kind):
+    """fp16 storage (the state takes its binary16 round trip in registers every step) and the Racer variants."""
+    from fpyv_amd.env import DroneBatch, RacerBatch
+    rng = np.random.default_rng(5)
+    for n, k in ((1, 7), (333, 40), (4096 + 3, 25)):
+        if kind == "fp16":
+            p = params_1k.replace(ceiling=10.4)
+            mk = lambda: DroneBatch(p, n, device=DEV, fp16_state=True, rounding_seed=9, auto_reset=True, with_done_bits=True)   # noqa: E731
+            acts = torch.from_numpy(sticks.ema_noise(k, range(n), seed=3)).to(DEV)
+        else:
+            pid = np.array([[0.004, 0.02, 1e-6], [0.003, 0.01, 2e-6], [0.002, 0.005, 0]])
+            p = params_1k.replace(mode=1, racer_pid=pid, racer_omega_dt=(kind == "racer"), ceiling=5e-4)
+            if kind == "racer_cpid":
+                p = p.replace(racer_pid=-pid, racer_pid_variant=1, pid_integral_clip=0.05, pid_min_output=-0.004,
+                              pid_max_output=0.006, pid_derivative_transition_rate=0.3)
+            mk = lambda: RacerBatch(p, n, device=DEV, auto_reset=True, with_done_bits=True, track_episodes=True)   # noqa: E731
+            acts = torch.from_numpy(np.concatenate([rng.uniform(-6, 6, (k, n, 3)), rng.uniform(0, 8, (k, n, 1))], axis=2).astype(np.float32)).to(DEV)
+        a, b = mk(), mk()
+        a.reset(); b.reset()
+        ra, rb = torch.zeros((k, n), device=DEV), torch.zeros((k, n), device=DEV)
+        a.rollout(acts, rewards=ra, fused=False)
+        b.rollout(acts, rewards=rb, fused=True)
+        a.rollout(acts[: k // 2 + 1], fused=False)          # a second call continues the step counter / rounding seeds
+        b.rollout(acts[: k // 2 + 1], fused=True)
+        torch.cuda.synchronize()
+        assert torch.equal(a.state, b.state) and torch.equal(ra, rb), (kind, n, k)
+        assert torch.equal(a.done_u8, b.done_u8) and torch.equal(a.done_bits, b.done_bits) and torch.equal(a.reward, b.reward)
+        if kind == "fp16":
+            assert torch.equal(a.state_h.view(torch.int16), b.state_h.view(torch.int16))
+        else:
+            assert torch.equal(a.ep_length, b.ep_length) and torch.equal(a.last_return, b.last_return)
+            if n > 1 and k >= 25:
+                assert bool((a.last_length > 0).any()), "the ceiling must end some episodes"
+
+
+def test_config2_full_size_1000_steps_fused_noise_vs_oracle(params_1k):
+    """BASELINE configs[2] at its full size and length: 2^20 drones x 1000 steps of in-kernel EMA-noise
+    sticks.  The applied sticks of 4096 sampled drones (block / wave edges + random) are captured from
+    `action_out` every step, replayed through the float64 oracle, and must agree to 1e-5; the fused
+    k-step kernel must then reproduce the 1000 single launches bit for bit on all 2^20 drones."""
+    from fpyv_amd.env import DroneBatch
+    n, T = 1 << 20, 1000
+    kw = dict(device=DEV, stick_noise=True, noise_seed=4242, with_accel=False, with_action_out=True)
+    env = DroneBatch(params_1k, n, **kw)
+    env.reset()
+    idx = np.unique(np.concatenate([np.arange(0, 192), np.arange(n - 192, n), np.arange(65536 - 64, 65536 + 64),
+                                    np.random.default_rng(1).integers(0, n, 3700)]))[:4096]
+    assert len(idx) == 4096
+    idx_t = torch.from_numpy(idx).to(DEV)
+    acts = torch.zeros((T, len(idx), 4), device=DEV)
+    for t in range(T):
+        env.step(None, return_imu=False)
+        acts[t] = env.action_out[idx_t]
+    torch.cuda.synchronize()
+    assert 0.05 < float(acts.std()) < 0.5                       # the stationary EMA profile (sigma = 0.229 per channel)
+    got = env.state[:, idx_t].cpu().numpy()
+    ref = oracle.drone_initial_state(len(idx), params_1k.init_position, params_1k.init_velocity, [0, 0, 0])
+    oracle.drone_run(params_1k, ref, acts.cpu().numpy().astype(np.float64), threads=0)
+    assert_parity(soa_vs_oracle(np.ascontiguousarray(got), ref, len(idx)), REL_TOL, "configs[2] full size, 1000 steps")
+    fused = DroneBatch(params_1k, n, **kw)
+    fused.reset()
+    fused.rollout(None, steps=T)
+    torch.cuda.synchronize()
+    assert torch.equal(fused.state, env.state) and torch.equal(fused.noise_state, env.noise_state)
+    assert torch.equal(fused.action_out, env.action_out) and torch.equal(fused.reward, env.reward)
+
+
+def test_obs_aos_rows_vs_reference_return_triple(params_1k):
+    """The AoS observation row against the reference capture directly: p, v from `state`, q against R,
+    prev_rates, and the accelerometer triple R_new @ acc (components.py:247-248) of golden G3."""
+    g = load_golden("g3_ema_noise")
+    acts = g["actions"]
+    T, n = acts.shape[:2]
+    env = _drone_batch(params_1k, n, with_obs_aos=True)
+    env.reset(position=g["init_position"], velocity=g["init_velocity"], ypr=g["init_ypr"])
+    a = torch.from_numpy(acts).to(DEV)
+    for t in range(T):
+        env.step(a[t], return_imu=False)
+    torch.cuda.synchronize()
+    obs = env.obs_aos.cpu().numpy().astype(np.float64)
+    np.testing.assert_allclose(obs[:, 0:3], g["state"][:, -1, 0:3], rtol=1e-5, atol=1e-5)
+    np.testing.assert_allclose(obs[:, 3:6], g["state"][:, -1, 3:6], rtol=2e-5, atol=2e-5)
+    Rq = oracle.quat_to_matrix(obs[:, 6:10])
+    assert np.abs(Rq - g["R"][:, -1]).max() < 2e-5
+    np.testing.assert_allclose(obs[:, 10:13], g["prev_rates"][:, -1], rtol=1e-5, atol=1e-4)
+    np.testing.assert_allclose(obs[:, 13:16], g["accel"][:, -1], rtol=2e-4, atol=2e-4)
+
+
+def test_simulator_call_sequence_through_components(params_1k):
+    """Drop-in check: the reference's own call sequence - src/core/simulator.py:53-59 (construction from the
+    params dict, world objects with their reference constructor arguments, reset), :85-91 (object_list with
+    gates, target update, action) and :156 (drone.step(action, wind_velocity_vector, object_list)) - executed
+    against fpyv_amd.components with num_envs=1 must land on the reference captures G10 (objects, moving
+    target) and G2 (free flight)."""
+    import yaml
+    from fpyv_amd.components import Cylinder, Drone, Gate, Ground, Target
+    from fpyv_amd.params import DEFAULT_PARAMS_PATH
+    with open(DEFAULT_PARAMS_PATH) as f:
+        params = yaml.safe_load(f)                                    # the params.yaml-shaped dict of simulator.py:9
+    params["simulator"]["fps"] = 1000
+    params["camera"] = {"camera_angle": 35.0}                         # sections the stepper does not use are ignored
+    frozen = yaml.safe_dump(params)
+
+    g = load_golden("g10_objects")
+    T, n = g["actions"].shape[:2]
+    first = lambda d: int(np.argmax(d)) if d.any() else -1      # noqa: E731
+    for k in range(n):
+        drone = Drone(params, num_envs=1, device=DEV)                                              # simulator.py:53
+        targets = [Target(np.array([0.0, -6.0, 3.0]), 0.8, 1, {"radius": 1.5, "resolution": 20000})]   # :54, generators.py:22-25
+        obstacles = [Cylinder(np.array([3.0, 0.0, 0.0]), 1.0, 5.0, 4, 2, random=False),           # :56, generators.py:33-37
+                     Cylinder(np.array([-2.0, 2.5, 0.0]), 0.6, 1.5, 4, 2, random=False)]
+        gates = [Gate(np.array([4.0, 0.0, 2.5]), np.eye(3), 2.5, shape="circle", resolution=17)]   # :57
+        ground = Ground(size=60, resolution=4, random=False)                                       # :58
+        drone.reset(position=g["init_position"][k], velocity=g["init_velocity"][k], ypr=g["init_ypr"][k])   # :59
+        wind_velocity_vector = np.array([0, 0, 0])                                                 # :63
+        dones = []
+        for i in range(T):                                                                         # :83
+            object_list = [*targets, *gates, *obstacles, ground]                                   # :85
+            [target.update() for target in targets]                                                # :87
+            action = g["actions"][i, k]                                                            # :89
+            ret = drone.step(action=action, wind_velocity_vector=wind_velocity_vector, object_list=object_list)   # :156
+            dones.append(drone.done_u8.clone())
+        seq = torch.stack(dones).cpu().numpy()[:, 0]
+        assert abs(first(seq) - first(g["done"][k])) <= 2, (k, first(seq), first(g["done"][k]))
+        if not g["done"][k].any():
+            ref = np.concatenate([g["state"][k:k + 1, -1], g["R"][k:k + 1, -1].reshape(1, 9), g["prev_rates"][k:k + 1, -1],
+                                  g["prev_thrust"][k:k + 1, -1:]], axis=1)
+            err = soa_vs_oracle(drone.state.cpu().numpy(), ref, 1)
+            assert err["pos_comp"] < 1e-4 and err["quat_abs"] < 1e-5, (k, err)
+            RT, gyro, acc = (x.cpu().numpy()[0] for x in ret)
+            np.testing.assert_allclose(RT, g["ret_RT"][k], atol=2e-5)
+    assert yaml.safe_dump(params) == frozen, "Drone(params) must not modify the caller's dict (the reference does, :143-144)"
+
+    g = load_golden("g2_sin_4096")
+    for k in (0, 7):
+        drone = Drone(params, num_envs=1, device=DEV)
+        drone.reset(position=np.array(params["drone"]["initial_position"]), velocity=np.array(params["drone"]["initial_velocity"]),
+                    ypr=np.array(params["drone"]["initial_orientation"]))                           # simulator.py:59
+        for i in range(g["actions"].shape[0]):
+            ret = drone.step(action=g["actions"][i, k], wind_velocity_vector=np.array([0, 0, 0]), object_list=[])
+            assert not bool(drone.done)                                                              # :92-94
+        ref = np.concatenate([g["state"][k:k + 1, -1], g["R"][k:k + 1, -1].reshape(1, 9), g["prev_rates"][k:k + 1, -1],
+                              g["prev_thrust"][k:k + 1, -1:]], axis=1)
+        assert_parity(soa_vs_oracle(drone.state.cpu().numpy(), ref, 1), REL_TOL, f"simulator sequence, G2 drone {k}")
+        np.testing.assert_allclose(ret[0].cpu().numpy()[0], g["ret_RT"][k], atol=1e-5)
+        np.testing.assert_allclose(drone.position.cpu().numpy()[0], g["state"][k, -1, 0:3], rtol=1e-5, atol=1e-5)
+    drone2 = Drone(DEFAULT_PARAMS_PATH, num_envs=3, device=DEV)         # a YAML path works too
+    assert drone2.dt == pytest.approx(1 / 60) and drone2.max_rates == 200
+
+
+def test_set_done_bits_target_public_api(params_1k):
+    n, k = 1000, 12
+    words = (n + 63) // 64
+    env = _drone_batch(params_1k.replace(ceiling=10.2), n, with_done_bits=True, auto_reset=True)
+    env.reset()
+    acts = torch.from_numpy(sticks.ema_noise(k, range(n), seed=2)).to(DEV)
+    acts[..., 3] = 1.0                                                   # full throttle: the ceiling ends episodes
+    rows = torch.zeros((k, words), dtype=torch.int64, device=DEV)
+    dones = torch.zeros((k, n), dtype=torch.uint8, device=DEV)
+    for t in range(k):                                                   # per-step destinations (what bench.py's gather does)
+        env.set_done_bits_target(rows[t])
+        env.step(acts[t], return_imu=False)
+        dones[t] = env.done_u8
+    env.set_done_bits_target(None)
+    env.step(acts[0], return_imu=False)
+    torch.cuda.synchronize()
+    from fpyv_amd.dist import unpack_done_bits
+    for t in range(k):
+        assert torch.equal(unpack_done_bits(rows[t], n), dones[t])
+    assert bool(dones.any())
+    assert torch.equal(unpack_done_bits(env.done_bits, n), env.done_u8)
+    with pytest.raises(ValueError):
+        env.set_done_bits_target(torch.zeros(words - 1, dtype=torch.int64, device=DEV))
+    with pytest.raises(ValueError):
+        env.set_done_bits_target(rows, stride_words=words - 1)

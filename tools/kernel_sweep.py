@@ -12,7 +12,7 @@ sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import torch  # noqa: E402
 
 from fpyv_amd import _lib, load_params, sticks  # noqa: E402
-from fpyv_amd.env import DroneBatch  # noqa: E402
+from fpyv_amd.env import DroneBatch, RacerBatch  # noqa: E402
 
 
 def main():
@@ -28,6 +28,8 @@ def main():
     ap.add_argument("--noise", action="store_true", help="also time pure in-kernel noise sticks (no action read)")
     ap.add_argument("--extras", action="store_true", help="also time the Kahan-row and 4-object collision variants")
     ap.add_argument("--graph", action="store_true", help="also time the hipGraph-replayed rollout")
+    ap.add_argument("--fused", action="store_true", help="also time the k-step kernel (fpv_step_n), k = ring span per launch")
+    ap.add_argument("--racer", action="store_true", help="also time the Racer kernels (as written / omega*dt / components.PID)")
     ap.add_argument("--out", default=None)
     a = ap.parse_args()
     dev = torch.device("cuda:0")
@@ -65,53 +67,70 @@ def main():
         world = [Target([0, -6, 3], 0.8), Cylinder([3, 0, 0], 1.0, 5.0), Cylinder([-2, 2.5, 0], 0.6, 1.5), Ground()]
         envs["obj1x128"] = eo
         a.geom = list(a.geom) + ["kahan1x128", "obj1x128"]
+    if a.racer:
+        import numpy as np
+        pid = np.array([[0.004, 0.02, 1e-6], [0.003, 0.01, 2e-6], [0.002, 0.005, 0.0]])
+        for tag, kw in (("racerW", dict(racer_omega_dt=False)), ("racerD", dict(racer_omega_dt=True)),
+                        ("racerWC", dict(racer_omega_dt=False, racer_pid_variant=1, racer_pid=-pid, pid_integral_clip=0.05,
+                                         pid_min_output=-0.004, pid_max_output=0.006, pid_derivative_transition_rate=0.3))):
+            rp = p.replace(**dict(dict(mode=1, racer_pid=pid, ceiling=50.0), **kw))
+            er = RacerBatch(rp, a.n, device=dev, auto_reset=True)
+            er.reset()
+            for blk in ("1x128", "1x256"):
+                envs[tag + blk] = er
+                a.geom = list(a.geom) + [tag + blk]
     variants = [(g, api) for g in a.geom for api in ("rollout", "step")]
     if a.graph:
         variants += [(g, "graph") for g in a.geom if g[0].isdigit()]
+    if a.fused:
+        variants += [(g, "fused") for g in a.geom if g.endswith("1x128") and not g.startswith("aos")]
     times = {v: [] for v in variants}
     ev0, ev1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
     for r in range(a.rounds + 1):
         for v in variants:
             d, api = v
             e = envs[d]
-            e.set_tuning(*[int(x) for x in d.replace("aos", "").replace("noise", "").replace("kahan", "").replace("obj", "").lstrip("h").split("x")])
+            e.set_tuning(*[int(x) for x in d.replace("aos", "").replace("noise", "").replace("kahan", "").replace("obj", "")
+                           .replace("racerWC", "").replace("racerW", "").replace("racerD", "").lstrip("h").split("x")])
             torch.cuda.synchronize()
             ev0.record()
             done = 0
             while done < a.launches:
                 span = min(a.ring, a.launches - done)
                 if d.startswith("noise"):
-                    if api == "rollout":
-                        e.rollout(None, steps=span)
+                    if api in ("rollout", "fused"):
+                        e.rollout(None, steps=span, fused=(api == "fused"))
                     else:
                         for t in range(span):
                             e.step(None, return_imu=False)
                 elif d.startswith("obj"):
-                    if api == "rollout":
+                    if api in ("rollout", "fused"):
                         e._set_objects(world)
-                        e.rollout(acts[:span], graph=False)
+                        e.rollout(acts[:span], fused=(api == "fused"))
                     else:
                         for t in range(span):
                             e.step(acts[t], object_list=world, return_imu=False)
                 elif api == "graph":
                     e.rollout(acts[:span], graph=True)
-                elif api == "rollout":
-                    e.rollout(acts[:span])
+                elif api in ("rollout", "fused"):
+                    e.rollout(acts[:span], fused=(api == "fused"))
                 else:
                     for t in range(span):
                         e.step(acts[t], return_imu=False)
                 done += span
             ev1.record()
             torch.cuda.synchronize()
-            if r:   # round 0 = warm-up
+            if r:   # round 0 = warm-up;  "launches" counts env steps: a fused launch advances `span` of them
                 times[v].append(ev0.elapsed_time(ev1) * 1e3 / a.launches)
     res = []
     for v in variants:
         B = envs[v[0]].algorithmic_bytes() + (64 if v[0].startswith("aos") else 0) + (16 if v[0].startswith("noise") else 0) + (48 if v[0].startswith("kahan") else 0)
+        if v[1] == "fused":        # state traffic amortised over the ring span; reward/done only after the last step
+            B = 16 + (B - 16) / min(a.ring, a.launches) if not v[0].startswith("noise") else (B - 16) / min(a.ring, a.launches)
         med, mn = statistics.median(times[v]), min(times[v])
         res.append({"geom": v[0], "api": v[1], "median_us": med, "min_us": mn,
                     "GBps_alg_median": B * a.n / med / 1e3, "env_steps_per_s_median": a.n / med * 1e6})
-        print(f"geom={v[0]} api={v[1]:8s} median {med:8.2f} us  min {mn:8.2f} us  "
+        print(f"geom={v[0]} api={v[1]:8s} median {med:8.2f} us/step  min {mn:8.2f}  "
               f"{B * a.n / med / 1e3:8.1f} GB/s(alg)  {a.n / med:8.1f} M env-steps/s", flush=True)
     if a.out:
         json.dump({"n": a.n, "launches": a.launches, "rounds": a.rounds, "results": res}, open(a.out, "w"), indent=1)

@@ -30,7 +30,7 @@ acts = sticks.ema_noise_device(a.ring, a.n, dev)
 done = 0
 while done < a.launches:
     span = min(a.ring, a.launches - done)
-    env.rollout(acts[:span])
+    env.rollout(acts[:span], fused=False)        # single-step launches: the kernel being measured
     done += span
 torch.cuda.synchronize()
 src = torch.randn(a.calib_floats, device=dev)

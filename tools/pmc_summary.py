@@ -16,7 +16,10 @@ import glob
 import json
 import os
 
+import sys
+
 REPO = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, REPO)
 
 
 def counters(d):
@@ -24,7 +27,7 @@ def counters(d):
     agg = collections.defaultdict(list)
     for r in csv.DictReader(open(f)):
         k = r["Kernel_Name"]
-        short = "step" if "fpv_drone_step" in k else ("copy" if "fpv_diag_copy" in k else None)
+        short = "step" if "fpv_drone_step_kernel" in k else ("copy" if "fpv_diag_copy" in k else None)
         if short:
             agg[(short, r["Counter_Name"])].append(
                 (float(r["Counter_Value"]), int(r["End_Timestamp"]) - int(r["Start_Timestamp"]), int(r["Grid_Size"])))
@@ -33,7 +36,7 @@ def counters(d):
 
 def main():
     ap = argparse.ArgumentParser()
-    ap.add_argument("--round", default="r01")
+    ap.add_argument("--round", default="r02")
     ap.add_argument("--kt", required=True)
     ap.add_argument("--fetch", required=True)
     ap.add_argument("--write", required=True)
@@ -49,7 +52,7 @@ def main():
     keep = [rows[0]] + [r for r in rows[1:] if "fpv_" in r[0]]
     with open(os.path.join(out_dir, f"{a.round}_kernel_stats.csv"), "w", newline="") as f:
         csv.writer(f).writerows(keep)
-    step_row = [r for r in keep[1:] if "fpv_drone_step" in r[0]][0]
+    step_row = [r for r in keep[1:] if "fpv_drone_step_kernel" in r[0]][0]
     avg_ns, calls = float(step_row[3]), int(step_row[1])
 
     fe, wr = counters(a.fetch), counters(a.write)
@@ -63,7 +66,9 @@ def main():
     res = {
         "source": f"profiles/{a.round}_pmc_summary.md (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE, separate passes, "
                   f"calibrated on fpv_diag_stream_copy)",
-        "kernel": "fpv_drone_step_kernel<1,false>", "drones": a.n,
+        "kernel": "fpv_drone_step_kernel<128,1,false>", "drones": a.n,
+        # bench.py reports this traffic only while the kernel sources still hash to this value
+        "kernel_source_sha256_16": __import__("bench").kernel_source_hash(),
         "fetch_raw_kib": mean(fe[("step", "FETCH_SIZE")]), "write_raw_kib": mean(wr[("step", "WRITE_SIZE")]),
         "fetch_scale": f_scale, "write_scale": w_scale,
         "read_bytes_per_launch": fetch_kib * 1024, "write_bytes_per_launch": write_kib * 1024,
@@ -77,7 +82,7 @@ def main():
     with open(os.path.join(out_dir, f"{a.round}_pmc_summary.md"), "w") as f:
         f.write(f"# {a.round}: rocprofv3 summary of the step kernel (N = {a.n} drones, dt = 1 ms, EMA-noise sticks)\n\n")
         f.write("Commands (GPU box, one MI355X):\n\n```\n"
-                "rocprofv3 --kernel-trace --stats --output-format csv -d prof_kt -- python3 bench.py --steps 2000 --warmup 200 --no-cpu-baseline\n"
+                "rocprofv3 --kernel-trace --stats --output-format csv -d prof_kt -- python3 bench.py --steps 2000 --warmup 200 --no-cpu-baseline --no-beyond-mall\n"
                 "rocprofv3 --kernel-trace --pmc FETCH_SIZE --output-format csv -d pmc_fetch -- python3 tools/pmc_probe.py\n"
                 "rocprofv3 --kernel-trace --pmc WRITE_SIZE --output-format csv -d pmc_write -- python3 tools/pmc_probe.py\n```\n\n")
         f.write("## kernel trace (--stats)\n\n| kernel | calls | avg ns | min ns | max ns |\n|---|---:|---:|---:|---:|\n")
