@@ -157,6 +157,8 @@ struct RollOut {
     {
         if (track && live) { ep_r = B.ep_return[i]; ep_l = B.ep_length[i]; }
     }
+    // does step t store (or accumulate) a reward?  wave-uniform
+    __device__ __forceinline__ bool wants(int t) const { return track || out_stride != 0 || t == last_t; }
     // called by every live lane of the wave in the same iteration (the ballot spans the wave)
     __device__ __forceinline__ void step(uint32_t i, int t, float reward, bool done)
     {
@@ -293,7 +295,9 @@ __global__ __launch_bounds__(BS) void fpv_drone_rollout_kernel(const FpvK K, con
             a_next = ld_action_any(reinterpret_cast<const float4*>(ap), B.action_ld, i);
         }
         if (NOISE) fpv_stick_noise(K.noise, B.step + (uint32_t)t, (uint64_t)i, ns, av);
-        o = fpv_drone_step_lane<BIG, OBJ>(K, s, av[0], av[1], av[2], av[3], B.wx, B.wy, B.wz, &B.objs, KAHAN ? kc : nullptr);
+        // reward / R_new @ acc are computed only on the steps that store them (wave-uniform choice)
+        if (out.wants(t)) o = fpv_drone_step_lane<BIG, OBJ, true>(K, s, av[0], av[1], av[2], av[3], B.wx, B.wy, B.wz, &B.objs, KAHAN ? kc : nullptr);
+        else o = fpv_drone_step_lane<BIG, OBJ, false>(K, s, av[0], av[1], av[2], av[3], B.wx, B.wy, B.wz, &B.objs, KAHAN ? kc : nullptr);
         const bool rst = (K.flags & FPV_FLAG_AUTO_RESET) && o.done;
         if (KAHAN && rst) {
 #pragma unroll
@@ -302,20 +306,23 @@ __global__ __launch_bounds__(BS) void fpv_drone_rollout_kernel(const FpvK K, con
         if (rst) fpv_drone_reset_lane(K, s);
         out.step(i, t, o.reward, o.done);
     }
+    // the store addresses are formed only now: computed before the loop they would sit in ~30 VGPRs for all k steps
+    uint32_t j = i;
+    asm volatile("" : "+v"(j));
     if (B.accel) {
-        row_at(ROW(B.accel, 0, B.ld), i) = o.ax; row_at(ROW(B.accel, 1, B.ld), i) = o.ay; row_at(ROW(B.accel, 2, B.ld), i) = o.az;
+        row_at(ROW(B.accel, 0, B.ld), j) = o.ax; row_at(ROW(B.accel, 1, B.ld), j) = o.ay; row_at(ROW(B.accel, 2, B.ld), j) = o.az;
     }
-    st_drone(B.state, B.ld, i, s);
+    st_drone(B.state, B.ld, j, s);
     if (NOISE) {
 #pragma unroll
-        for (int k = 0; k < 4; ++k) row_at(ROW(B.noise_state, k, B.ld), i) = ns[k];
-        if (B.action_out) B.action_out[i] = make_float4(av[0], av[1], av[2], av[3]);
+        for (int k = 0; k < 4; ++k) row_at(ROW(B.noise_state, k, B.ld), j) = ns[k];
+        if (B.action_out) B.action_out[j] = make_float4(av[0], av[1], av[2], av[3]);
     }
     if (KAHAN) {
 #pragma unroll
-        for (int k = 0; k < 6; ++k) row_at(ROW(B.pos_comp, k, B.ld), i) = kc[k];
+        for (int k = 0; k < 6; ++k) row_at(ROW(B.pos_comp, k, B.ld), j) = kc[k];
     }
-    out.finish(i);
+    out.finish(j);
 }
 
 // Same step + an array-of-structures observation row per drone, obs_aos[i][16] =
@@ -459,23 +466,26 @@ __global__ __launch_bounds__(BS) void fpv_drone_rollout_h_kernel(const FpvK K, c
         for (int t = 0; t < R.k; ++t) {
             const float4 a = a_next;
             if (R.action_stride && t + 1 < R.k) { ap += R.action_stride; a_next = ld_action(reinterpret_cast<const float4*>(ap), i); }
-            o = fpv_drone_step_lane<BIG>(K, s, a.x, a.y, a.z, a.w, B.wx, B.wy, B.wz);
+            if (out.wants(t)) o = fpv_drone_step_lane<BIG, false, true>(K, s, a.x, a.y, a.z, a.w, B.wx, B.wy, B.wz);
+            else o = fpv_drone_step_lane<BIG, false, false>(K, s, a.x, a.y, a.z, a.w, B.wx, B.wy, B.wz);
             if ((K.flags & FPV_FLAG_AUTO_RESET) && o.done) fpv_drone_reset_lane(K, s);
             fpv_pack_half(s, B.seed + (uint32_t)t, (uint32_t)i, h);       // the HBM round trip of a single step, in registers
             if (t + 1 < R.k) fpv_unpack_half(h, s);
             out.step(i, t, o.reward, o.done);
         }
+        uint32_t j = i;                              // form the store addresses after the loop (VGPR pressure)
+        asm volatile("" : "+v"(j));
         if (B.accel) {
-            row_at(ROW(B.accel, 0, B.ld), i) = o.ax; row_at(ROW(B.accel, 1, B.ld), i) = o.ay; row_at(ROW(B.accel, 2, B.ld), i) = o.az;
+            row_at(ROW(B.accel, 0, B.ld), j) = o.ax; row_at(ROW(B.accel, 1, B.ld), j) = o.ay; row_at(ROW(B.accel, 2, B.ld), j) = o.az;
         }
-        row_at(ROW(B.state, 0, B.ld), i) = s.px; row_at(ROW(B.state, 1, B.ld), i) = s.py; row_at(ROW(B.state, 2, B.ld), i) = s.pz;
+        row_at(ROW(B.state, 0, B.ld), j) = s.px; row_at(ROW(B.state, 1, B.ld), j) = s.py; row_at(ROW(B.state, 2, B.ld), j) = s.pz;
         uint32_t w[FPV_HALF_PAIR_ROWS];
         fpv_join_pairs(h, w);
         uint32_t* __restrict__ sh = reinterpret_cast<uint32_t*>(B.state_h);
 #pragma unroll
-        for (int k = 0; k < FPV_HALF_PAIR_ROWS; ++k) row_at(ROW(sh, k, B.ld), i) = w[k];
+        for (int k = 0; k < FPV_HALF_PAIR_ROWS; ++k) row_at(ROW(sh, k, B.ld), j) = w[k];
         th = h.t;
-        out.finish(i);
+        out.finish(j);
     }
     st_thrust_pair_h(B, i, live, th);
 }
@@ -552,8 +562,10 @@ __global__ __launch_bounds__(BS) void fpv_racer_rollout_kernel(const FpvK K, con
         if ((K.flags & FPV_FLAG_AUTO_RESET) && done) fpv_racer_reset_lane(s);
         out.step(i, t, reward, done);
     }
-    st_racer<WIDE, PIDV>(B.state, B.ld, i, s);
-    out.finish(i);
+    uint32_t j = i;                                  // form the store addresses after the loop (VGPR pressure)
+    asm volatile("" : "+v"(j));
+    st_racer<WIDE, PIDV>(B.state, B.ld, j, s);
+    out.finish(j);
 }
 
 // Drone.reset (components.py:150-169): p, v, R = E(deg2rad(ypr)) with the triple consumed as

@@ -412,7 +412,9 @@ FPV_HD bool fpv_collide_objects(const FpvK& K, const FpvObjects& T, const float 
     return crashed;
 }
 
-template <bool BIG, bool OBJ = false>
+// OUT = false skips the values that only leave the lane (R_new @ acc and the reward): the k-step kernel
+// needs them only on the steps whose outputs are stored.  The state update is identical either way.
+template <bool BIG, bool OBJ = false, bool OUT = true>
 FPV_HD FpvStepOut fpv_drone_step_lane(const FpvK& K, FpvDroneState& s, float a0, float a1, float a2, float a3,
                                       float wx, float wy, float wz, const FpvObjects* objs = nullptr,
                                       float* kahan = nullptr)
@@ -518,12 +520,15 @@ FPV_HD FpvStepOut fpv_drone_step_lane(const FpvK& K, FpvDroneState& s, float a0,
     s.q = fpv_quat_advance(s.q, -2.0f * vv, m2w * ex, m2w * ey, m2w * ez);
 
     FpvStepOut o;
-    const FpvRot Rn = fpv_rot(s.q);                                        // components.py:248
-    o.ax = fmaf(Rn.r00, accx, fmaf(Rn.r01, accy, Rn.r02 * accz));
-    o.ay = fmaf(Rn.r10, accx, fmaf(Rn.r11, accy, Rn.r12 * accz));
-    o.az = fmaf(Rn.r20, accx, fmaf(Rn.r21, accy, Rn.r22 * accz));
-    const float gx = s.px - K.goal[0], gy = s.py - K.goal[1], gz = s.pz - K.goal[2];
-    o.reward = -sqrtf(fmaf(gx, gx, fmaf(gy, gy, gz * gz)));
+    o.ax = o.ay = o.az = 0.0f; o.reward = 0.0f;
+    if (OUT) {
+        const FpvRot Rn = fpv_rot(s.q);                                    // components.py:248
+        o.ax = fmaf(Rn.r00, accx, fmaf(Rn.r01, accy, Rn.r02 * accz));
+        o.ay = fmaf(Rn.r10, accx, fmaf(Rn.r11, accy, Rn.r12 * accz));
+        o.az = fmaf(Rn.r20, accx, fmaf(Rn.r21, accy, Rn.r22 * accz));
+        const float gx = s.px - K.goal[0], gy = s.py - K.goal[1], gz = s.pz - K.goal[2];
+        o.reward = -sqrtf(fmaf(gx, gx, fmaf(gy, gy, gz * gz)));
+    }
     o.done = done || !(fabsf(s.pz) <= K.ceiling);
     return o;
 }

@@ -471,8 +471,9 @@ class RacerBatch(_Batch):
     def reset(self, mask=None) -> None:
         self._reset_raw(mask=mask)
 
-    def step(self, action) -> None:
-        """action [num_envs, 4] = desired body rates (3) + thrust force (racer_drone_test.py:95-100)."""
+    def step(self, action, return_imu: bool = False) -> None:
+        """action [num_envs, 4] = desired body rates (3) + thrust force (racer_drone_test.py:95-100).
+        Racer.step returns nothing; `return_imu` exists only so a loop written for DroneBatch runs unchanged."""
         self._step_raw(action)
 
     @property
