@@ -32,7 +32,8 @@ R_OMEGA, R_IERR, R_LERR, R_FIRST, R_OMEGA_LO, R_IERR_LO, R_DFILT = 10, 13, 16, 1
 # every symbol include/fpv_abi.h declares
 EXPORTS = ("fpv_abi_version", "fpv_sizeof", "fpv_state_rows", "fpv_algorithmic_bytes", "fpv_handle_algorithmic_bytes", "fpv_create", "fpv_destroy",
            "fpv_reset", "fpv_step", "fpv_rollout", "fpv_step_n", "fpv_rollout_graph", "fpv_set_params", "fpv_set_step_counter", "fpv_set_tuning", "fpv_recommended_ld",
-           "fpv_diag_stream_copy", "fpv_pid_reset", "fpv_pid_call", "fpv_last_error",
+           "fpv_diag_stream_copy", "fpv_pid_reset", "fpv_pid_call", "fpv_comm_unique_id", "fpv_comm_create", "fpv_comm_destroy",
+           "fpv_allgather_done", "fpv_allgather_f32", "fpv_last_error",
            "fpv_error_name")
 
 
@@ -61,6 +62,7 @@ class FpvParams(C.Structure):
 FPV_MAX_OBJECTS = 8
 OBJ_GROUND, OBJ_CYLINDER, OBJ_SPHERE = 0, 1, 2
 FPV_PID_ROWS = 4       # integral, prev_derivative, previous_error, is_first
+FPV_COMM_ID_BYTES = 128
 
 
 class FpvPidParams(C.Structure):
@@ -184,6 +186,12 @@ def lib() -> C.CDLL:
     L.fpv_recommended_ld.argtypes = [i64]
     L.fpv_recommended_ld.restype = i64
     L.fpv_diag_stream_copy.argtypes = [vp, vp, i64, vp]
+    L.fpv_comm_unique_id.argtypes = [vp]
+    L.fpv_comm_create.argtypes = [vp, C.c_int, C.c_int, C.c_int, C.POINTER(vp)]
+    L.fpv_comm_destroy.argtypes = [vp]
+    L.fpv_comm_destroy.restype = None
+    L.fpv_allgather_done.argtypes = [vp, vp, vp, i64, vp]
+    L.fpv_allgather_f32.argtypes = [vp, vp, vp, i64, vp]
     L.fpv_pid_reset.argtypes = [vp, i64, i64, vp, C.c_int, vp]
     L.fpv_pid_call.argtypes = [C.POINTER(FpvPidParams), vp, i64, i64, vp, vp, C.c_float, vp, vp, C.c_int, vp]
     L.fpv_last_error.restype = C.c_char_p

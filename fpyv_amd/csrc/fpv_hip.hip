@@ -16,8 +16,10 @@
 // Drone.reset :150-169, Racer.step /root/reference/tests/racer_drone_test.py:95-103.
 #include <hip/hip_runtime.h>
 
+#include <dlfcn.h>
 #include <math.h>
 #include <stdint.h>
+#include <stdlib.h>
 #include <string.h>
 
 #include <new>
@@ -1243,6 +1245,120 @@ int fpv_pid_call(const fpv_pid_params_t* params, float* pid_state, int64_t ld, i
     const hipError_t e = hipGetLastError();
     if (e != hipSuccess) return hip_fail(e, "pid kernel launch");
     return FPV_OK;
+}
+
+// ---- RCCL, opened at run time ------------------------------------------------------------------------------
+namespace {
+struct NcclId { char internal[FPV_COMM_ID_BYTES]; };          // = ncclUniqueId (rccl.h: NCCL_UNIQUE_ID_BYTES 128)
+typedef void* NcclComm;
+enum { kNcclSuccess = 0, kNcclUint64 = 5, kNcclFloat32 = 7 };   // rccl.h: ncclResult_t / ncclDataType_t values
+struct Rccl {
+    void* lib = nullptr;
+    int (*GetUniqueId)(NcclId*) = nullptr;
+    int (*CommInitRank)(NcclComm*, int, NcclId, int) = nullptr;
+    int (*CommDestroy)(NcclComm) = nullptr;
+    int (*AllGather)(const void*, void*, size_t, int, NcclComm, hipStream_t) = nullptr;
+    const char* (*GetErrorString)(int) = nullptr;
+    std::string why;
+};
+
+Rccl* rccl()
+{
+    static Rccl R;
+    if (R.lib || !R.why.empty()) return &R;
+    const char* env = getenv("FPV_RCCL_PATH");
+    if (env && *env) R.lib = dlopen(env, RTLD_NOW | RTLD_LOCAL);
+    // reuse a copy the process already has (PyTorch links its own as "librccl.so"), else load the system one
+    if (!R.lib) R.lib = dlopen("librccl.so", RTLD_NOW | RTLD_NOLOAD);
+    if (!R.lib) R.lib = dlopen("librccl.so.1", RTLD_NOW | RTLD_NOLOAD);
+    if (!R.lib) R.lib = dlopen("librccl.so.1", RTLD_NOW | RTLD_LOCAL);
+    if (!R.lib) R.lib = dlopen("/opt/rocm/lib/librccl.so.1", RTLD_NOW | RTLD_LOCAL);
+    if (!R.lib) { R.why = std::string("librccl not found: ") + dlerror(); return &R; }
+    R.GetUniqueId = reinterpret_cast<int (*)(NcclId*)>(dlsym(R.lib, "ncclGetUniqueId"));
+    R.CommInitRank = reinterpret_cast<int (*)(NcclComm*, int, NcclId, int)>(dlsym(R.lib, "ncclCommInitRank"));
+    R.CommDestroy = reinterpret_cast<int (*)(NcclComm)>(dlsym(R.lib, "ncclCommDestroy"));
+    R.AllGather = reinterpret_cast<int (*)(const void*, void*, size_t, int, NcclComm, hipStream_t)>(dlsym(R.lib, "ncclAllGather"));
+    R.GetErrorString = reinterpret_cast<const char* (*)(int)>(dlsym(R.lib, "ncclGetErrorString"));
+    if (!R.GetUniqueId || !R.CommInitRank || !R.CommDestroy || !R.AllGather) { R.why = "librccl lacks the ncclGetUniqueId/CommInitRank/CommDestroy/AllGather symbols"; R.lib = nullptr; }
+    return &R;
+}
+
+int rccl_fail(int rc, const char* what)
+{
+    Rccl* R = rccl();
+    return fail(FPV_EHIP, std::string(what) + ": " + (R->GetErrorString ? R->GetErrorString(rc) : "RCCL error ") + " (" + std::to_string(rc) + ")");
+}
+}  // namespace
+
+struct fpv_comm {
+    NcclComm comm;
+    int world, rank, device;
+};
+
+int fpv_comm_unique_id(uint8_t id[FPV_COMM_ID_BYTES])
+{
+    if (!id) return fail(FPV_EINVAL, "null id");
+    Rccl* R = rccl();
+    if (!R->lib) return fail(FPV_EHIP, R->why);
+    NcclId u;
+    const int rc = R->GetUniqueId(&u);
+    if (rc != kNcclSuccess) return rccl_fail(rc, "ncclGetUniqueId");
+    memcpy(id, u.internal, FPV_COMM_ID_BYTES);
+    return FPV_OK;
+}
+
+int fpv_comm_create(const uint8_t id[FPV_COMM_ID_BYTES], int world_size, int rank, int device, fpv_comm_t* out)
+{
+    if (!id || !out) return fail(FPV_EINVAL, "null argument");
+    *out = nullptr;
+    if (world_size <= 0 || rank < 0 || rank >= world_size) return fail(FPV_EINVAL, "need 0 <= rank < world_size");
+    Rccl* R = rccl();
+    if (!R->lib) return fail(FPV_EHIP, R->why);
+    int rc = bind_device_index(device);
+    if (rc != FPV_OK) return rc;
+    NcclId u;
+    memcpy(u.internal, id, FPV_COMM_ID_BYTES);
+    NcclComm c = nullptr;
+    rc = R->CommInitRank(&c, world_size, u, rank);
+    if (rc != kNcclSuccess) return rccl_fail(rc, "ncclCommInitRank");
+    fpv_comm* h = new (std::nothrow) fpv_comm;
+    if (!h) { (void)R->CommDestroy(c); return fail(FPV_EINVAL, "out of host memory"); }
+    h->comm = c; h->world = world_size; h->rank = rank; h->device = device;
+    *out = h;
+    return FPV_OK;
+}
+
+void fpv_comm_destroy(fpv_comm_t c)
+{
+    if (!c) return;
+    Rccl* R = rccl();
+    if (R->lib && c->comm) (void)R->CommDestroy(c->comm);
+    delete c;
+}
+
+namespace {
+int allgather(fpv_comm_t c, const void* send, void* recv, int64_t count, int dtype, void* stream)
+{
+    if (!c || !send || !recv) return fail(FPV_EINVAL, "null argument");
+    if (count <= 0) return fail(FPV_EINVAL, "count per rank must be positive");
+    Rccl* R = rccl();
+    if (!R->lib) return fail(FPV_EHIP, R->why);
+    int rc = bind_device_index(c->device);
+    if (rc != FPV_OK) return rc;
+    rc = R->AllGather(send, recv, (size_t)count, dtype, c->comm, (hipStream_t)stream);
+    if (rc != kNcclSuccess) return rccl_fail(rc, "ncclAllGather");
+    return FPV_OK;
+}
+}  // namespace
+
+int fpv_allgather_done(fpv_comm_t c, const uint64_t* send_bits, uint64_t* recv_bits, int64_t words_per_rank, void* stream)
+{
+    return allgather(c, send_bits, recv_bits, words_per_rank, kNcclUint64, stream);
+}
+
+int fpv_allgather_f32(fpv_comm_t c, const float* send, float* recv, int64_t count_per_rank, void* stream)
+{
+    return allgather(c, send, recv, count_per_rank, kNcclFloat32, stream);
 }
 
 const char* fpv_last_error(void) { return g_err.c_str(); }

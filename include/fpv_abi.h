@@ -257,6 +257,26 @@ int64_t fpv_recommended_ld(int64_t n);
  * (one dword per lane); a known-byte-count launch for calibrating rocprofv3 byte counters. */
 int fpv_diag_stream_copy(float* dst, const float* src, int64_t n_floats, void* stream);
 
+/* ---- multi-GPU: contiguous shards, one process (or thread) per GPU, RCCL over xGMI ---------------------------
+ * The physics needs no collective (drones are independent); the only exchange of the path is the all-gather of the
+ * done mask (and, on request, per-drone episode returns) for a learner that wants the global view.  These entry
+ * points give a non-Python host that exchange: RCCL is opened at run time (dlopen: an already loaded librccl - e.g.
+ * the one PyTorch ships - is reused, else librccl.so.1 from the loader path or $FPV_RCCL_PATH), so libfpv_hip.so has
+ * no link-time dependency on it.  The Python host uses torch.distributed (backend "nccl" = RCCL) instead. */
+#define FPV_COMM_ID_BYTES 128
+typedef struct fpv_comm* fpv_comm_t;
+/* rank 0: create the rendezvous token (ncclGetUniqueId) and hand its 128 bytes to the other ranks out of band */
+int fpv_comm_unique_id(uint8_t id[FPV_COMM_ID_BYTES]);
+/* every rank: join the communicator (ncclCommInitRank) on `device`; collective - returns when all ranks joined */
+int fpv_comm_create(const uint8_t id[FPV_COMM_ID_BYTES], int world_size, int rank, int device, fpv_comm_t* out);
+void fpv_comm_destroy(fpv_comm_t c);
+/* all-gather of the bit-packed done masks: every rank contributes words_per_rank 64-bit words (its
+ * fpv_buffers_t.done_bits, or a whole [steps][words] bucket of them) and receives world_size * words_per_rank words,
+ * rank r's block at recv + r * words_per_rank.  Enqueued on `stream`; equal shard sizes on every rank. */
+int fpv_allgather_done(fpv_comm_t c, const uint64_t* send_bits, uint64_t* recv_bits, int64_t words_per_rank, void* stream);
+/* same for fp32 values (episode returns: fpv_buffers_t.last_return) */
+int fpv_allgather_f32(fpv_comm_t c, const float* send, float* recv, int64_t count_per_rank, void* stream);
+
 /* ---- components.PID for N drones at once (src/utils/components.py:15-54) --------------------------------
  * The reference's guidance PID (Drone.force_multiplier_pid, components.py:145,:288): leaky clipped integral,
  * clipped and low-passed derivative, clipped output.  One lane per drone, state as SoA rows

@@ -14,7 +14,7 @@ from fpyv_amd import _lib, load_params
 def _declared_symbols():
     hdr = open(os.path.join(REPO, "include", "fpv_abi.h")).read()
     hdr = re.sub(r"/\*.*?\*/", "", hdr, flags=re.S)
-    return sorted(set(re.findall(r"\b(fpv_[a-z_]+)\s*\(", hdr)))
+    return sorted(set(re.findall(r"\b(fpv_[a-z_0-9]+)\s*\(", hdr)))
 
 
 def test_header_and_binding_agree():

@@ -52,7 +52,9 @@ def test_golden_profiles_vs_oracle_and_reference(params_1k, name):
                                  g["prev_thrust"][:, -1:]], axis=1)
     assert_parity(soa_vs_oracle(got, ref_direct, n), REL_TOL, name + " (reference capture)")
     assert np.array_equal(env.done_u8.cpu().numpy(), g["done"][:, -1])
-    np.testing.assert_allclose(env.accel[:, :n].t().cpu().numpy(), g["accel"][:, -1], rtol=2e-4, atol=2e-4)
+    # R_new @ acc is an OUTPUT (not state): thrust/m (up to 108 m/s^2), gravity and drag cancel in fp32, so it
+    # carries ~6e-5 of its own magnitude (measured worst case, G4: 2.6e-4 m/s^2 on 75 m/s^2); 1e-4 relative + floor
+    np.testing.assert_allclose(env.accel[:, :n].t().cpu().numpy(), g["accel"][:, -1], rtol=1e-4, atol=1e-4)
 
 
 def test_step_return_triple_matches_reference(params_1k):
@@ -68,7 +70,7 @@ def test_step_return_triple_matches_reference(params_1k):
     RT, gyro, acc = (x.cpu().numpy() for x in out)
     np.testing.assert_allclose(RT, g["ret_RT"], atol=1e-5)
     np.testing.assert_allclose(gyro, g["ret_gyro"], atol=2e-4)     # rates ~ tens of deg used as radians
-    np.testing.assert_allclose(acc, g["accel"][:, -1], rtol=2e-4, atol=2e-4)
+    np.testing.assert_allclose(acc, g["accel"][:, -1], rtol=1e-4, atol=1e-4)
     np.testing.assert_allclose(env.position.cpu().numpy(), g["state"][:, -1, 0:3], rtol=1e-5, atol=1e-5)
     assert env.done.dtype == torch.bool and not env.done.any()
 
@@ -152,8 +154,7 @@ def test_ground_contact_done_sequence(params_1k):
     env.rollout(torch.from_numpy(acts).to(DEV), rewards=rewards, dones=dones)
     torch.cuda.synchronize()
     seq = dones.cpu().numpy().T
-    assert (seq != g["done"]).sum() <= 4          # fp32 may move an edge by one step
-    assert np.array_equal(seq.any(axis=1), g["done"].any(axis=1))
+    assert np.array_equal(seq, g["done"]), "done must flip on exactly the reference's steps"
     assert seq[2].any() and not seq[2][-1], "done is recomputed every step, not latched (components.py:236)"
 
 
@@ -169,12 +170,12 @@ def test_ground_plane_contact_vs_reference_capture(params_1k):
     dones = torch.zeros((T, n), dtype=torch.uint8, device=DEV)
     env.rollout(torch.from_numpy(acts).to(DEV), dones=dones)
     torch.cuda.synchronize()
-    assert (dones.cpu().numpy().T != g["done"]).sum() <= 2
+    assert np.array_equal(dones.cpu().numpy().T, g["done"])
     ref = np.concatenate([g["state"][:, -1], g["R"][:, -1].reshape(n, 9), g["prev_rates"][:, -1],
                           g["prev_thrust"][:, -1:]], axis=1)
     got = env.state.cpu().numpy()
     err = soa_vs_oracle(got, ref, n)
-    assert err["pos_comp"] < 2e-5 and err["quat_abs"] < 1e-5, err
+    assert err["pos_comp"] < REL_TOL and err["quat_abs"] < REL_TOL, err      # measured 1.2e-6 (tests/test_lane_model.py)
     lane_model.run(p, model, acts)
     assert np.array_equal(got[:, :n].view(np.uint32), model[:, :n].view(np.uint32))
 
@@ -558,12 +559,12 @@ def test_object_list_collisions_vs_reference_capture(params_1k):
     assert np.array_equal(got[:, :n].view(np.uint32), model[:, :n].view(np.uint32)), "kernel != lane model (bitwise)"
     first = lambda d: int(np.argmax(d)) if d.any() else -1      # noqa: E731
     for i in range(n):
-        assert abs(first(seq[i]) - first(g["done"][i])) <= 2
+        assert first(seq[i]) == first(g["done"][i]), "crash on exactly the reference's step"
     ok = ~g["done"].any(axis=1)
     ref = np.concatenate([g["state"][:, -1], g["R"][:, -1].reshape(n, 9), g["prev_rates"][:, -1],
                           g["prev_thrust"][:, -1:]], axis=1)
     err = soa_vs_oracle(np.ascontiguousarray(got[:, np.flatnonzero(ok)]), ref[ok], int(ok.sum()))
-    assert err["pos_comp"] < 1e-4 and err["quat_abs"] < 1e-5, err
+    assert err["pos_comp"] < REL_TOL and err["quat_abs"] < REL_TOL, err      # measured 4.1e-6 (tests/test_lane_model.py)
     # an object list and FPV_FLAG_GROUND are mutually exclusive; too many objects are rejected
     with pytest.raises(ValueError):
         env.step(a[0], object_list=[Ground()] * 9)
@@ -980,7 +981,7 @@ def test_obs_aos_rows_vs_reference_return_triple(params_1k):
     Rq = oracle.quat_to_matrix(obs[:, 6:10])
     assert np.abs(Rq - g["R"][:, -1]).max() < 2e-5
     np.testing.assert_allclose(obs[:, 10:13], g["prev_rates"][:, -1], rtol=1e-5, atol=1e-4)
-    np.testing.assert_allclose(obs[:, 13:16], g["accel"][:, -1], rtol=2e-4, atol=2e-4)
+    np.testing.assert_allclose(obs[:, 13:16], g["accel"][:, -1], rtol=1e-4, atol=1e-4)
 
 
 def test_simulator_call_sequence_through_components(params_1k):
@@ -1018,12 +1019,12 @@ def test_simulator_call_sequence_through_components(params_1k):
             ret = drone.step(action=action, wind_velocity_vector=wind_velocity_vector, object_list=object_list)   # :156
             dones.append(drone.done_u8.clone())
         seq = torch.stack(dones).cpu().numpy()[:, 0]
-        assert abs(first(seq) - first(g["done"][k])) <= 2, (k, first(seq), first(g["done"][k]))
+        assert first(seq) == first(g["done"][k]), (k, first(seq), first(g["done"][k]))         # crash on the reference's step
         if not g["done"][k].any():
             ref = np.concatenate([g["state"][k:k + 1, -1], g["R"][k:k + 1, -1].reshape(1, 9), g["prev_rates"][k:k + 1, -1],
                                   g["prev_thrust"][k:k + 1, -1:]], axis=1)
             err = soa_vs_oracle(drone.state.cpu().numpy(), ref, 1)
-            assert err["pos_comp"] < 1e-4 and err["quat_abs"] < 1e-5, (k, err)
+            assert err["pos_comp"] < REL_TOL and err["quat_abs"] < REL_TOL, (k, err)
             RT, gyro, acc = (x.cpu().numpy()[0] for x in ret)
             np.testing.assert_allclose(RT, g["ret_RT"][k], atol=2e-5)
     assert yaml.safe_dump(params) == frozen, "Drone(params) must not modify the caller's dict (the reference does, :143-144)"
@@ -1070,3 +1071,40 @@ def test_set_done_bits_target_public_api(params_1k):
         env.set_done_bits_target(torch.zeros(words - 1, dtype=torch.int64, device=DEV))
     with pytest.raises(ValueError):
         env.set_done_bits_target(rows, stride_words=words - 1)
+
+
+def test_c_abi_allgather_done_over_rccl(params_1k):
+    """fpv_comm_* / fpv_allgather_done: the done-mask exchange for a non-Python host, through RCCL opened
+    at run time.  One GPU here, so a communicator of one rank (the driver's multi-GPU run covers N > 1):
+    the gathered block must be this rank's masks, for a single mask and for a [k, words] bucket written
+    by the k-step kernel, and the fp32 variant must carry the episode returns."""
+    import ctypes as C
+    L = _lib.lib()
+    ident = (C.c_uint8 * _lib.FPV_COMM_ID_BYTES)()
+    _lib.check(L.fpv_comm_unique_id(ident))
+    comm = C.c_void_p()
+    _lib.check(L.fpv_comm_create(ident, 1, 0, 0, C.byref(comm)))
+    try:
+        n, k = 5000, 16
+        words = (n + 63) // 64
+        env = _drone_batch(params_1k.replace(ceiling=10.01), n, with_done_bits=True, auto_reset=True, track_episodes=True)
+        env.reset()
+        acts = torch.from_numpy(sticks.ema_noise(k, range(n), seed=4)).to(DEV)
+        acts[..., 3] = 1.0
+        bucket = torch.zeros((k, words), dtype=torch.int64, device=DEV)
+        env.set_done_bits_target(bucket, stride_words=words)
+        env.rollout(acts)                                              # one launch writes all k mask rows
+        gathered = torch.full((k, words), -1, dtype=torch.int64, device=DEV)
+        stream = torch.cuda.current_stream().cuda_stream
+        _lib.check(L.fpv_allgather_done(comm, bucket.data_ptr(), gathered.data_ptr(), k * words, stream))
+        returns = torch.zeros(n, device=DEV)
+        _lib.check(L.fpv_allgather_f32(comm, env.last_return.data_ptr(), returns.data_ptr(), n, stream))
+        torch.cuda.synchronize()
+        assert torch.equal(gathered, bucket) and bool((bucket != 0).any())
+        assert torch.equal(returns, env.last_return)
+        assert L.fpv_allgather_done(comm, None, gathered.data_ptr(), words, stream) == -1
+        assert L.fpv_allgather_done(None, bucket.data_ptr(), gathered.data_ptr(), words, stream) == -1
+    finally:
+        L.fpv_comm_destroy(comm)
+    bad = C.c_void_p()
+    assert L.fpv_comm_create(ident, 2, 5, 0, C.byref(bad)) == -1 and not bad.value

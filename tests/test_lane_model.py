@@ -25,7 +25,7 @@ def test_fp32_within_1e5_after_1000_steps(params_1k, name):
     err = soa_vs_oracle(s, ref, n)
     assert_parity(err, REL_TOL, name)
     assert np.array_equal(done, ref_done)
-    np.testing.assert_allclose(acc[:, :n].T, ref_acc, rtol=2e-4, atol=2e-4)   # third return value, R_new @ acc
+    np.testing.assert_allclose(acc[:, :n].T, ref_acc, rtol=1e-4, atol=1e-4)   # third return value, R_new @ acc (an output: fp32 cancellation of ~100 m/s^2 terms)
     goal = params_1k.goal
     np.testing.assert_allclose(rew, -np.linalg.norm(ref[:, 0:3] - goal, axis=1), rtol=1e-5, atol=1e-5)
 
@@ -55,9 +55,7 @@ def test_ground_flag_sequence(params_1k):
     for t in range(T):
         _, _, done, _ = lane_model.run(params_1k, s, acts[t:t + 1], wind=g["wind"])
         seq[:, t] = done
-    # fp32 may flip a flag one step early/late exactly at a zero crossing; allow <= 1 step per edge
-    assert (seq != g["done"]).sum() <= 4
-    assert np.array_equal(seq.any(axis=1), g["done"].any(axis=1))
+    assert np.array_equal(seq, g["done"]), "the fp32 done flag must flip on exactly the reference's steps"
 
 
 def test_big_angle_path_matches_small(params_1k):
@@ -180,12 +178,13 @@ def test_ground_contact_fp32(params_1k):
     for t in range(T):
         _, _, done, _ = lane_model.run(p, s, acts[t:t + 1])
         seq[:, t] = done
-    assert (seq != g["done"]).sum() <= 2
+    assert np.array_equal(seq, g["done"])
     ref = np.concatenate([g["state"][:, -1], g["R"][:, -1].reshape(n, 9), g["prev_rates"][:, -1],
                           g["prev_thrust"][:, -1:]], axis=1)
     err = soa_vs_oracle(s, ref, n)
-    # bouncing on an undamped 100 N/m spring for 0.6 s: position within 2e-5 m per metre
-    assert err["pos_comp"] < 2e-5 and err["quat_abs"] < 1e-5, err
+    # bouncing on an undamped 100 N/m spring for 0.6 s: measured 1.2e-6 (per component, 1 m floor) - the
+    # float64 oracle itself moves by 1.4e-7 under an fp32-ulp perturbation of its initial state
+    assert err["pos_comp"] < REL_TOL and err["quat_abs"] < REL_TOL, err
 
 
 # ---- fp16 storage (BASELINE config 4): v, q, rates, thrust in binary16, p and all arithmetic in fp32 ----
@@ -273,13 +272,14 @@ def test_object_list_collisions_fp32(params_1k):
         lane_model.set_objects(())
     first = lambda d: int(np.argmax(d)) if d.any() else -1      # noqa: E731
     for i in range(n):
-        assert abs(first(seq[i]) - first(g["done"][i])) <= 2, (i, first(seq[i]), first(g["done"][i]))
+        assert first(seq[i]) == first(g["done"][i]), (i, first(seq[i]), first(g["done"][i]))   # crash on the reference's step
     ok = ~g["done"].any(axis=1)                                  # compare end states of the survivors
     ref = np.concatenate([g["state"][:, -1], g["R"][:, -1].reshape(n, 9), g["prev_rates"][:, -1],
                           g["prev_thrust"][:, -1:]], axis=1)
     err = soa_vs_oracle(np.ascontiguousarray(s[:, np.flatnonzero(ok)]), ref[ok], int(ok.sum()))
-    # contact episodes amplify fp32 rounding (stiff, undamped springs): 1e-4 on position after 0.8 s
-    assert err["pos_comp"] < 1e-4 and err["quat_abs"] < 1e-5, err
+    # contact episodes amplify rounding (stiff, undamped springs): measured 4.1e-6 m after 0.8 s; the float64
+    # oracle itself moves by 1.7e-6 m under an fp32-ulp perturbation of its initial state
+    assert err["pos_comp"] < REL_TOL and err["quat_abs"] < REL_TOL, err
 
 
 def test_config1_10k_steps_with_kahan_compensation(params_1k):
