@@ -35,12 +35,13 @@ def main():
     params = load_params(fps=a.fps)                      # same params.yaml schema as the reference
 
     # world, as generators.py builds it from params["simulator"] (targets on a circular path, 5 cylinders)
-    targets = [Target(np.array([0.0, 0.0, 3.0]) + 0.1 * rng.standard_normal(3), 1.0,
-                      path={"radius": 25.0, "resolution": 5500})]
+    # (the reference's own constructor calls: generators.py:22-25, :33-37, simulator.py:58)
+    targets = [Target(np.array([0.0, 0.0, 3.0]) + 0.1 * rng.standard_normal(3), 1.0, 5,
+                      {"radius": 25.0, "resolution": 5500})]
     obstacles = [Cylinder(np.array([0.0, 0.0, 0.0]) + np.array([10.0, 10.0, 0.0]) * rng.standard_normal(3),
-                          abs(2.0 + 0.5 * rng.standard_normal()), abs(10.0 + 5.0 * rng.standard_normal()))
+                          abs(2.0 + 0.5 * rng.standard_normal()), abs(10.0 + 5.0 * rng.standard_normal()), 10, 25, random=True)
                  for _ in range(5)]
-    ground = Ground()
+    ground = Ground(size=60, resolution=50, random=True)
 
     drone = Drone(params, num_envs=a.drones, device="cuda:0")
     spread = rng.uniform([-20, -20, 5], [20, 20, 15], (a.drones, 3)).astype(np.float32)
