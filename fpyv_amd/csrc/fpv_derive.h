@@ -105,6 +105,8 @@ static inline int fpv_derive_constants(const fpv_params_t* P, FpvK* K, bool* big
     K->flags = P->flags;
     // |rates| <= max_rates always (clip + convex low-pass from 0), so the largest half-angle of one
     // step is known here; beyond pi/4 the short polynomial is no longer exact to fp32.
-    *big_angle = (0.5 * (M_PI / 180.0) * P->dt * P->max_rates) > 0.78;
+    const double half_max = 0.5 * (M_PI / 180.0) * P->dt * P->max_rates;
+    *big_angle = half_max > 0.78;
+    K->tiny_angle = half_max <= 0.03 ? 1u : 0u;
     return FPV_OK;
 }

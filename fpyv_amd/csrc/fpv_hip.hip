@@ -74,22 +74,40 @@ __device__ __forceinline__ T& row_at(T* row_base, uint32_t i)
 }
 #define ROW(st, r, ld) ((st) + (int64_t)(r) * (ld))
 
+// ---- experiment hooks (tools/exp/ab_variants.py builds variants with -DFPV_EXP_*; the shipped values are the defaults)
+#ifndef FPV_EXP_LD_NT
+#define FPV_EXP_LD_NT 0
+#endif
+#ifndef FPV_EXP_ST_NT
+#define FPV_EXP_ST_NT 0
+#endif
+#if FPV_EXP_LD_NT
+#define LDROW(st, r, ld, i) __builtin_nontemporal_load(&row_at(ROW(st, r, ld), i))
+#else
+#define LDROW(st, r, ld, i) row_at(ROW(st, r, ld), i)
+#endif
+#if FPV_EXP_ST_NT
+#define STROW(st, r, ld, i, v) __builtin_nontemporal_store((v), &row_at(ROW(st, r, ld), i))
+#else
+#define STROW(st, r, ld, i, v) (row_at(ROW(st, r, ld), i) = (v))
+#endif
+
 __device__ __forceinline__ void ld_drone(const float* __restrict__ st, int64_t ld, uint32_t i, FpvDroneState& s)
 {
-    s.px = row_at(ROW(st, FPV_PX, ld), i); s.py = row_at(ROW(st, FPV_PY, ld), i); s.pz = row_at(ROW(st, FPV_PZ, ld), i);
-    s.vx = row_at(ROW(st, FPV_VX, ld), i); s.vy = row_at(ROW(st, FPV_VY, ld), i); s.vz = row_at(ROW(st, FPV_VZ, ld), i);
-    s.q.w = row_at(ROW(st, FPV_QW, ld), i); s.q.x = row_at(ROW(st, FPV_QX, ld), i); s.q.y = row_at(ROW(st, FPV_QY, ld), i); s.q.z = row_at(ROW(st, FPV_QZ, ld), i);
-    s.rx = row_at(ROW(st, FPV_RX, ld), i); s.ry = row_at(ROW(st, FPV_RY, ld), i); s.rz = row_at(ROW(st, FPV_RZ, ld), i);
-    s.thrust = row_at(ROW(st, FPV_THRUST, ld), i);
+    s.px = LDROW(st, FPV_PX, ld, i); s.py = LDROW(st, FPV_PY, ld, i); s.pz = LDROW(st, FPV_PZ, ld, i);
+    s.vx = LDROW(st, FPV_VX, ld, i); s.vy = LDROW(st, FPV_VY, ld, i); s.vz = LDROW(st, FPV_VZ, ld, i);
+    s.q.w = LDROW(st, FPV_QW, ld, i); s.q.x = LDROW(st, FPV_QX, ld, i); s.q.y = LDROW(st, FPV_QY, ld, i); s.q.z = LDROW(st, FPV_QZ, ld, i);
+    s.rx = LDROW(st, FPV_RX, ld, i); s.ry = LDROW(st, FPV_RY, ld, i); s.rz = LDROW(st, FPV_RZ, ld, i);
+    s.thrust = LDROW(st, FPV_THRUST, ld, i);
 }
 
 __device__ __forceinline__ void st_drone(float* __restrict__ st, int64_t ld, uint32_t i, const FpvDroneState& s)
 {
-    row_at(ROW(st, FPV_PX, ld), i) = s.px; row_at(ROW(st, FPV_PY, ld), i) = s.py; row_at(ROW(st, FPV_PZ, ld), i) = s.pz;
-    row_at(ROW(st, FPV_VX, ld), i) = s.vx; row_at(ROW(st, FPV_VY, ld), i) = s.vy; row_at(ROW(st, FPV_VZ, ld), i) = s.vz;
-    row_at(ROW(st, FPV_QW, ld), i) = s.q.w; row_at(ROW(st, FPV_QX, ld), i) = s.q.x; row_at(ROW(st, FPV_QY, ld), i) = s.q.y; row_at(ROW(st, FPV_QZ, ld), i) = s.q.z;
-    row_at(ROW(st, FPV_RX, ld), i) = s.rx; row_at(ROW(st, FPV_RY, ld), i) = s.ry; row_at(ROW(st, FPV_RZ, ld), i) = s.rz;
-    row_at(ROW(st, FPV_THRUST, ld), i) = s.thrust;
+    STROW(st, FPV_PX, ld, i, s.px); STROW(st, FPV_PY, ld, i, s.py); STROW(st, FPV_PZ, ld, i, s.pz);
+    STROW(st, FPV_VX, ld, i, s.vx); STROW(st, FPV_VY, ld, i, s.vy); STROW(st, FPV_VZ, ld, i, s.vz);
+    STROW(st, FPV_QW, ld, i, s.q.w); STROW(st, FPV_QX, ld, i, s.q.x); STROW(st, FPV_QY, ld, i, s.q.y); STROW(st, FPV_QZ, ld, i, s.q.z);
+    STROW(st, FPV_RX, ld, i, s.rx); STROW(st, FPV_RY, ld, i, s.ry); STROW(st, FPV_RZ, ld, i, s.rz);
+    STROW(st, FPV_THRUST, ld, i, s.thrust);
 }
 
 typedef float fpv_v4f __attribute__((ext_vector_type(4)));

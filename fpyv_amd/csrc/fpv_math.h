@@ -71,7 +71,7 @@ struct FpvK {
     uint32_t flags;
     uint32_t r_wide;        // Racer: attitude increment in float64 (Racer.step as written: angle = omega per step)
     uint32_t r_pid_variant; // 0: racer_drone_test.PID.step, 1: components.PID.__call__
-    uint32_t _pad0;
+    uint32_t tiny_angle;    // 1: no step can turn by more than 0.03 rad of half-angle: two-term sin/cos suffice
     double r_ang_k_d;       // r_ang_k in double (the racer_omega_dt variant multiplies by the exact dt)
     FpvPidK<double> rd;     // rate-loop constants in float64 (Racer as written)
 };
@@ -105,10 +105,22 @@ FPV_HD void fpv_sincos_full(float x, float* s, float* c)
 #endif
 }
 
+// sin and cos for |x| <= 0.03 (half-angles of one step at dt <= 1/60 s and 200 deg/s): two terms each,
+// truncation x^4/120 < 7e-9 relative on sin and x^6/720 < 1e-12 on cos - below fp32 rounding.
+FPV_HD void fpv_sincos_tiny(float x, float* s, float* c)
+{
+    const float x2 = x * x;
+    *s = fmaf(x * x2, -1.6666667e-1f, x);
+    *c = fmaf(x2, fmaf(x2, 4.1666667e-2f, -0.5f), 1.0f);
+}
+
+// BIG: library range reduction (compile-time kernel choice); otherwise `tiny` (wave-uniform, from the
+// host-known bound on the half-angle) picks the two-term or the five-term polynomial
 template <bool BIG>
-FPV_HD void fpv_sincos(float x, float* s, float* c)
+FPV_HD void fpv_sincos(float x, bool tiny, float* s, float* c)
 {
     if (BIG) fpv_sincos_full(x, s, c);
+    else if (tiny) fpv_sincos_tiny(x, s, c);
     else fpv_sincos_small(x, s, c);
 }
 
@@ -452,15 +464,21 @@ FPV_HD FpvStepOut fpv_drone_step_lane(const FpvK& K, FpvDroneState& s, float a0,
     // spring force along +z; if ANY motor is below the plane the reference reports a crash and
     // returns before adding any force                                        components.py:198-214
     bool done = false;
-    float contact = 0.0f;
+    float mzg[4];
 #pragma unroll
     for (int m = 0; m < 4; ++m) {
-        const float mz = s.pz + fmaf(K.motor_x[m], R.r20, K.motor_y[m] * R.r21);
-        done = done || (mz < 0.0f);
-        const float d = mz - K.motor_radius;
-        if (d < 0.0f) contact += fmaf(-K.ground_k_m, d, -K.ground_c_m * s.vz);   // kinematics.py:56-59, normal = +z
+        mzg[m] = s.pz + fmaf(K.motor_x[m], R.r20, K.motor_y[m] * R.r21);
+        done = done || (mzg[m] < 0.0f);
     }
-    if ((K.flags & FPV_MATH_FLAG_GROUND) && !done) accz += contact;
+    if (K.flags & FPV_MATH_FLAG_GROUND) {                    // wave-uniform: the spring pass is skipped without the flag
+        float contact = 0.0f;
+#pragma unroll
+        for (int m = 0; m < 4; ++m) {
+            const float d = mzg[m] - K.motor_radius;
+            if (d < 0.0f) contact += fmaf(-K.ground_k_m, d, -K.ground_c_m * s.vz);   // kinematics.py:56-59, normal = +z
+        }
+        if (!done) accz += contact;
+    }
     if (OBJ) {                                               // general object_list replaces the ground-only pass
         float mxw[4], myw[4], mzw[4], ca[3];
 #pragma unroll
@@ -507,9 +525,10 @@ FPV_HD FpvStepOut fpv_drone_step_lane(const FpvK& K, FpvDroneState& s, float a0,
 
     // attitude: q <- q (x) conj(q_E)^2, q_E = qz(psi) qy(theta) qx(phi)     kinematics.py:27-30 (x2)
     float sr, cr, sp, cp, sy, cy;
-    fpv_sincos<BIG>(s.rx * K.half_k, &sr, &cr);
-    fpv_sincos<BIG>(s.ry * K.half_k, &sp, &cp);
-    fpv_sincos<BIG>(s.rz * K.half_k, &sy, &cy);
+    const bool tiny = K.tiny_angle != 0u;
+    fpv_sincos<BIG>(s.rx * K.half_k, tiny, &sr, &cr);
+    fpv_sincos<BIG>(s.ry * K.half_k, tiny, &sp, &cp);
+    fpv_sincos<BIG>(s.rz * K.half_k, tiny, &sy, &cy);
     const float ew = fmaf(cy * cp, cr, sy * sp * sr);
     const float ex = fmaf(cy * cp, sr, -(sy * sp * cr));
     const float ey = fmaf(cy * sp, cr, sy * cp * sr);

@@ -1108,3 +1108,35 @@ def test_c_abi_allgather_done_over_rccl(params_1k):
         L.fpv_comm_destroy(comm)
     bad = C.c_void_p()
     assert L.fpv_comm_create(ident, 2, 5, 0, C.byref(bad)) == -1 and not bad.value
+
+
+def test_integration_md_stub_runs_and_lands_on_the_reference(params_1k):
+    """The binding INTEGRATION.md shows a reference maintainer (src/utils/hip_drone.py) is executed as
+    written: Drone(params dict), reset, 1000 x step with the reference's arguments, against capture G2."""
+    import os
+    import re
+    import yaml
+    from conftest import REPO
+    from fpyv_amd.params import DEFAULT_PARAMS_PATH
+    txt = open(os.path.join(REPO, "INTEGRATION.md")).read()
+    code = re.search(r"```python\n(# src/utils/hip_drone\.py.*?)```", txt, re.S).group(1)
+    assert "..." not in code, "the stub must be complete"
+    ns = {}
+    exec(compile(code, "hip_drone.py", "exec"), ns)
+    with open(DEFAULT_PARAMS_PATH) as f:
+        params = yaml.safe_load(f)
+    params["simulator"]["fps"] = 1000
+    g = load_golden("g2_sin_4096")
+    k = 3
+    drone = ns["Drone"](params, num_envs=1, device=DEV)
+    drone.reset(position=np.array(params["drone"]["initial_position"]), velocity=np.array(params["drone"]["initial_velocity"]),
+                ypr=np.array(params["drone"]["initial_orientation"]))
+    for i in range(g["actions"].shape[0]):
+        RT, gyro, acc = drone.step(g["actions"][i, k], np.array([0, 0, 0]), [])
+    torch.cuda.synchronize()
+    ref = np.concatenate([g["state"][k:k + 1, -1], g["R"][k:k + 1, -1].reshape(1, 9), g["prev_rates"][k:k + 1, -1],
+                          g["prev_thrust"][k:k + 1, -1:]], axis=1)
+    assert_parity(soa_vs_oracle(drone.state.cpu().numpy(), ref, 1), REL_TOL, "INTEGRATION.md stub")
+    np.testing.assert_allclose(RT.cpu().numpy()[0], g["ret_RT"][k], atol=1e-5)
+    np.testing.assert_allclose(acc.cpu().numpy()[0], g["accel"][k, -1], rtol=1e-4, atol=1e-4)
+    assert not bool(drone.done)

@@ -1,0 +1,66 @@
+#!/usr/bin/env python3
+"""A/B builds of libfpv_hip.so that differ by -DFPV_EXP_* macros, in ONE process on the SAME buffers,
+interleaved (cdna_hip_programming.md 5.4 rule 24).  Variants are built here (hipcc cross-compiles) by
+`--build`, timed on the GPU box without flags.
+
+    python tools/exp/ab_variants.py --build            # in the build container
+    python tools/exp/ab_variants.py [--n 1048576]      # on the GPU box
+"""
+import argparse, ctypes as C, os, statistics, subprocess, sys
+HERE = os.path.dirname(os.path.abspath(__file__))
+REPO = os.path.dirname(os.path.dirname(HERE))
+sys.path.insert(0, REPO)
+VARIANTS = {
+    "base": [],
+    "ld_nt": ["-DFPV_EXP_LD_NT=1"],
+    "st_nt": ["-DFPV_EXP_ST_NT=1"],
+    "ld_st_nt": ["-DFPV_EXP_LD_NT=1", "-DFPV_EXP_ST_NT=1"],
+}
+ap = argparse.ArgumentParser()
+ap.add_argument("--build", action="store_true")
+ap.add_argument("--n", type=int, default=1 << 20)
+ap.add_argument("--rounds", type=int, default=8)
+ap.add_argument("--only", nargs="*", default=None)
+a = ap.parse_args()
+names = [k for k in VARIANTS if not a.only or k in a.only]
+if a.build:
+    for k in names:
+        out = os.path.join(HERE, f"libfpv_v_{k}.so")
+        subprocess.run(["/opt/rocm/bin/hipcc", "-O3", "--offload-arch=gfx950", "-ffp-contract=off", "-std=c++17", "-shared", "-fPIC",
+                        *VARIANTS[k], "-o", out, os.path.join(REPO, "fpyv_amd", "csrc", "fpv_hip.hip")], check=True)
+        print("built", out)
+    sys.exit(0)
+import torch
+from fpyv_amd import _lib, load_params, sticks
+dev = torch.device("cuda:0"); torch.zeros(1, device=dev)
+p = load_params(fps=1000, ceiling=100.0); cp = _lib.pack_params(p, auto_reset=True)
+n = a.n; ring = 32 if n <= (1 << 21) else 4
+acts = sticks.ema_noise_device(ring, n, dev)
+L, H = {}, {}
+for k in names:
+    l = C.CDLL(os.path.join(HERE, f"libfpv_v_{k}.so"))
+    l.fpv_create.argtypes = [C.c_void_p, C.c_int64, C.c_int, C.c_void_p]
+    l.fpv_rollout.argtypes = [C.c_void_p, C.c_void_p, C.c_int, C.c_int64, C.c_int64, C.c_void_p]
+    l.fpv_recommended_ld.argtypes = [C.c_int64]; l.fpv_recommended_ld.restype = C.c_int64
+    l.fpv_last_error.restype = C.c_char_p
+    h = C.c_void_p(); rc = l.fpv_create(C.byref(cp), n, 0, C.byref(h)); assert rc == 0, l.fpv_last_error()
+    L[k], H[k] = l, h
+ld = int(L[names[0]].fpv_recommended_ld(n))
+st = torch.zeros((14, ld), device=dev); rew = torch.zeros(n, device=dev); done = torch.zeros(n, dtype=torch.uint8, device=dev)
+b = _lib.FpvBuffers(); b.state, b.ld, b.reward, b.done = st.data_ptr(), ld, rew.data_ptr(), done.data_ptr()
+b.action = acts.data_ptr()
+def reset(): st.zero_(); st[2] = 10; st[3] = 1; st[6] = 1
+res = {k: [] for k in names}; fin = {}
+e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+reps = 8 if n <= (1 << 21) else 16
+for r in range(a.rounds):
+    for k in names:
+        reset(); torch.cuda.synchronize(); e0.record()
+        for rep in range(reps):
+            rc = L[k].fpv_rollout(H[k], C.byref(b), ring, n * 4, 0, None); assert rc == 0, L[k].fpv_last_error()
+        e1.record(); torch.cuda.synchronize()
+        if r: res[k].append(e0.elapsed_time(e1) * 1e3 / (reps * ring))
+        fin[k] = st.clone()
+for k in names:
+    med = statistics.median(res[k])
+    print(f"n={n} {k:12s}: median {med:8.3f} us  min {min(res[k]):8.3f} us   {133 * n / med / 1e3:8.1f} GB/s   bitwise==base {bool(torch.equal(fin[k], fin[names[0]]))}", flush=True)

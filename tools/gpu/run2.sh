@@ -12,6 +12,7 @@ timeout -k 10 300 python bench.py --racer omega_dt --no-cpu-baseline --steps 500
 timeout -k 10 300 python bench.py --force-dist --no-cpu-baseline --steps 5000 > $O/r2_bench_forcedist.json 2> $O/r2_bench_forcedist.err && \
 timeout -k 10 300 python bench.py --force-dist --api rollout --no-cpu-baseline --steps 5000 > $O/r2_bench_forcedist_rollout.json 2> $O/r2_bench_forcedist_rollout.err && \
 timeout -k 10 500 python tools/kernel_sweep.py --geom 1x128 1x256 --fp16 --noise --extras --racer --fused --rounds 5 --out $O/r2_sweep.json > $O/r2_sweep.log 2>&1 && \
+timeout -k 10 300 python tools/kernel_sweep.py --n 4096 --geom 1x128 --fused --graph --launches 256 --rounds 5 --out $O/r2_sweep_4096.json > $O/r2_sweep_4096.log 2>&1 && \
 timeout -k 10 300 rocprofv3 --kernel-trace --stats --output-format csv -d $O/prof_kt -- python3 bench.py --steps 2000 --warmup 200 --no-cpu-baseline --no-beyond-mall > $O/prof_kt.log 2>&1 && \
 timeout -k 10 300 rocprofv3 --kernel-trace --stats --output-format csv -d $O/prof_kt_variants -- python3 tools/kernel_sweep.py --geom 1x128 --fp16 --noise --extras --racer --fused --rounds 2 > $O/prof_kt_variants.log 2>&1 && \
 timeout -k 10 300 rocprofv3 --kernel-trace --pmc FETCH_SIZE --output-format csv -d $O/pmc_fetch -- python3 tools/pmc_probe.py > $O/pmc_fetch.log 2>&1 && \
@@ -25,4 +26,4 @@ try:
 except Exception as e: print(sys.argv[1], "ERR", e)
 PY
 done
-cat $O/r2_sweep.log | tail -50
+cat $O/r2_sweep.log | tail -50; cat $O/r2_sweep_4096.log | tail -6
