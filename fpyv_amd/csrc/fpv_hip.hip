@@ -160,6 +160,12 @@ __device__ __forceinline__ void emit_lane_outputs(const FpvBufD& B, uint32_t i, 
     }
 }
 
+// "These values are used here": makes the compiler complete the loads that produced them BEFORE a k-step
+// loop.  Without it the wait for the pre-loop state loads lands inside the loop, and because vmcnt retires
+// in order it also waits for the action prefetch issued a few instructions earlier - every iteration then
+// exposes a full memory latency (measured: 48 % VALU utilisation; PMC SQ_INSTS_VALU / time).
+__device__ __forceinline__ void fpv_settle(float x) { asm volatile("" ::"v"(x)); }
+
 // Per-step outputs of a k-step launch (fpv_step_n).  reward/done/done_bits go out every step when their
 // stride is non-zero, otherwise once after the last step (= what k single-step launches leave behind);
 // the episode accumulators live in registers for the k steps and touch memory once.
@@ -308,6 +314,12 @@ __global__ __launch_bounds__(BS) void fpv_drone_rollout_kernel(const FpvK K, con
     FpvStepOut o;
     o.done = false; o.reward = 0.0f; o.ax = o.ay = o.az = 0.0f;
     float av[4] = {0.f, 0.f, 0.f, 0.f};
+    fpv_settle(s.px); fpv_settle(s.py); fpv_settle(s.pz); fpv_settle(s.vx); fpv_settle(s.vy); fpv_settle(s.vz);
+    fpv_settle(s.q.w); fpv_settle(s.q.x); fpv_settle(s.q.y); fpv_settle(s.q.z);
+    fpv_settle(s.rx); fpv_settle(s.ry); fpv_settle(s.rz); fpv_settle(s.thrust);
+    if (NOISE) { fpv_settle(ns[0]); fpv_settle(ns[1]); fpv_settle(ns[2]); fpv_settle(ns[3]); }
+    if (KAHAN) { for (int k = 0; k < 6; ++k) fpv_settle(kc[k]); }
+    if (out.track) { fpv_settle(out.ep_r); fpv_settle(__int_as_float(out.ep_l)); }
     for (int t = 0; t < R.k; ++t) {
         av[0] = a_next.x; av[1] = a_next.y; av[2] = a_next.z; av[3] = a_next.w;
         if (has_action && R.action_stride && t + 1 < R.k) {
@@ -483,6 +495,10 @@ __global__ __launch_bounds__(BS) void fpv_drone_rollout_h_kernel(const FpvK K, c
         const float* ap = reinterpret_cast<const float*>(B.action);
         float4 a_next = ld_action(reinterpret_cast<const float4*>(ap), i);
         FpvHalfState h;
+        fpv_settle(s.px); fpv_settle(s.py); fpv_settle(s.pz); fpv_settle(s.vx); fpv_settle(s.vy); fpv_settle(s.vz);
+        fpv_settle(s.q.w); fpv_settle(s.q.x); fpv_settle(s.q.y); fpv_settle(s.q.z);
+        fpv_settle(s.rx); fpv_settle(s.ry); fpv_settle(s.rz); fpv_settle(s.thrust);
+        if (out.track) { fpv_settle(out.ep_r); fpv_settle(__int_as_float(out.ep_l)); }
         for (int t = 0; t < R.k; ++t) {
             const float4 a = a_next;
             if (R.action_stride && t + 1 < R.k) { ap += R.action_stride; a_next = ld_action(reinterpret_cast<const float4*>(ap), i); }
@@ -574,6 +590,15 @@ __global__ __launch_bounds__(BS) void fpv_racer_rollout_kernel(const FpvK K, con
     RollOut out(B, R, i, true);
     const float* ap = reinterpret_cast<const float*>(B.action);
     float4 a_next = ld_action(reinterpret_cast<const float4*>(ap), i);
+    fpv_settle(s.px); fpv_settle(s.py); fpv_settle(s.pz); fpv_settle(s.vx); fpv_settle(s.vy); fpv_settle(s.vz);
+    fpv_settle(s.q.w); fpv_settle(s.q.x); fpv_settle(s.q.y); fpv_settle(s.q.z); fpv_settle(s.first);
+#pragma unroll
+    for (int k = 0; k < 3; ++k) {
+        fpv_settle(s.w[k]); fpv_settle(s.ierr[k]); fpv_settle(s.lerr[k]);
+        if (WIDE) { fpv_settle(s.wlo[k]); fpv_settle(s.ilo[k]); }
+        if (PIDV) fpv_settle(s.dflt[k]);
+    }
+    if (out.track) { fpv_settle(out.ep_r); fpv_settle(__int_as_float(out.ep_l)); }
     for (int t = 0; t < R.k; ++t) {
         const float4 a = a_next;
         if (R.action_stride && t + 1 < R.k) { ap += R.action_stride; a_next = ld_action(reinterpret_cast<const float4*>(ap), i); }

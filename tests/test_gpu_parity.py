@@ -1140,3 +1140,41 @@ def test_integration_md_stub_runs_and_lands_on_the_reference(params_1k):
     np.testing.assert_allclose(RT.cpu().numpy()[0], g["ret_RT"][k], atol=1e-5)
     np.testing.assert_allclose(acc.cpu().numpy()[0], g["accel"][k, -1], rtol=1e-4, atol=1e-4)
     assert not bool(drone.done)
+
+
+def test_plain_c_host_through_the_c_abi(params_1k, tmp_path):
+    """The boundary is a C ABI: examples/c_host/main.c - plain C, hipMalloc'd buffers, no Python or torch in
+    the process - is compiled here with gcc against include/fpv_abi.h and libfpv_hip.so, runs config 2
+    (4096 drones, sinusoidal sticks) as k fpv_step launches and as one fpv_step_n launch, and must
+    reproduce the Python host's result bit for bit."""
+    import ctypes as C
+    import os
+    import subprocess
+    from conftest import REPO
+    n, k = 4096, 200
+    exe = str(tmp_path / "c_host")
+    subprocess.run(["gcc", "-O2", "-I", os.path.join(REPO, "include"), "-I", "/opt/rocm/include", "-D__HIP_PLATFORM_AMD__",
+                    os.path.join(REPO, "examples", "c_host", "main.c"), "-L", os.path.join(REPO, "fpyv_amd"), "-lfpv_hip",
+                    "-L", "/opt/rocm/lib", "-lamdhip64", "-Wl,-rpath," + os.path.join(REPO, "fpyv_amd"),
+                    "-Wl,-rpath,/opt/rocm/lib", "-o", exe], check=True)
+    acts = sticks.sinusoid(k, n, params_1k.dt)
+    cp = _lib.pack_params(params_1k)
+    (tmp_path / "params.bin").write_bytes(bytes(C.string_at(C.addressof(cp), C.sizeof(cp))))
+    (tmp_path / "actions.bin").write_bytes(acts.tobytes())
+    env = _drone_batch(params_1k, n, with_accel=False)
+    env.reset()
+    env.rollout(torch.from_numpy(acts).to(DEV), fused=False)
+    torch.cuda.synchronize()
+    want = env.state.cpu().numpy()
+    rows, ld = want.shape
+    for mode in ("steps", "fused"):
+        out = tmp_path / f"state_{mode}.bin"
+        r = subprocess.run([exe, str(tmp_path / "params.bin"), str(tmp_path / "actions.bin"), str(n), str(k), str(out)]
+                           + (["fused"] if mode == "fused" else []), capture_output=True, text=True, timeout=300)
+        assert r.returncode == 0, r.stderr
+        raw = np.fromfile(out, dtype=np.uint8)
+        got = raw[:rows * ld * 4].view(np.float32).reshape(rows, ld)
+        rew = raw[rows * ld * 4:rows * ld * 4 + n * 4].view(np.float32)
+        done = raw[rows * ld * 4 + n * 4:]
+        assert np.array_equal(got[:, :n].view(np.uint32), want[:, :n].view(np.uint32)), mode
+        assert np.array_equal(rew.view(np.uint32), env.reward.cpu().numpy().view(np.uint32)) and not done.any()
