@@ -26,7 +26,7 @@ names = [k for k in VARIANTS if not a.only or k in a.only]
 if a.build:
     for k in names:
         out = os.path.join(HERE, f"libfpv_v_{k}.so")
-        subprocess.run(["/opt/rocm/bin/hipcc", "-O3", "--offload-arch=gfx950", "-ffp-contract=off", "-std=c++17", "-shared", "-fPIC",
+        subprocess.run(["/opt/rocm/bin/hipcc", "-O3", "--offload-arch=gfx950", "-ffp-contract=off", "-fno-slp-vectorize", "-std=c++17", "-shared", "-fPIC",
                         *VARIANTS[k], "-o", out, os.path.join(REPO, "fpyv_amd", "csrc", "fpv_hip.hip")], check=True)
         print("built", out)
     sys.exit(0)

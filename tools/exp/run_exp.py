@@ -12,7 +12,7 @@ def build():
     so = os.path.join(HERE, "libfpv_exp.so")
     src = os.path.join(HERE, "exp_kernels.hip")
     if not os.path.isfile(so) or os.path.getmtime(so) < os.path.getmtime(src):
-        subprocess.run(["/opt/rocm/bin/hipcc", "-O3", "--offload-arch=gfx950", "-ffp-contract=off", "-std=c++17", "-shared", "-fPIC",
+        subprocess.run(["/opt/rocm/bin/hipcc", "-O3", "--offload-arch=gfx950", "-ffp-contract=off", "-fno-slp-vectorize", "-std=c++17", "-shared", "-fPIC",
                         "-o", so, src], check=True)
     return so
 

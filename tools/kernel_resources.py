@@ -11,7 +11,7 @@ SRC = os.path.join(REPO, "fpyv_amd", "csrc", "fpv_hip.hip")
 
 
 def main():
-    cmd = ["/opt/rocm/bin/hipcc", "-O3", "--offload-arch=gfx950", "-ffp-contract=off", "-std=c++17", "-shared", "-fPIC",
+    cmd = ["/opt/rocm/bin/hipcc", "-O3", "--offload-arch=gfx950", "-ffp-contract=off", "-fno-slp-vectorize", "-std=c++17", "-shared", "-fPIC",
            "-Rpass-analysis=kernel-resource-usage", "-o", "/tmp/_fpv_res.so", SRC]
     out = subprocess.run(cmd, capture_output=True, text=True).stderr
     rows = []
