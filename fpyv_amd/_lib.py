@@ -13,7 +13,7 @@ from typing import Optional
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, "libfpv_hip.so")
 
-FPV_ABI_VERSION = 2
+FPV_ABI_VERSION = 3
 FPV_OK = 0
 FPV_MODE_DRONE, FPV_MODE_RACER = 0, 1
 FPV_DRONE_ROWS, FPV_RACER_ROWS = 14, 29
@@ -101,7 +101,7 @@ class FpvBuffers(C.Structure):
         ("ep_length", C.c_void_p), ("last_return", C.c_void_p), ("last_length", C.c_void_p),
         ("wind", C.c_float * 3), ("rounding_seed", C.c_uint32), ("state_h", C.c_void_p),
         ("pos_comp", C.c_void_p), ("noise_state", C.c_void_p), ("action_out", C.c_void_p), ("action_ld", C.c_int64), ("objects", C.c_void_p), ("obs_aos", C.c_void_p),
-        ("done_bits_stride", C.c_int64),
+        ("done_bits_stride", C.c_int64), ("rotation_override", C.c_void_p), ("thrust_override", C.c_void_p),
     ]
 
 

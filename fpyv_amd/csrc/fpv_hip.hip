@@ -58,6 +58,8 @@ struct FpvBufD {
     FpvObjects objs;       // the step's object_list (count 0 = none); only the OBJ instantiation reads it
     uint16_t* state_h;     // FPV_FLAG_FP16_STATE: [5][ld] half2 pair rows + [ld] thrust halves
     uint32_t seed;         // stochastic-rounding seed of this launch
+    const float* rot_over;     // [n][9] guidance override of the attitude (Drone.step rotation_matrix=) or null
+    const float* thrust_over;  // [n] thrust_force= of the same call (NaN = this drone is not overridden)
 };
 
 // k-step launches (fpv_step_n): step t reads its action at + t*action_stride floats and writes
@@ -230,9 +232,13 @@ __device__ __forceinline__ float4 apply_stick_noise(const FpvK& K, const FpvBufD
     return r;
 }
 
-template <int BS, int DPL, bool BIG, bool NOISE = false, bool OBJ = false, bool KAHAN = false>
+// OVR: the guidance call shape Drone.step(..., rotation_matrix=R, thrust_force=f) (components.py:230-232,
+// simulator.py:110): nine more floats and the thrust force per drone, read with a 36-byte lane stride - the
+// matrices arrive in the caller's [n][3][3] layout; this is the closed-loop guidance path, not the headline one.
+template <int BS, int DPL, bool BIG, bool NOISE = false, bool OBJ = false, bool KAHAN = false, bool OVR = false>
 __global__ __launch_bounds__(BS) void fpv_drone_step_kernel(const FpvK K, const FpvBufD B, const int64_t n)
 {
+    static_assert(!OVR || DPL == 1, "the guidance override is built for one drone per lane");
     const uint32_t base = blockIdx.x * (uint32_t)(BS * DPL) + threadIdx.x;    // n <= 2^28 (fpv_create)
     // one drone per lane: lanes past the end leave at once (a ballot over the remaining lanes still
     // yields the right done bits: exited lanes contribute 0, and a wave whose lane 0 is gone is empty)
@@ -240,6 +246,7 @@ __global__ __launch_bounds__(BS) void fpv_drone_step_kernel(const FpvK K, const 
     FpvDroneState s[DPL];
     float4 a[DPL];
     bool live[DPL];
+    float ro[9] = {1.f, 0.f, 0.f, 0.f, 1.f, 0.f, 0.f, 0.f, 1.f}, to = 0.0f;
     // issue every load of every drone of this lane before the first use
 #pragma unroll
     for (int j = 0; j < DPL; ++j) {
@@ -249,6 +256,11 @@ __global__ __launch_bounds__(BS) void fpv_drone_step_kernel(const FpvK K, const 
             a[j] = (!NOISE || B.action) ? ld_action_any(B.action, B.action_ld, i) : make_float4(0.f, 0.f, 0.f, 0.f);
             ld_drone(B.state, B.ld, i, s[j]);
             if (NOISE) a[j] = apply_stick_noise(K, B, i, a[j]);
+            if (OVR) {
+#pragma unroll
+                for (int k = 0; k < 9; ++k) ro[k] = B.rot_over[(int64_t)i * 9 + k];     // 64-bit index: 36 * i can pass 2^32
+                to = B.thrust_over[i];
+            }
         }
     }
     // keep every vector load ahead of the scalar (kernarg) loads of the physics constants: without
@@ -267,7 +279,7 @@ __global__ __launch_bounds__(BS) void fpv_drone_step_kernel(const FpvK K, const 
                 for (int k = 0; k < 6; ++k) kc[k] = row_at(ROW(B.pos_comp, k, B.ld), i);
             }
             o = fpv_drone_step_lane<BIG, OBJ>(K, s[j], a[j].x, a[j].y, a[j].z, a[j].w, B.wx, B.wy, B.wz, &B.objs,
-                                              KAHAN ? kc : nullptr);
+                                              KAHAN ? kc : nullptr, OVR ? ro : nullptr, to);
             if (KAHAN) {
                 const bool rst = (K.flags & FPV_FLAG_AUTO_RESET) && o.done;
 #pragma unroll
@@ -784,6 +796,16 @@ int check_buffers(const fpv_env* h, const fpv_buffers_t* b, bool need_action)  /
         if (!b->state_h) return fail(FPV_EINVAL, "FPV_FLAG_FP16_STATE needs fpv_buffers_t.state_h");
         if ((uintptr_t)b->state_h & 7) return fail(FPV_EALIGN, "state_h must be 8-byte aligned");
     }
+    if ((b->rotation_override == nullptr) != (b->thrust_override == nullptr))
+        return fail(FPV_EINVAL, "rotation_override and thrust_override must be given together (Drone.step: thrust_force is only "
+                                "used with rotation_matrix, components.py:230-232)");
+    if (b->rotation_override) {
+        if (h->mode != FPV_MODE_DRONE || (h->K.flags & (FPV_FLAG_FP16_STATE | FPV_FLAG_STICK_NOISE)) || b->obs_aos || b->pos_comp)
+            return fail(FPV_EINVAL, "the guidance override needs drone mode with fp32 state, caller-supplied sticks, and no "
+                                    "obs_aos / pos_comp (objects and FPV_FLAG_GROUND are fine)");
+        if (((uintptr_t)b->rotation_override & 3) || ((uintptr_t)b->thrust_override & 3))
+            return fail(FPV_EALIGN, "rotation_override / thrust_override must be 4-byte aligned");
+    }
     if ((b->ep_return == nullptr) != (b->ep_length == nullptr))
         return fail(FPV_EINVAL, "ep_return and ep_length must be given together");
     if ((b->last_return || b->last_length) && !b->ep_return)
@@ -804,6 +826,7 @@ FpvBufD to_device_view(const fpv_buffers_t* b)
     d.pos_comp = b->pos_comp;
     d.noise_state = b->noise_state; d.action_out = reinterpret_cast<float4*>(b->action_out); d.step = 0;
     d.action_ld = b->action_ld;
+    d.rot_over = b->rotation_override; d.thrust_over = b->thrust_override;
     d.objs.count = 0;
     if (b->objects) {
         d.objs.count = b->objects->count;
@@ -919,9 +942,15 @@ KernelChoice choose_kernel(const fpv_env* h, const FpvBufD& d)
                                  : (big ? fpv_drone_step_aos_kernel<128, true> : fpv_drone_step_aos_kernel<128, false>);
     } else {
         const bool noise = (h->K.flags & FPV_FLAG_STICK_NOISE) != 0, obj = d.objs.count > 0, kahan = d.pos_comp != nullptr;
-        const int dpl = (noise || obj || kahan) ? 1 : h->dpl;
+        const int dpl = (noise || obj || kahan || d.rot_over) ? 1 : h->dpl;
         per_block = (int64_t)h->block * dpl;
-        c.func = big ? drone_kernel<true>(h->block, dpl, noise, obj, kahan) : drone_kernel<false>(h->block, dpl, noise, obj, kahan);
+        if (d.rot_over) {                   // guidance override: plain or object-list kernel, 128 threads (check_buffers)
+            c.block = 128; per_block = 128;
+            c.func = obj ? (big ? fpv_drone_step_kernel<128, 1, true, false, true, false, true> : fpv_drone_step_kernel<128, 1, false, false, true, false, true>)
+                         : (big ? fpv_drone_step_kernel<128, 1, true, false, false, false, true> : fpv_drone_step_kernel<128, 1, false, false, false, false, true>);
+        } else {
+            c.func = big ? drone_kernel<true>(h->block, dpl, noise, obj, kahan) : drone_kernel<false>(h->block, dpl, noise, obj, kahan);
+        }
     }
     c.grid = (unsigned)((h->n + per_block - 1) / per_block);
     return c;
@@ -1092,6 +1121,7 @@ int fpv_rollout(fpv_handle_t h, const fpv_buffers_t* b, int k, int64_t action_st
     if (rc != FPV_OK) return rc;
     if (k < 0) return fail(FPV_EINVAL, "k must be >= 0");
     if (action_stride % 4) return fail(FPV_EALIGN, "action_stride must keep 16-byte alignment");
+    if (b->rotation_override) return fail(FPV_EINVAL, "the guidance override is a per-step input: use fpv_step");
     if ((rc = bind_device(h)) != FPV_OK) return rc;
     FpvBufD d = to_device_view(b);
     const float* a0 = b->action;
@@ -1125,6 +1155,7 @@ int fpv_step_n(fpv_handle_t h, const fpv_buffers_t* b, int k, int64_t action_str
     if (k == 0) return FPV_OK;
     if (action_stride % 4) return fail(FPV_EALIGN, "action_stride must keep 16-byte alignment");
     if (b->obs_aos) return fail(FPV_EINVAL, "fpv_step_n does not write obs_aos rows (a per-step observation is a closed-loop need: use fpv_step)");
+    if (b->rotation_override) return fail(FPV_EINVAL, "the guidance override is a per-step input: use fpv_step");
     if ((rc = bind_device(h)) != FPV_OK) return rc;
     FpvBufD d = to_device_view(b);
     d.step = h->launches;
@@ -1176,6 +1207,7 @@ int fpv_rollout_graph(fpv_handle_t h, const fpv_buffers_t* b, int k, int64_t act
     if (h->K.flags & (FPV_FLAG_STICK_NOISE | FPV_FLAG_FP16_STATE))
         return fail(FPV_EINVAL, "fpv_rollout_graph replays frozen kernel arguments; stick noise and fp16 state need the "
                                 "per-launch step index - use fpv_step_n or fpv_rollout");
+    if (b->rotation_override) return fail(FPV_EINVAL, "the guidance override is a per-step input: use fpv_step");
     if ((rc = bind_device(h)) != FPV_OK) return rc;
     const FpvBufD d0 = to_device_view(b);
     // SHAPE of the graph: everything that selects kernels, grids and non-pointer arguments

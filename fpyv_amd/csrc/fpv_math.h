@@ -155,6 +155,29 @@ FPV_HD FpvQuat fpv_quat_advance(FpvQuat q, float dw, float dx, float dy, float d
     return n;
 }
 
+// Unit quaternion (w,x,y,z) of a rotation matrix m (row-major, body -> world): Shepperd's branch on the largest of
+// (trace, m00, m11, m22), then one normalisation.  Used by the guidance override of Drone.step, which REPLACES the
+// attitude by a caller-supplied matrix (components.py:230-231); the matrix is expected to be a rotation (the
+// reference builds it from normalised cross products, components.py:283-300), a small loss of orthonormality is
+// absorbed by the normalisation.
+FPV_HD FpvQuat fpv_quat_from_rot(const float m[9])
+{
+    const float tr = m[0] + m[4] + m[8];
+    FpvQuat q;
+    if (tr > 0.0f) {
+        q.w = 1.0f + tr; q.x = m[7] - m[5]; q.y = m[2] - m[6]; q.z = m[3] - m[1];
+    } else if (m[0] >= m[4] && m[0] >= m[8]) {
+        q.w = m[7] - m[5]; q.x = 1.0f + m[0] - m[4] - m[8]; q.y = m[1] + m[3]; q.z = m[2] + m[6];
+    } else if (m[4] >= m[8]) {
+        q.w = m[2] - m[6]; q.x = m[1] + m[3]; q.y = 1.0f + m[4] - m[0] - m[8]; q.z = m[5] + m[7];
+    } else {
+        q.w = m[3] - m[1]; q.x = m[2] + m[6]; q.y = m[5] + m[7]; q.z = 1.0f + m[8] - m[0] - m[4];
+    }
+    const float inv = 1.0f / sqrtf(fmaf(q.w, q.w, fmaf(q.x, q.x, fmaf(q.y, q.y, q.z * q.z))));
+    q.w *= inv; q.x *= inv; q.y *= inv; q.z *= inv;
+    return q;
+}
+
 struct FpvDroneState {
     float px, py, pz, vx, vy, vz;
     FpvQuat q;
@@ -429,7 +452,7 @@ FPV_HD bool fpv_collide_objects(const FpvK& K, const FpvObjects& T, const float 
 template <bool BIG, bool OBJ = false, bool OUT = true>
 FPV_HD FpvStepOut fpv_drone_step_lane(const FpvK& K, FpvDroneState& s, float a0, float a1, float a2, float a3,
                                       float wx, float wy, float wz, const FpvObjects* objs = nullptr,
-                                      float* kahan = nullptr)
+                                      float* kahan = nullptr, const float* rot_over = nullptr, float thrust_over = 0.0f)
 {
     // (1)-(2) stick -> rate command (deg/s), clipped, low-passed          components.py:185-189
     const float c0 = fminf(fmaxf(-a0 * K.max_rates, -K.max_rates), K.max_rates);
@@ -441,6 +464,15 @@ FPV_HD FpvStepOut fpv_drone_step_lane(const FpvK& K, FpvDroneState& s, float a0,
     // (3) thrust cubic (Horner in the stick, no clamp), low-passed          components.py:136,:192-194
     const float poly = fmaf(fmaf(fmaf(K.d3, a3, K.d2), a3, K.d1), a3, K.d0);
     s.thrust = fmaf(poly, K.kt, s.thrust * K.omkt);
+    // guidance override (components.py:230-232): AFTER action2force has advanced prev_rates / prev_thrust the
+    // attitude is replaced by the caller's rotation_matrix and the thrust becomes thrust_force * R[:,2]; drag, the
+    // motor positions and the attitude increment then start from the new attitude.  A NaN thrust_force leaves
+    // this drone alone (the reference's `rotation_matrix is None` for one drone of a batch).
+    float thrust_now = s.thrust;
+    if (rot_over && thrust_over == thrust_over) {
+        s.q = fpv_quat_from_rot(rot_over);
+        thrust_now = thrust_over;
+    }
 
     const FpvRot R = fpv_rot(s.q);                                         // PRE-update attitude
 
@@ -454,7 +486,7 @@ FPV_HD FpvStepOut fpv_drone_step_lane(const FpvK& K, FpvDroneState& s, float a0,
     const float fy = -K.kdrag_m[1] * by * speed;
     const float fz = -K.kdrag_m[2] * bz * speed;
     // (4) thrust along body z (third column), gravity; everything already divided by m
-    const float tm = s.thrust * K.inv_mass;
+    const float tm = thrust_now * K.inv_mass;
     float accx = fmaf(R.r00, fx, fmaf(R.r01, fy, fmaf(R.r02, fz, tm * R.r02)));
     float accy = fmaf(R.r10, fx, fmaf(R.r11, fy, fmaf(R.r12, fz, tm * R.r12)));
     float accz = fmaf(R.r20, fx, fmaf(R.r21, fy, fmaf(R.r22, fz, fmaf(tm, R.r22, -K.g))));

@@ -436,14 +436,22 @@ class DroneBatch(_Batch):
              return_imu: bool = True):
         """Drone.step for every drone.  `object_list` holds up to 8 analytic collision objects
         (fpyv_amd.objects.Ground / Cylinder / Target, or raw (type, x, y, z, radius, height) rows) in
-        the reference's list order; the guidance overrides `rotation_matrix` / `thrust_force`
-        (components.py:230-232) are not supported."""
+        the reference's list order.
+
+        `rotation_matrix` ([3,3] or [num_envs,3,3], body -> world) with `thrust_force` (scalar or [num_envs],
+        newtons) is the guidance call of simulator.py:110 (components.py:230-232): the sticks still advance
+        prev_rates / prev_thrust, then the attitude is REPLACED by the matrix and the thrust is
+        thrust_force * R[:,2].  A NaN thrust_force entry leaves that drone un-overridden.  Like the
+        reference, `thrust_force` without `rotation_matrix` is ignored."""
         if action is None and not self.stick_noise:
             raise ValueError("action=None reads a physical joystick in the reference; pass stick values")
-        if rotation_matrix is not None or thrust_force is not None:
-            raise NotImplementedError("guidance overrides (rotation_matrix=, thrust_force=) are not supported")
+        self._set_override(rotation_matrix, thrust_force)
         self._set_objects(object_list)
-        self._step_raw(action, wind_velocity_vector)
+        try:
+            self._step_raw(action, wind_velocity_vector)
+        finally:
+            if rotation_matrix is not None:
+                self._buf.rotation_override = self._buf.thrust_override = None
         if not return_imu:
             return None
         R = self.rotation_matrix
@@ -451,6 +459,28 @@ class DroneBatch(_Batch):
         gyro = euler_zyx_matrix(rates)            # deg/s values used as radians, as the reference does (:247)
         acc = self.accel[:, :self.n].t() if self.accel is not None else None
         return R.transpose(-1, -2), gyro, acc
+
+    def _set_override(self, rotation_matrix, thrust_force) -> None:
+        if rotation_matrix is None:
+            return                                   # components.py:230: thrust_force alone changes nothing
+        if thrust_force is None:
+            raise TypeError("rotation_matrix= needs thrust_force= (kinematics.thrust_vector(None, R) raises in the reference)")
+        f32 = dict(dtype=torch.float32, device=self.device)
+        R = torch.as_tensor(np.asarray(rotation_matrix, dtype=np.float32) if not torch.is_tensor(rotation_matrix)
+                            else rotation_matrix, **f32)
+        if R.shape == (3, 3):
+            R = R.expand(self.n, 3, 3)
+        if R.shape != (self.n, 3, 3):
+            raise ValueError(f"rotation_matrix must be [3, 3] or [{self.n}, 3, 3], got {tuple(R.shape)}")
+        f = torch.as_tensor(np.asarray(thrust_force, dtype=np.float32) if not torch.is_tensor(thrust_force)
+                            else thrust_force, **f32).reshape(-1)
+        if f.numel() == 1:
+            f = f.expand(self.n)
+        if f.shape != (self.n,):
+            raise ValueError(f"thrust_force must be a scalar or [{self.n}], got {tuple(f.shape)}")
+        self._override_keep = (R.reshape(self.n, 9).contiguous(), f.contiguous())
+        self._buf.rotation_override = self._override_keep[0].data_ptr()
+        self._buf.thrust_override = self._override_keep[1].data_ptr()
 
     @property
     def prev_rates(self) -> torch.Tensor:

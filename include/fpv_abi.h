@@ -26,7 +26,7 @@
 extern "C" {
 #endif
 
-#define FPV_ABI_VERSION 2
+#define FPV_ABI_VERSION 3
 
 enum {
     FPV_OK = 0,
@@ -179,6 +179,14 @@ typedef struct fpv_buffers {
                                 (components.py:247-248) gathered in one row; drone mode, fp32 state only */
     int64_t done_bits_stride;/* fpv_rollout / fpv_step_n: step t writes its bit mask at done_bits + t*done_bits_stride
                                 words (>= ceil(n/64)); 0 = every step overwrites the same mask */
+    const float* rotation_override; /* [n][9] row-major body->world rotation matrices, or NULL: the guidance call shape
+                                Drone.step(..., rotation_matrix=R, thrust_force=f) (components.py:230-232, simulator.py:110):
+                                after action2force has advanced prev_rates / prev_thrust from the sticks, the attitude is
+                                REPLACED by R and the thrust becomes f * R[:,2]; drag, motor positions, collisions and the
+                                attitude increment of the step start from R.  fpv_step only; drone mode, fp32 state,
+                                caller-supplied sticks; combines with objects / FPV_FLAG_GROUND */
+    const float* thrust_override;   /* [n] thrust_force [N] of the same call; required with rotation_override.  A NaN entry
+                                leaves that drone un-overridden (its own attitude and low-passed thrust) */
 } fpv_buffers_t;
 
 typedef struct fpv_env* fpv_handle_t;
@@ -209,7 +217,8 @@ void fpv_destroy(fpv_handle_t h);
 int fpv_reset(fpv_handle_t h, const fpv_buffers_t* b, const uint8_t* mask, const float* position,
               const float* velocity, const float* ypr_deg, void* stream);
 
-/* Replaces one Drone.step (components.py:220-248, object_list == []) / Racer.step (:95-103) per drone. */
+/* Replaces one Drone.step (components.py:220-248; object_list via fpv_buffers_t.objects, the guidance arguments
+ * rotation_matrix= / thrust_force= via rotation_override / thrust_override) / Racer.step (:95-103) per drone. */
 int fpv_step(fpv_handle_t h, const fpv_buffers_t* b, void* stream);
 
 /* k consecutive steps, one launch each, with no host work in between: step t reads

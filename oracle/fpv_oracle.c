@@ -55,9 +55,10 @@ static void rotate_body_by_rates(double* R, const double rates[3], double dt)
 
 static inline double clipd(double x, double lo, double hi) { return x < lo ? lo : (x > hi ? hi : x); }
 
-/* src/utils/components.py:220-248 (Drone.step) with object_list == [] and no guidance override. */
-void fpvo_drone_step(const fpvo_params* P, double* s, const double action[4], const double wind[3],
-                     double accel_out[3], uint8_t* done_out)
+/* src/utils/components.py:220-248 (Drone.step).  rotation_override (row-major 3x3, or NULL) and thrust_force
+ * are the guidance arguments rotation_matrix= / thrust_force= (:230-232). */
+void fpvo_drone_step_guided(const fpvo_params* P, double* s, const double action[4], const double wind[3],
+                            const double* rotation_override, double thrust_force, double accel_out[3], uint8_t* done_out)
 {
     double* p = s;
     double* v = s + 3;
@@ -79,7 +80,13 @@ void fpvo_drone_step(const fpvo_params* P, double* s, const double action[4], co
     const double T = poly * P->thrust_transition_rate + *prev_thrust * (1 - P->thrust_transition_rate);
     *prev_thrust = T;
     /* kinematics.py:48-49: thrust along the third COLUMN of the pre-update R */
-    const double thrust[3] = {R[2] * T, R[5] * T, R[8] * T};
+    double thrust[3] = {R[2] * T, R[5] * T, R[8] * T};
+    /* components.py:230-232: `if rotation_matrix is not None`: the attitude is replaced (prev_rates / prev_thrust
+     * above keep the values derived from the sticks) and the thrust vector is rebuilt from thrust_force */
+    if (rotation_override) {
+        for (int i = 0; i < 9; ++i) R[i] = rotation_override[i];
+        thrust[0] = R[2] * thrust_force; thrust[1] = R[5] * thrust_force; thrust[2] = R[8] * thrust_force;
+    }
 
     /* kinematics.py:33-38: body-frame quadratic drag; wind is ADDED to the velocity */
     const double vs[3] = {v[0] + wind[0], v[1] + wind[1], v[2] + wind[2]};
@@ -194,6 +201,12 @@ void fpvo_drone_step(const fpvo_params* P, double* s, const double action[4], co
         for (int i = 0; i < 3; ++i)
             accel_out[i] = R[3 * i + 0] * acc[0] + R[3 * i + 1] * acc[1] + R[3 * i + 2] * acc[2];
     if (done_out) *done_out = done;
+}
+
+void fpvo_drone_step(const fpvo_params* P, double* s, const double action[4], const double wind[3],
+                     double accel_out[3], uint8_t* done_out)
+{
+    fpvo_drone_step_guided(P, s, action, wind, 0, 0.0, accel_out, done_out);
 }
 
 /* Drones are independent, so the batch is cut into contiguous tiles of FPVO_TILE drones; each thread

@@ -365,6 +365,59 @@ def main():
          clips=np.array([clip12["integral_clip"], clip12["min_output"], clip12["max_output"], clip12["derivative_transition_rate"]]),
          **stack([run_racer_cpid(a)]))
 
+    # ---- G13: the guidance call shape Drone.step(..., rotation_matrix=R, thrust_force=f) (components.py:230-232,
+    # simulator.py:110).  R comes from the reference's own Euler builder (helper_functions.py:39-44), rounded through
+    # float32 like every other input; a NaN thrust_force marks the steps stepped WITHOUT the override (the gamepad
+    # button of simulator.py:104-110 released).  Case 0: override switched on for steps 150..449 of a noise-stick
+    # flight; case 1: overridden on every step; case 2: overridden on every step above a Ground object
+    # (object_list = [ground]), descending into spring contact and a crash. ----
+    from utils.helper_functions import euler_angles_to_rotation_matrix
+    T13 = 600
+    tt = np.arange(T13) * 1e-3
+    a13 = sticks.ema_noise(T13, [200, 201, 202], seed=0)
+    a13[..., 3] += np.float32(-0.4)
+    ang = np.stack([                                          # roll, pitch, yaw [rad] of the commanded attitude
+        np.stack([0.35 * np.sin(2 * np.pi * 1.5 * tt), -0.26 + 0.17 * np.cos(2 * np.pi * 0.8 * tt), 0.7 * tt], axis=1),
+        np.stack([0.5 * np.sin(2 * np.pi * 0.7 * tt + 1.0), 0.4 * np.sin(2 * np.pi * 1.1 * tt), 2.5 * np.sin(2 * np.pi * 0.5 * tt)], axis=1),
+        np.stack([0.10 * np.sin(2 * np.pi * 2.0 * tt), 0.08 * np.cos(2 * np.pi * 1.3 * tt), 0.2 * tt], axis=1)], axis=1)   # [T, 3 drones, 3]
+    rot13 = np.zeros((T13, 3, 3, 3))
+    for t in range(T13):
+        for k in range(3):
+            rot13[t, k] = euler_angles_to_rotation_matrix(*ang[t, k])
+    rot13 = rot13.astype(np.float32).astype(np.float64)
+    tf13 = np.stack([7.36 + 2.0 * np.sin(2 * np.pi * 2 * tt), 9.0 + 4.0 * np.cos(2 * np.pi * 0.9 * tt),
+                     6.2 + 0.5 * np.sin(2 * np.pi * 3 * tt)], axis=1).astype(np.float32).astype(np.float64)     # [T, 3] newtons
+    tf13[:150, 0] = np.nan
+    tf13[450:, 0] = np.nan
+    ip = np.array([[0, 0, 10.0], [2.0, -1.0, 20.0], [0, 0, 0.45]])
+    iv = np.array([[1.0, 0, 0], [-2.0, 1.5, 0.5], [0.3, 0, -0.2]])
+    io_ = np.array([[0, 0, 0], [10.0, -20.0, 45.0], [0, 0, 0]])
+    cs = []
+    for k in range(3):
+        objs = [ground] if k == 2 else []
+        rec = {kk: [] for kk in ("state", "R", "prev_rates", "prev_thrust", "accel")}
+        done = np.zeros(T13, dtype=np.uint8)
+        with contextlib.redirect_stdout(io.StringIO()):
+            d = Drone(copy.deepcopy(P1k))
+            d.reset(position=ip[k].astype(float), velocity=iv[k].astype(float), ypr=io_[k].astype(float))
+            for t in range(T13):
+                if np.isnan(tf13[t, k]):
+                    ret = d.step(action=a13[t, k].astype(np.float64), wind_velocity_vector=np.zeros(3), object_list=objs)
+                else:
+                    ret = d.step(action=a13[t, k].astype(np.float64), wind_velocity_vector=np.zeros(3), object_list=objs,
+                                 rotation_matrix=rot13[t, k].copy(), thrust_force=float(tf13[t, k]))
+                done[t] = bool(d.done)
+                rec["state"].append(d.state.copy()); rec["R"].append(d.rotation_matrix.copy())
+                rec["prev_rates"].append(np.asarray(d.prev_rates, float).copy())
+                rec["prev_thrust"].append(float(d.prev_thrust)); rec["accel"].append(np.asarray(ret[2], float).copy())
+        c = {kk: np.asarray(v) for kk, v in rec.items()}
+        c["done"] = done
+        c["snap_steps"] = np.arange(1, T13 + 1)
+        c["ret_RT"] = np.asarray(ret[0], float); c["ret_gyro"] = np.asarray(ret[1], float)
+        cs.append(c)
+    save("g13_guidance_override", dt=1e-3, actions=a13, init_position=ip, init_velocity=iv, init_ypr=io_, wind=np.zeros(3),
+         rotation_override=rot13, thrust_force=tf13, ground_case=np.array([0, 0, 1]), **stack(cs))
+
     leftovers = [r for r, ds, _ in os.walk(REF) if "__pycache__" in ds]
     assert not leftovers, f"bytecode written into the reference mount: {leftovers}"
 

@@ -20,6 +20,10 @@ extern "C" {
 static FpvObjects g_objs = {0, {}};
 static float* g_pos_comp = nullptr;      // [6][ld] Kahan compensation rows (p, v) used by subsequent fpvl_run calls, or null
 void fpvl_set_pos_comp(float* c) { g_pos_comp = c; }
+// guidance override ([n][9] rotation matrices, [n] thrust forces) applied on every step of subsequent fpvl_run calls, or null
+static const float* g_rot_over = nullptr;
+static const float* g_thrust_over = nullptr;
+void fpvl_set_override(const float* rot, const float* thrust) { g_rot_over = rot; g_thrust_over = thrust; }
 
 // object_list used by subsequent fpvl_run calls (count 0 = none)
 void fpvl_set_objects(const fpv_objects_t* t)
@@ -53,12 +57,14 @@ int fpvl_run(const fpv_params_t* P, int64_t n, int steps, float* st, int64_t ld,
                 float kc[6] = {0, 0, 0, 0, 0, 0};
                 if (g_pos_comp) { for (int k = 0; k < 6; ++k) kc[k] = g_pos_comp[k * ld + i]; }
                 float* kp = g_pos_comp ? kc : nullptr;
+                const float* ro = g_rot_over ? g_rot_over + i * 9 : nullptr;
+                const float to = g_rot_over ? g_thrust_over[i] : 0.0f;
                 if (g_objs.count > 0)
-                    o = big ? fpv_drone_step_lane<true, true>(K, s, a[0], a[1], a[2], a[3], wind[0], wind[1], wind[2], &g_objs, kp)
-                            : fpv_drone_step_lane<false, true>(K, s, a[0], a[1], a[2], a[3], wind[0], wind[1], wind[2], &g_objs, kp);
+                    o = big ? fpv_drone_step_lane<true, true>(K, s, a[0], a[1], a[2], a[3], wind[0], wind[1], wind[2], &g_objs, kp, ro, to)
+                            : fpv_drone_step_lane<false, true>(K, s, a[0], a[1], a[2], a[3], wind[0], wind[1], wind[2], &g_objs, kp, ro, to);
                 else
-                    o = big ? fpv_drone_step_lane<true>(K, s, a[0], a[1], a[2], a[3], wind[0], wind[1], wind[2], nullptr, kp)
-                            : fpv_drone_step_lane<false>(K, s, a[0], a[1], a[2], a[3], wind[0], wind[1], wind[2], nullptr, kp);
+                    o = big ? fpv_drone_step_lane<true>(K, s, a[0], a[1], a[2], a[3], wind[0], wind[1], wind[2], nullptr, kp, ro, to)
+                            : fpv_drone_step_lane<false>(K, s, a[0], a[1], a[2], a[3], wind[0], wind[1], wind[2], nullptr, kp, ro, to);
                 if (g_pos_comp) {
                     const bool rst = (K.flags & FPV_FLAG_AUTO_RESET) && o.done;
                     for (int k = 0; k < 6; ++k) g_pos_comp[k * ld + i] = rst ? 0.0f : kc[k];
@@ -202,4 +208,11 @@ extern "C" void fpvl_pid_run(const double k[8], float st[4], int T, const float*
         out[t] = fpv_pid_axis<float, 1>(P, 0, current[t], target[t], st[3] != 0.0f, st[0], st[2], st[1]);
         st[3] = 0.0f;
     }
+}
+
+// rotation matrix -> unit quaternion (w,x,y,z) as the guidance override of the step kernel does it
+extern "C" void fpvl_quat_from_rot(const float m[9], float q[4])
+{
+    const FpvQuat r = fpv_quat_from_rot(m);
+    q[0] = r.w; q[1] = r.x; q[2] = r.y; q[3] = r.z;
 }

@@ -58,6 +58,26 @@ def set_pos_comp(comp: Optional[np.ndarray]) -> None:
     L.fpvl_set_pos_comp(None if comp is None else comp.ctypes.data)
 
 
+_override_keep = None
+
+
+def set_override(rotations=None, thrust_forces=None) -> None:
+    """Guidance override for subsequent run() calls: rotations [n,3,3] fp32 and thrust forces [n] (NaN = not
+    overridden), applied on every step of the call; None clears it."""
+    global _override_keep
+    L = lib()
+    L.fpvl_set_override.argtypes = [C.c_void_p, C.c_void_p]
+    if rotations is None:
+        _override_keep = None
+        L.fpvl_set_override(None, None)
+        return
+    r = np.ascontiguousarray(rotations, dtype=np.float32).reshape(-1, 9)
+    f = np.ascontiguousarray(thrust_forces, dtype=np.float32).reshape(-1)
+    assert r.shape[0] == f.shape[0]
+    _override_keep = (r, f)
+    L.fpvl_set_override(r.ctypes.data, f.ctypes.data)
+
+
 def set_objects(rows) -> None:
     """object_list (rows of (type, x, y, z, radius, height)) for subsequent run() calls; () clears it."""
     L = lib()
@@ -186,3 +206,15 @@ def pid_run(gains, current: np.ndarray, target: np.ndarray):
     fp = lambda a: a.ctypes.data_as(C.POINTER(C.c_float))  # noqa: E731
     L.fpvl_pid_run(k.ctypes.data_as(C.POINTER(C.c_double)), fp(st), len(cur), fp(cur), fp(tgt), fp(out))
     return out, st
+
+
+def quat_from_rot(R) -> np.ndarray:
+    """[...,3,3] rotation matrices -> [...,4] (w,x,y,z) in the kernel's fp32 arithmetic (fpv_quat_from_rot)."""
+    L = lib()
+    L.fpvl_quat_from_rot.argtypes = [C.POINTER(C.c_float), C.POINTER(C.c_float)]
+    R = np.ascontiguousarray(R, dtype=np.float32).reshape(-1, 9)
+    q = np.zeros((R.shape[0], 4), dtype=np.float32)
+    fp = lambda a: a.ctypes.data_as(C.POINTER(C.c_float))  # noqa: E731
+    for i in range(R.shape[0]):
+        L.fpvl_quat_from_rot(fp(R[i]), fp(q[i]))
+    return q

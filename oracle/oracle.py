@@ -69,6 +69,8 @@ def lib(native: bool = False) -> C.CDLL:
         L.fpvo_drone_step_batch.argtypes = [C.POINTER(OracleParams), C.c_int64, C.c_int, dp, dp, C.c_int,
                                             dp, dp, u8p, C.c_int]
         L.fpvo_drone_step_batch.restype = None
+        L.fpvo_drone_step_guided.argtypes = [C.POINTER(OracleParams), dp, dp, dp, dp, C.c_double, dp, u8p]
+        L.fpvo_drone_step_guided.restype = None
         L.fpvo_racer_step_batch.argtypes = [C.POINTER(OracleParams), C.c_int64, C.c_int, dp, dp, C.c_int, C.c_int]
         L.fpvo_racer_step_batch.restype = None
         L.fpvo_matrix_to_quat_wxyz.argtypes = [dp, dp]
@@ -178,6 +180,27 @@ def drone_run(p, state: np.ndarray, actions: np.ndarray, steps: Optional[int] = 
     lib(native).fpvo_drone_step_batch(C.byref(op), n, steps, _dp(state), _dp(actions), int(per_step), _dp(w),
                                     _dp(accel), done.ctypes.data_as(C.POINTER(C.c_uint8)), threads)
     return state, accel, done
+
+
+def drone_run_guided(p, state: np.ndarray, actions: np.ndarray, rotations, thrust_forces, wind=(0.0, 0.0, 0.0)
+                     ) -> Tuple[np.ndarray, np.ndarray, np.ndarray]:
+    """One drone (state [19]), T steps with the guidance arguments of Drone.step (components.py:230-232):
+    rotations [T,3,3] and thrust_forces [T]; a NaN thrust force means `rotation_matrix=None` on that step.
+    Returns (states [T,19] after every step, accel [T,3], done [T])."""
+    assert state.shape == (DRONE_STATE,) and state.dtype == np.float64
+    actions = np.ascontiguousarray(actions, dtype=np.float64)
+    T = actions.shape[0]
+    rot = np.ascontiguousarray(rotations, dtype=np.float64).reshape(T, 9)
+    tf = np.asarray(thrust_forces, dtype=np.float64)
+    w = np.asarray(wind, dtype=np.float64)
+    op, L = pack_params(p), lib()
+    states, accel, done = np.zeros((T, DRONE_STATE)), np.zeros((T, 3)), np.zeros(T, dtype=np.uint8)
+    for t in range(T):
+        d = C.c_uint8(0)
+        L.fpvo_drone_step_guided(C.byref(op), _dp(state), _dp(actions[t]), _dp(w),
+                                 None if np.isnan(tf[t]) else _dp(rot[t]), float(tf[t]), _dp(accel[t]), C.byref(d))
+        states[t], done[t] = state, d.value
+    return states, accel, done
 
 
 def racer_initial_state(n: int) -> np.ndarray:

@@ -23,6 +23,7 @@ int fpvl_stick_noise(const fpv_params_t* P, int64_t n, int steps, float* ns, int
                      float* applied, uint32_t step0);
 void fpvl_set_objects(const fpv_objects_t* t);
 void fpvl_set_pos_comp(float* c);
+void fpvl_set_override(const float* rot, const float* thrust);
 void fpvl_pid_run(const double k[8], float st[4], int T, const float* current, const float* target, float* out);
 void fpvl_sincos_wide(double x, double* s, double* c);
 }
@@ -101,6 +102,27 @@ int main()
             if (fpvl_run(&P, n, 5, st.data(), ld, acts.data(), 0, wind, nullptr, nullptr, nullptr) != 0) return 2;      // held action, no outputs
             fpvl_set_objects(nullptr); fpvl_set_pos_comp(nullptr);
             for (int64_t i = 0; i < n; ++i) if (!(st[FPV_QW * ld + i] == st[FPV_QW * ld + i])) { fprintf(stderr, "NaN in lane model\n"); return 3; }
+        }
+        // ---- both builds, guidance override (rotation_matrix= / thrust_force=): every Shepperd branch, NaN = no override ----
+        {
+            fpv_params_t P = abi_params(FPV_MODE_DRONE, 0);
+            const fpvo_params PO = oracle_params(P);
+            std::vector<float> st((size_t)FPV_DRONE_ROWS * ld, 0.0f), rot((size_t)n * 9), thr((size_t)n);
+            std::vector<uint8_t> done((size_t)n);
+            for (int64_t i = 0; i < n; ++i) {
+                st[FPV_PZ * ld + i] = 5.0f; st[FPV_QW * ld + i] = 1.0f;
+                double E[9];
+                fpvo_euler_zyx_matrix(3.2 * urand(), 1.5 * urand(), 3.2 * urand(), E);      // all attitudes: trace > 0 and the three diagonal branches
+                for (int k = 0; k < 9; ++k) rot[(size_t)i * 9 + k] = (float)E[k];
+                thr[(size_t)i] = (i % 5 == 4) ? NAN : (float)(7.0 + 3.0 * urand());
+                double s19[FPVO_DRONE_STATE] = {0, 0, 5.0, 0, 0, 0, 1, 0, 0, 0, 1, 0, 0, 0, 1, 0, 0, 0, 0}, a3[3];
+                uint8_t d = 0;
+                fpvo_drone_step_guided(&PO, s19, &actsd[(size_t)i * 4], windd, (i % 5 == 4) ? nullptr : E, thr[(size_t)i], a3, &d);
+            }
+            fpvl_set_override(rot.data(), thr.data());
+            if (fpvl_run(&P, n, 3, st.data(), ld, acts.data(), 1, wind, nullptr, done.data(), nullptr) != 0) return 2;
+            fpvl_set_override(nullptr, nullptr);
+            for (int64_t i = 0; i < n; ++i) if (!(st[FPV_QW * ld + i] == st[FPV_QW * ld + i])) { fprintf(stderr, "NaN in the override path\n"); return 3; }
         }
         // ---- lane model, fp16 storage ----
         {

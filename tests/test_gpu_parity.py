@@ -1178,3 +1178,51 @@ def test_plain_c_host_through_the_c_abi(params_1k, tmp_path):
         done = raw[rows * ld * 4 + n * 4:]
         assert np.array_equal(got[:, :n].view(np.uint32), want[:, :n].view(np.uint32)), mode
         assert np.array_equal(rew.view(np.uint32), env.reward.cpu().numpy().view(np.uint32)) and not done.any()
+
+
+def test_guidance_override_vs_reference_capture(params_1k):
+    """Drone.step(action, wind, object_list, rotation_matrix=R, thrust_force=f) - the guidance call of
+    simulator.py:110 (components.py:230-232) - through the public API against the reference capture G13: override
+    switched on and off mid-flight (NaN thrust_force = that drone is not overridden), on every step, and on
+    every step above a Ground object.  Bitwise against the host build of the same arithmetic, 1e-5 against the
+    reference, `done` equal on every step."""
+    from fpyv_amd.objects import Ground
+    g = load_golden("g13_guidance_override")
+    acts = g["actions"]
+    T = acts.shape[0]
+    for cases, world, rows in (([0, 1], [], ()), ([2], [Ground()], [(0, 0, 0, 0, 0, 0)])):
+        m = len(cases)
+        env = _drone_batch(params_1k, m)
+        model = lane_model.initial_state(params_1k, m, g["init_position"][cases], g["init_velocity"][cases], g["init_ypr"][cases])
+        env.state[:, :m] = torch.from_numpy(model[:, :m]).to(DEV)
+        a = torch.from_numpy(np.ascontiguousarray(acts[:, cases])).to(DEV)
+        R = torch.from_numpy(np.ascontiguousarray(g["rotation_override"][:, cases]).astype(np.float32)).to(DEV)
+        f = torch.from_numpy(np.ascontiguousarray(g["thrust_force"][:, cases]).astype(np.float32)).to(DEV)
+        lane_model.set_objects(rows)
+        try:
+            for t in range(T):
+                ret = env.step(a[t], wind_velocity_vector=np.zeros(3), object_list=world, rotation_matrix=R[t], thrust_force=f[t])
+                assert np.array_equal(env.done_u8.cpu().numpy(), g["done"][cases, t])
+                lane_model.set_override(g["rotation_override"][t, cases], g["thrust_force"][t, cases])
+                lane_model.run(params_1k, model, acts[t:t + 1, cases])
+        finally:
+            lane_model.set_override(None)
+            lane_model.set_objects(())
+        got = env.state.cpu().numpy()
+        assert np.array_equal(got[:, :m].view(np.uint32), model[:, :m].view(np.uint32)), "kernel != lane model (bitwise)"
+        ref = np.concatenate([g["state"][cases, -1], g["R"][cases, -1].reshape(m, 9), g["prev_rates"][cases, -1],
+                              g["prev_thrust"][cases, -1][:, None]], axis=1)
+        assert_parity(soa_vs_oracle(got, ref, m), REL_TOL, f"G13 cases {cases}")
+        # the return triple of the last (overridden) step: R_new.T and R_new @ acc
+        np.testing.assert_allclose(ret[0].cpu().numpy(), g["ret_RT"][cases], atol=2e-6)
+        np.testing.assert_allclose(ret[2].cpu().numpy(), g["accel"][cases, -1], rtol=1e-4, atol=1e-4)
+    # a [3,3] matrix and a scalar force broadcast over the batch; the override is a per-step input
+    env = _drone_batch(params_1k, 5)
+    env.reset()
+    env.step(np.zeros(4, np.float32), rotation_matrix=np.eye(3), thrust_force=7.0)
+    env.step(np.zeros(4, np.float32), thrust_force=7.0)                    # ignored without rotation_matrix (components.py:230)
+    with pytest.raises(TypeError):
+        env.step(np.zeros(4, np.float32), rotation_matrix=np.eye(3))
+    with pytest.raises(ValueError):
+        env.step(np.zeros(4, np.float32), rotation_matrix=np.zeros((4, 3, 3)), thrust_force=1.0)
+    assert env._buf.rotation_override is None and env._buf.thrust_override is None, "the override must not outlive its step"

@@ -297,3 +297,50 @@ def test_config1_10k_steps_with_kahan_compensation(params_1k):
                           g["prev_thrust"][:, -1:]], axis=1)
     err = soa_vs_oracle(s, ref, 1)
     assert err["pos_rel"] < 1e-6 and err["vel_rel"] < 1e-6 and err["quat_abs"] < 1e-6, err
+
+
+def test_guidance_override_fp32(params_1k):
+    """The kernel's fp32 arithmetic for Drone.step(..., rotation_matrix=, thrust_force=) (matrix -> quaternion by
+    Shepperd's method, then the usual step) against the reference capture G13, every step of every case."""
+    from parity import soa_vs_oracle
+    g = load_golden("g13_guidance_override")
+    acts = g["actions"]
+    T, n = acts.shape[:2]
+    worst = {}
+    for cases, objs in (([0, 1], ()), ([2], [(0, 0, 0, 0, 0, 0)])):
+        m = len(cases)
+        model = lane_model.initial_state(params_1k, m, g["init_position"][cases], g["init_velocity"][cases], g["init_ypr"][cases])
+        lane_model.set_objects(objs)
+        try:
+            for t in range(T):
+                lane_model.set_override(g["rotation_override"][t, cases], g["thrust_force"][t, cases])
+                _, _, done, _ = lane_model.run(params_1k, model, acts[t:t + 1, cases])
+                assert np.array_equal(done, g["done"][cases, t])
+                if (t + 1) % 50 == 0:
+                    ref = np.concatenate([g["state"][cases, t], g["R"][cases, t].reshape(m, 9), g["prev_rates"][cases, t],
+                                          g["prev_thrust"][cases, t][:, None]], axis=1)
+                    err = soa_vs_oracle(model, ref, m)
+                    for k, v in err.items():
+                        worst[k] = max(worst.get(k, 0.0), v)
+        finally:
+            lane_model.set_override(None)
+            lane_model.set_objects(())
+    assert worst["pos_comp"] < 1e-5 and worst["quat_abs"] < 1e-5 and worst["qnorm"] < 5e-7, worst
+
+
+def test_quat_from_rot_every_branch():
+    """fpv_quat_from_rot (the override's matrix -> quaternion step): random attitudes plus half-turns about
+    x, y, z and near them (trace <= 0: the three diagonal branches) reproduce R(q) = R to fp32 rounding."""
+    rng = np.random.default_rng(42)
+    q = rng.standard_normal((400, 4))
+    q /= np.linalg.norm(q, axis=1, keepdims=True)
+    for ax in range(3):                                     # half-turns and their neighbourhood: w ~ 0
+        for eps in (0.0, 1e-4, -3e-3, 0.05):
+            v = np.zeros(4); v[0] = eps; v[1 + ax] = 1.0; v[1 + (ax + 1) % 3] = 0.3 * eps
+            q = np.vstack([q, v / np.linalg.norm(v)])
+    R = oracle.quat_to_matrix(q)
+    got = lane_model.quat_from_rot(R).astype(np.float64)
+    assert np.abs(np.linalg.norm(got, axis=1) - 1).max() < 2e-7
+    assert np.abs(oracle.quat_to_matrix(got) - R).max() < 1e-6
+    sign = np.sign(np.sum(got * q, axis=1, keepdims=True))
+    assert np.abs(got * sign - q).max() < 5e-7

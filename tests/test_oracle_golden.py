@@ -194,3 +194,26 @@ def test_racer_with_components_pid_matches_reference():
 def load_params_1k():
     from fpyv_amd import load_params
     return load_params(fps=1000)
+
+
+def test_guidance_override_matches_reference(params_1k):
+    """Drone.step(..., rotation_matrix=R, thrust_force=f) (components.py:230-232) on G13: override switched on
+    and off mid-flight (case 0), on every step (case 1), on every step above a Ground object (case 2)."""
+    g = load_golden("g13_guidance_override")
+    acts = g["actions"].astype(np.float64)
+    T, n = acts.shape[:2]
+    assert np.isnan(g["thrust_force"][:, 0]).sum() == 300 and not np.isnan(g["thrust_force"][:, 1:]).any()
+    for i in range(n):
+        p = params_1k.replace(objects=[(0, 0, 0, 0, 0, 0)]) if g["ground_case"][i] else params_1k
+        s = oracle.drone_initial_state(1, g["init_position"][i], g["init_velocity"][i], g["init_ypr"][i])[0]
+        states, accel, done = oracle.drone_run_guided(p, s, acts[:, i], g["rotation_override"][:, i], g["thrust_force"][:, i])
+        assert np.abs(states[:, 0:6] - g["state"][i]).max() < TOL * max(1.0, np.abs(g["state"][i]).max())
+        assert np.abs(states[:, 6:15] - g["R"][i].reshape(T, 9)).max() < TOL
+        assert np.abs(states[:, 15:18] - g["prev_rates"][i]).max() < TOL * 200
+        assert np.abs(states[:, 18] - g["prev_thrust"][i]).max() < TOL * 100
+        assert np.abs(accel - g["accel"][i]).max() < 1e-9 * max(1.0, np.abs(g["accel"][i]).max())
+        assert np.array_equal(done, g["done"][i])
+    # the override really bites: on an overridden step the attitude after the step is R_override turned by the
+    # step's double increment, i.e. within the increment's size of the commanded matrix and far from the free flight
+    i, t = 1, 300
+    assert np.abs(g["R"][i, t] - g["rotation_override"][t, i]).max() < 0.02
