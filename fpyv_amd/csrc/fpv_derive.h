@@ -62,6 +62,17 @@ static inline int fpv_derive_constants(const fpv_params_t* P, FpvK* K, bool* big
         K->kdrag_m[i] = (float)(0.5 * P->drag_coefficients[i] * P->air_density * P->cross_section_areas[i] / P->mass);
     K->half_k = (float)(0.5 * (M_PI / 180.0) * P->dt);
     for (int m = 0; m < 4; ++m) { K->motor_x[m] = (float)P->motor_xy[m][0]; K->motor_y[m] = (float)P->motor_xy[m][1]; }
+    {   // the reference's X frame after narrowing: (c,c) (-c,c) (-c,-c) (c,-c) in any order, one |c| bit for bit
+        const float c = fabsf(K->motor_x[0]);
+        bool square = c > 0.0f;
+        int seen = 0;
+        for (int m = 0; m < 4; ++m) {
+            square = square && fabsf(K->motor_x[m]) == c && fabsf(K->motor_y[m]) == c;
+            seen |= 1 << ((K->motor_x[m] < 0 ? 1 : 0) | (K->motor_y[m] < 0 ? 2 : 0));
+        }
+        K->motor_square = (square && seen == 15) ? 1u : 0u;
+        K->motor_c = c;
+    }
     for (int i = 0; i < 3; ++i) { K->p0[i] = (float)P->init_position[i]; K->v0[i] = (float)P->init_velocity[i]; K->goal[i] = (float)P->goal[i]; }
     for (int i = 0; i < 4; ++i) K->q0[i] = (float)(P->init_quat[i] / qn);
     K->ceiling = (float)P->ceiling;        // +inf stays +inf

@@ -185,24 +185,29 @@ struct RollOut {
     {
         if (track && live) { ep_r = B.ep_return[i]; ep_l = B.ep_length[i]; }
     }
-    // does step t store (or accumulate) a reward?  wave-uniform
-    __device__ __forceinline__ bool wants(int t) const { return track || out_stride != 0 || t == last_t; }
-    // called by every live lane of the wave in the same iteration (the ballot spans the wave)
+    // called by every live lane of the wave in the same iteration (the ballot spans the wave).  QUIET = a step of a
+    // launch that neither stores reward/done per step nor tracks episodes, and is not the last one: only the
+    // optional per-step done_bits row is left of it
+    template <bool QUIET = false>
     __device__ __forceinline__ void step(uint32_t i, int t, float reward, bool done)
     {
-        const bool last = t == last_t;
-        const unsigned long long mask = __ballot(done);
-        if (bp && (bits_stride || last) && (threadIdx.x & 63) == 0) bp[i >> 6] = mask;
-        if (out_stride || last) {
-            if (rp) __builtin_nontemporal_store(reward, &row_at(rp, i));
-            if (dp) __builtin_nontemporal_store((uint8_t)(done ? 1 : 0), &row_at(dp, i));
+        const bool last = !QUIET && t == last_t;
+        if (bp && (bits_stride || last)) {
+            const unsigned long long mask = __ballot(done);
+            if ((threadIdx.x & 63) == 0) bp[i >> 6] = mask;
         }
-        if (track) {
-            ep_r += reward; ep_l += 1;
-            if (done) { last_r = ep_r; last_l = ep_l; had_done = true; ep_r = 0.0f; ep_l = 0; }
+        if (!QUIET) {
+            if (out_stride || last) {
+                if (rp) __builtin_nontemporal_store(reward, &row_at(rp, i));
+                if (dp) __builtin_nontemporal_store((uint8_t)(done ? 1 : 0), &row_at(dp, i));
+            }
+            if (track) {
+                ep_r += reward; ep_l += 1;
+                if (done) { last_r = ep_r; last_l = ep_l; had_done = true; ep_r = 0.0f; ep_l = 0; }
+            }
+            if (rp) rp += out_stride;
+            if (dp) dp += out_stride;
         }
-        if (rp) rp += out_stride;
-        if (dp) dp += out_stride;
         if (bp) bp += bits_stride;
     }
     __device__ __forceinline__ void finish(uint32_t i)
@@ -303,9 +308,17 @@ __global__ __launch_bounds__(BS) void fpv_drone_step_kernel(const FpvK K, const 
 // bound by the fp32 vector ALUs (~400 instructions per env-step), not by HBM.  The arithmetic per step
 // is the single-step kernel's lane function, called in the same order: results are bit-identical to k
 // fpv_step launches.
-template <int BS, bool BIG, bool NOISE, bool OBJ, bool KAHAN>
-__global__ __launch_bounds__(BS) void fpv_drone_rollout_kernel(const FpvK K, const FpvBufD B, const int64_t n, const FpvRoll R)
+// SQ: launched only for the X frame without the ground-spring flag and without objects (choose_rollout_kernel):
+// the quiet steps use the two-height ground flag (fpv_drone_step_lane<.., SQ = true>).
+#ifdef FPV_EXP_ROLL_WAVES
+#define FPV_EXP_ROLL_ATTR __attribute__((amdgpu_waves_per_eu(FPV_EXP_ROLL_WAVES, FPV_EXP_ROLL_WAVES)))
+#else
+#define FPV_EXP_ROLL_ATTR
+#endif
+template <int BS, bool BIG, bool NOISE, bool OBJ, bool KAHAN, bool SQ = false>
+__global__ __launch_bounds__(BS) FPV_EXP_ROLL_ATTR void fpv_drone_rollout_kernel(const FpvK K, const FpvBufD B, const int64_t n, const FpvRoll R)
 {
+    static_assert(!(SQ && OBJ), "the two-height ground flag does not feed the object pass");
     const uint32_t i = blockIdx.x * (uint32_t)BS + threadIdx.x;
     if (i >= n) return;
     FpvDroneState s;
@@ -332,24 +345,31 @@ __global__ __launch_bounds__(BS) void fpv_drone_rollout_kernel(const FpvK K, con
     if (NOISE) { fpv_settle(ns[0]); fpv_settle(ns[1]); fpv_settle(ns[2]); fpv_settle(ns[3]); }
     if (KAHAN) { for (int k = 0; k < 6; ++k) fpv_settle(kc[k]); }
     if (out.track) { fpv_settle(out.ep_r); fpv_settle(__int_as_float(out.ep_l)); }
-    for (int t = 0; t < R.k; ++t) {
+    // reward / R_new @ acc are computed only on the steps that store or accumulate them.  A launch whose outputs
+    // leave only after the last step (no per-step stride, no episode bookkeeping) runs its first k-1 steps in a
+    // loop of their own that knows this at compile time - no per-step test, no output code in the loop
+    auto one_step = [&](int t, auto quiet_c) {
+        constexpr bool QUIET = decltype(quiet_c)::value;
         av[0] = a_next.x; av[1] = a_next.y; av[2] = a_next.z; av[3] = a_next.w;
         if (has_action && R.action_stride && t + 1 < R.k) {
             ap += R.action_stride;
             a_next = ld_action_any(reinterpret_cast<const float4*>(ap), B.action_ld, i);
         }
         if (NOISE) fpv_stick_noise(K.noise, B.step + (uint32_t)t, (uint64_t)i, ns, av);
-        // reward / R_new @ acc are computed only on the steps that store them (wave-uniform choice)
-        if (out.wants(t)) o = fpv_drone_step_lane<BIG, OBJ, true>(K, s, av[0], av[1], av[2], av[3], B.wx, B.wy, B.wz, &B.objs, KAHAN ? kc : nullptr);
-        else o = fpv_drone_step_lane<BIG, OBJ, false>(K, s, av[0], av[1], av[2], av[3], B.wx, B.wy, B.wz, &B.objs, KAHAN ? kc : nullptr);
+        o = fpv_drone_step_lane<BIG, OBJ, !QUIET, SQ && QUIET>(K, s, av[0], av[1], av[2], av[3], B.wx, B.wy, B.wz, &B.objs, KAHAN ? kc : nullptr);
         const bool rst = (K.flags & FPV_FLAG_AUTO_RESET) && o.done;
         if (KAHAN && rst) {
 #pragma unroll
             for (int k = 0; k < 6; ++k) kc[k] = 0.0f;
         }
         if (rst) fpv_drone_reset_lane(K, s);
-        out.step(i, t, o.reward, o.done);
+        out.template step<QUIET>(i, t, o.reward, o.done);
+    };
+    int t = 0;
+    if (!out.track && R.out_stride == 0) {
+        for (; t < R.k - 1; ++t) one_step(t, std::true_type{});
     }
+    for (; t < R.k; ++t) one_step(t, std::false_type{});
     // the store addresses are formed only now: computed before the loop they would sit in ~30 VGPRs for all k steps
     uint32_t j = i;
     asm volatile("" : "+v"(j));
@@ -511,16 +531,21 @@ __global__ __launch_bounds__(BS) void fpv_drone_rollout_h_kernel(const FpvK K, c
         fpv_settle(s.q.w); fpv_settle(s.q.x); fpv_settle(s.q.y); fpv_settle(s.q.z);
         fpv_settle(s.rx); fpv_settle(s.ry); fpv_settle(s.rz); fpv_settle(s.thrust);
         if (out.track) { fpv_settle(out.ep_r); fpv_settle(__int_as_float(out.ep_l)); }
-        for (int t = 0; t < R.k; ++t) {
+        auto one_step = [&](int t, auto quiet_c) {                       // see fpv_drone_rollout_kernel
+            constexpr bool QUIET = decltype(quiet_c)::value;
             const float4 a = a_next;
             if (R.action_stride && t + 1 < R.k) { ap += R.action_stride; a_next = ld_action(reinterpret_cast<const float4*>(ap), i); }
-            if (out.wants(t)) o = fpv_drone_step_lane<BIG, false, true>(K, s, a.x, a.y, a.z, a.w, B.wx, B.wy, B.wz);
-            else o = fpv_drone_step_lane<BIG, false, false>(K, s, a.x, a.y, a.z, a.w, B.wx, B.wy, B.wz);
+            o = fpv_drone_step_lane<BIG, false, !QUIET>(K, s, a.x, a.y, a.z, a.w, B.wx, B.wy, B.wz);
             if ((K.flags & FPV_FLAG_AUTO_RESET) && o.done) fpv_drone_reset_lane(K, s);
             fpv_pack_half(s, B.seed + (uint32_t)t, (uint32_t)i, h);       // the HBM round trip of a single step, in registers
-            if (t + 1 < R.k) fpv_unpack_half(h, s);
-            out.step(i, t, o.reward, o.done);
+            if (QUIET || t + 1 < R.k) fpv_unpack_half(h, s);
+            out.template step<QUIET>(i, t, o.reward, o.done);
+        };
+        int t = 0;
+        if (!out.track && R.out_stride == 0) {
+            for (; t < R.k - 1; ++t) one_step(t, std::true_type{});
         }
+        for (; t < R.k; ++t) one_step(t, std::false_type{});
         uint32_t j = i;                              // form the store addresses after the loop (VGPR pressure)
         asm volatile("" : "+v"(j));
         if (B.accel) {
@@ -899,15 +924,15 @@ StepKernel racer_kernel(int block, bool wide, bool pidv)
 typedef void (*RollKernel)(const FpvK, const FpvBufD, const int64_t, const FpvRoll);
 
 template <bool BIG>
-RollKernel drone_rollout_kernel(bool noise, bool obj, bool kahan)
+RollKernel drone_rollout_kernel(bool noise, bool obj, bool kahan, bool sq)
 {
     switch ((noise ? 4 : 0) | (obj ? 2 : 0) | (kahan ? 1 : 0)) {
-        case 0: return fpv_drone_rollout_kernel<128, BIG, false, false, false>;
-        case 1: return fpv_drone_rollout_kernel<128, BIG, false, false, true>;
+        case 0: return sq ? fpv_drone_rollout_kernel<128, BIG, false, false, false, true> : fpv_drone_rollout_kernel<128, BIG, false, false, false>;
+        case 1: return sq ? fpv_drone_rollout_kernel<128, BIG, false, false, true, true> : fpv_drone_rollout_kernel<128, BIG, false, false, true>;
         case 2: return fpv_drone_rollout_kernel<128, BIG, false, true, false>;
         case 3: return fpv_drone_rollout_kernel<128, BIG, false, true, true>;
-        case 4: return fpv_drone_rollout_kernel<128, BIG, true, false, false>;
-        case 5: return fpv_drone_rollout_kernel<128, BIG, true, false, true>;
+        case 4: return sq ? fpv_drone_rollout_kernel<128, BIG, true, false, false, true> : fpv_drone_rollout_kernel<128, BIG, true, false, false>;
+        case 5: return sq ? fpv_drone_rollout_kernel<128, BIG, true, false, true, true> : fpv_drone_rollout_kernel<128, BIG, true, false, true>;
         case 6: return fpv_drone_rollout_kernel<128, BIG, true, true, false>;
         default: return fpv_drone_rollout_kernel<128, BIG, true, true, true>;
     }
@@ -923,7 +948,8 @@ RollKernel choose_rollout_kernel(const fpv_env* h, const FpvBufD& d)
     }
     if (h->K.flags & FPV_FLAG_FP16_STATE) return big ? fpv_drone_rollout_h_kernel<128, true> : fpv_drone_rollout_h_kernel<128, false>;
     const bool noise = (h->K.flags & FPV_FLAG_STICK_NOISE) != 0, obj = d.objs.count > 0, kahan = d.pos_comp != nullptr;
-    return big ? drone_rollout_kernel<true>(noise, obj, kahan) : drone_rollout_kernel<false>(noise, obj, kahan);
+    const bool sq = !obj && h->K.motor_square && !(h->K.flags & FPV_FLAG_GROUND);      // X frame, no ground springs
+    return big ? drone_rollout_kernel<true>(noise, obj, kahan, sq) : drone_rollout_kernel<false>(noise, obj, kahan, sq);
 }
 
 KernelChoice choose_kernel(const fpv_env* h, const FpvBufD& d)

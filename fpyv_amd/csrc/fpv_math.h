@@ -72,6 +72,8 @@ struct FpvK {
     uint32_t r_wide;        // Racer: attitude increment in float64 (Racer.step as written: angle = omega per step)
     uint32_t r_pid_variant; // 0: racer_drone_test.PID.step, 1: components.PID.__call__
     uint32_t tiny_angle;    // 1: no step can turn by more than 0.03 rad of half-angle: two-term sin/cos suffice
+    uint32_t motor_square;  // 1: the motors sit at (+-c, +-c) (the reference's X frame, components.py:120-125): the ground
+    float motor_c;          //    flag needs two heights instead of four (see fpv_drone_step_lane)
     double r_ang_k_d;       // r_ang_k in double (the racer_omega_dt variant multiplies by the exact dt)
     FpvPidK<double> rd;     // rate-loop constants in float64 (Racer as written)
 };
@@ -449,7 +451,11 @@ FPV_HD bool fpv_collide_objects(const FpvK& K, const FpvObjects& T, const float 
 
 // OUT = false skips the values that only leave the lane (R_new @ acc and the reward): the k-step kernel
 // needs them only on the steps whose outputs are stored.  The state update is identical either way.
-template <bool BIG, bool OBJ = false, bool OUT = true>
+// SQ = true is a promise of the caller: K.motor_square is set and FPV_MATH_FLAG_GROUND is not (the k-step kernels
+// test that once per launch); the ground flag then comes from two motor heights instead of four, bit for bit the
+// same flag.  The single-step kernels are HBM-bound and keep the four-height form (SQ = false): there the extra
+// uniform test costs more than the 14 instructions it saves.
+template <bool BIG, bool OBJ = false, bool OUT = true, bool SQ = false>
 FPV_HD FpvStepOut fpv_drone_step_lane(const FpvK& K, FpvDroneState& s, float a0, float a1, float a2, float a3,
                                       float wx, float wy, float wz, const FpvObjects* objs = nullptr,
                                       float* kahan = nullptr, const float* rot_over = nullptr, float thrust_over = 0.0f)
@@ -496,20 +502,30 @@ FPV_HD FpvStepOut fpv_drone_step_lane(const FpvK& K, FpvDroneState& s, float a0,
     // spring force along +z; if ANY motor is below the plane the reference reports a crash and
     // returns before adding any force                                        components.py:198-214
     bool done = false;
-    float mzg[4];
-#pragma unroll
-    for (int m = 0; m < 4; ++m) {
-        mzg[m] = s.pz + fmaf(K.motor_x[m], R.r20, K.motor_y[m] * R.r21);
-        done = done || (mzg[m] < 0.0f);
-    }
-    if (K.flags & FPV_MATH_FLAG_GROUND) {                    // wave-uniform: the spring pass is skipped without the flag
-        float contact = 0.0f;
+    if (SQ && !OBJ) {
+        // the reference's X frame, motors at (+-c, +-c): the four heights above the centre
+        // are +-hA and +-hB with hA = fl(c r20 + fl(c r21)), hB = fl(-c r20 + fl(c r21)) (negating both products
+        // negates the rounded result exactly), so "any of fl(pz +- hA), fl(pz +- hB) below zero" is exactly
+        // "pz < max(|hA|, |hB|)": 5 instructions instead of 19, the same flag bit for bit.
+        const float t = K.motor_c * R.r21;
+        const float hA = fmaf(K.motor_c, R.r20, t), hB = fmaf(-K.motor_c, R.r20, t);
+        done = s.pz < fmaxf(fabsf(hA), fabsf(hB));
+    } else {
+        float mzg[4];
 #pragma unroll
         for (int m = 0; m < 4; ++m) {
-            const float d = mzg[m] - K.motor_radius;
-            if (d < 0.0f) contact += fmaf(-K.ground_k_m, d, -K.ground_c_m * s.vz);   // kinematics.py:56-59, normal = +z
+            mzg[m] = s.pz + fmaf(K.motor_x[m], R.r20, K.motor_y[m] * R.r21);
+            done = done || (mzg[m] < 0.0f);
         }
-        if (!done) accz += contact;
+        if (K.flags & FPV_MATH_FLAG_GROUND) {                // wave-uniform: the spring pass is skipped without the flag
+            float contact = 0.0f;
+#pragma unroll
+            for (int m = 0; m < 4; ++m) {
+                const float d = mzg[m] - K.motor_radius;
+                if (d < 0.0f) contact += fmaf(-K.ground_k_m, d, -K.ground_c_m * s.vz);   // kinematics.py:56-59, normal = +z
+            }
+            if (!done) accz += contact;
+        }
     }
     if (OBJ) {                                               // general object_list replaces the ground-only pass
         float mxw[4], myw[4], mzw[4], ca[3];

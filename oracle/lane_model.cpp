@@ -24,6 +24,10 @@ void fpvl_set_pos_comp(float* c) { g_pos_comp = c; }
 static const float* g_rot_over = nullptr;
 static const float* g_thrust_over = nullptr;
 void fpvl_set_override(const float* rot, const float* thrust) { g_rot_over = rot; g_thrust_over = thrust; }
+// 1: subsequent fpvl_run calls evaluate the ground flag from all four motor heights even for the square X frame
+// (the unit test of the two-height shortcut compares both)
+static int g_general_motors = 0;
+void fpvl_set_general_motors(int on) { g_general_motors = on; }
 
 // object_list used by subsequent fpvl_run calls (count 0 = none)
 void fpvl_set_objects(const fpv_objects_t* t)
@@ -43,6 +47,9 @@ int fpvl_run(const fpv_params_t* P, int64_t n, int steps, float* st, int64_t ld,
     const char* why = "";
     const int rc = fpv_derive_constants(P, &K, &big, &why);
     if (rc != FPV_OK) return rc;
+    // the two-height ground flag of the k-step kernels' X-frame loop (fpv_drone_step_lane<.., SQ = true>) is used
+    // here whenever its precondition holds, unless a test asks for the four-height form
+    const bool sq = K.motor_square && !(K.flags & FPV_FLAG_GROUND) && g_objs.count == 0 && !g_general_motors;
     for (int64_t i = 0; i < n; ++i) {
         if (P->mode == FPV_MODE_DRONE) {
             FpvDroneState s;
@@ -62,6 +69,9 @@ int fpvl_run(const fpv_params_t* P, int64_t n, int steps, float* st, int64_t ld,
                 if (g_objs.count > 0)
                     o = big ? fpv_drone_step_lane<true, true>(K, s, a[0], a[1], a[2], a[3], wind[0], wind[1], wind[2], &g_objs, kp, ro, to)
                             : fpv_drone_step_lane<false, true>(K, s, a[0], a[1], a[2], a[3], wind[0], wind[1], wind[2], &g_objs, kp, ro, to);
+                else if (sq)
+                    o = big ? fpv_drone_step_lane<true, false, true, true>(K, s, a[0], a[1], a[2], a[3], wind[0], wind[1], wind[2], nullptr, kp, ro, to)
+                            : fpv_drone_step_lane<false, false, true, true>(K, s, a[0], a[1], a[2], a[3], wind[0], wind[1], wind[2], nullptr, kp, ro, to);
                 else
                     o = big ? fpv_drone_step_lane<true>(K, s, a[0], a[1], a[2], a[3], wind[0], wind[1], wind[2], nullptr, kp, ro, to)
                             : fpv_drone_step_lane<false>(K, s, a[0], a[1], a[2], a[3], wind[0], wind[1], wind[2], nullptr, kp, ro, to);

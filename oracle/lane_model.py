@@ -78,6 +78,12 @@ def set_override(rotations=None, thrust_forces=None) -> None:
     L.fpvl_set_override(r.ctypes.data, f.ctypes.data)
 
 
+def set_general_motors(on: bool) -> None:
+    """True: subsequent run() calls evaluate the ground flag from all four motor heights even for the square X
+    frame (the shortcut's unit test compares both)."""
+    lib().fpvl_set_general_motors(int(bool(on)))
+
+
 def set_objects(rows) -> None:
     """object_list (rows of (type, x, y, z, radius, height)) for subsequent run() calls; () clears it."""
     L = lib()

@@ -344,3 +344,38 @@ def test_quat_from_rot_every_branch():
     assert np.abs(oracle.quat_to_matrix(got) - R).max() < 1e-6
     sign = np.sign(np.sum(got * q, axis=1, keepdims=True))
     assert np.abs(got * sign - q).max() < 5e-7
+
+
+def test_square_frame_ground_flag_shortcut_is_exact(params_1k):
+    """The X-frame shortcut of the ground flag (two heights, `pz < max(|hA|, |hB|)`) against the four-height
+    evaluation it replaces: identical `done` and identical state bits on random attitudes with the centre placed
+    within fp32 rounding of the flip height, and over a crash / recover trajectory."""
+    from fpyv_amd import _lib as abi, sticks
+    rng = np.random.default_rng(7)
+    n = 4096
+    ypr = rng.uniform([-180, -89, -180], [180, 89, 180], (n, 3))
+    s0 = lane_model.initial_state(params_1k, n, [0, 0, 0.05], [0.5, -0.2, -0.3], ypr)
+    # put every drone's centre exactly at, one ulp above and one ulp below the height at which its lowest motor
+    # touches z = 0: c * (|r20| + |r21|) with R from the quaternion
+    q = s0[abi.QW:abi.QZ + 1, :n].astype(np.float64)
+    r20, r21 = 2 * (q[1] * q[3] - q[0] * q[2]), 2 * (q[2] * q[3] + q[0] * q[1])
+    c = float(np.float32(params_1k.motor_xy[0][0]))
+    flip = (abs(c) * (np.abs(r20) + np.abs(r21))).astype(np.float32)
+    flip = np.where(np.arange(n) % 3 == 0, flip, np.where(np.arange(n) % 3 == 1, np.nextafter(flip, np.float32(10)), np.nextafter(flip, np.float32(-10))))
+    s0[abi.PZ, :n] = flip
+    acts = sticks.ema_noise(40, range(n), seed=3)
+    outs = []
+    for general in (False, True):
+        s = s0.copy()
+        lane_model.set_general_motors(general)
+        try:
+            dones = []
+            for t in range(acts.shape[0]):
+                _, _, d, _ = lane_model.run(params_1k, s, acts[t:t + 1])
+                dones.append(d.copy())
+        finally:
+            lane_model.set_general_motors(False)
+        outs.append((s, np.stack(dones)))
+    assert np.array_equal(outs[0][1], outs[1][1])
+    assert np.array_equal(outs[0][0].view(np.uint32), outs[1][0].view(np.uint32))
+    assert 0.2 < outs[0][1][0].mean() < 0.8, "the first step must sit on the flip boundary"

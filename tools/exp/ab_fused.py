@@ -29,14 +29,22 @@ ap.add_argument("--n", type=int, default=1 << 20)
 ap.add_argument("--rounds", type=int, default=8)
 ap.add_argument("--only", nargs="*", default=None)
 ap.add_argument("--extra", nargs="*", default=[], help="name=flag,flag,... additional variants")
+ap.add_argument("--lib", nargs="*", default=[], help="name=path/to/lib.so: a ready-built library (e.g. an older commit) as a variant")
 a = ap.parse_args()
 for e in a.extra:
     k, v = e.split("=", 1)
     VARIANTS[k] = [f for f in v.split(",") if f]
+READY = {}
+for e in a.lib:
+    k, v = e.split("=", 1)
+    READY[k] = os.path.join(REPO, v)
+    VARIANTS[k] = None
 names = [k for k in VARIANTS if not a.only or k in a.only]
 
 
 def path_of(k):
+    if k in READY:
+        return READY[k]
     return os.path.join(REPO, "fpyv_amd", "libfpv_hip.so") if VARIANTS[k] is None else os.path.join(HERE, f"libfpv_f_{k}.so")
 
 
@@ -89,8 +97,8 @@ def reset():
 
 
 e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-reps = 8 if n <= (1 << 21) else 16
 for api in ("fpv_rollout", "fpv_step_n"):
+    reps = (8 if n <= (1 << 21) else 16) * (6 if api == "fpv_step_n" else 1)      # ~6-8 ms per timing either way
     res = {k: [] for k in names}
     fin = {}
     for r in range(a.rounds):
