@@ -329,6 +329,39 @@ FPV_HD void fpv_philox4x32_10(uint32_t c0, uint32_t c1, uint32_t c2, uint32_t c3
     out[0] = c0; out[1] = c1; out[2] = c2; out[3] = c3;
 }
 
+// sin and cos of 2*pi*u for u in [0, 1]: the quadrant is taken off exactly (k = rint(4u), u - k/4 has no rounding
+// error), the remainder |2 pi r| <= pi/4 goes through the short polynomials.  No library call, no slow path: the
+// same instructions on the host and on gfx950, so the noise stream is bit-identical on both.
+FPV_HD void fpv_sincos_2pi(float u, float* s, float* c)
+{
+    const float k = rintf(4.0f * u);                 // 0 .. 4
+    const float r = fmaf(-0.25f, k, u);              // exact
+    float sr, cr;
+    fpv_sincos_small(6.2831855f * r, &sr, &cr);
+    const int q = (int)k & 3;
+    const float ss = (q & 1) ? cr : sr, cs = (q & 1) ? sr : cr;
+    *s = (q & 2) ? -ss : ss;
+    *c = ((q + 1) & 2) ? -cs : cs;
+}
+
+// natural logarithm of a NORMAL positive float (the generator feeds it u in [2^-25, 1)): u = 2^e m with m in
+// [sqrt(1/2), sqrt(2)), log m = 2 atanh(s), s = (m - 1) / (m + 1), |s| < 0.1716, odd series to s^9 (next term
+// 2/11 s^11 < 5e-9 of the result); the division is the correctly rounded IEEE one on both sides.  Error < 2e-7 relative.
+FPV_HD float fpv_log_normal_arg(float u)
+{
+    uint32_t ix = fpv_f32_bits(u) + (0x3f800000u - 0x3f3504f3u);
+    const float e = (float)((int32_t)(ix >> 23) - 127);
+    ix = (ix & 0x007fffffu) + 0x3f3504f3u;
+    const float f = fpv_bits_f32(ix) - 1.0f;         // exact
+    const float sq = f / (2.0f + f);
+    const float z = sq * sq;
+    float p = fmaf(z, 0.22222222f, 0.2857143f);      // 2/9, 2/7
+    p = fmaf(p, z, 0.4f);                            // 2/5
+    p = fmaf(p, z, 0.6666667f);                      // 2/3
+    const float lm = fmaf(sq * z, p, 2.0f * sq);
+    return fmaf(e, 0.693145752f, fmaf(e, 1.42860677e-06f, lm));     // ln 2 = hi + lo, hi has 16 significant bits: e * hi is exact
+}
+
 // four standard normals from one Philox block (Box-Muller on two uniform pairs in (0,1))
 FPV_HD void fpv_normal4(uint32_t seed_lo, uint32_t seed_hi, uint32_t drone_lo, uint32_t drone_hi, uint32_t step,
                         float z[4])
@@ -339,11 +372,11 @@ FPV_HD void fpv_normal4(uint32_t seed_lo, uint32_t seed_hi, uint32_t drone_lo, u
     const float u1 = ((float)(r[1] >> 8) + 0.5f) * 5.9604644775390625e-08f;
     const float u2 = ((float)(r[2] >> 8) + 0.5f) * 5.9604644775390625e-08f;
     const float u3 = ((float)(r[3] >> 8) + 0.5f) * 5.9604644775390625e-08f;
-    const float ra = sqrtf(-2.0f * logf(u0)), rb = sqrtf(-2.0f * logf(u2));
+    const float ra = sqrtf(-2.0f * fpv_log_normal_arg(u0)), rb = sqrtf(-2.0f * fpv_log_normal_arg(u2));
     float s, c;
-    fpv_sincos_full(6.283185307179586f * u1, &s, &c);
+    fpv_sincos_2pi(u1, &s, &c);
     z[0] = ra * c; z[1] = ra * s;
-    fpv_sincos_full(6.283185307179586f * u3, &s, &c);
+    fpv_sincos_2pi(u3, &s, &c);
     z[2] = rb * c; z[3] = rb * s;
 }
 

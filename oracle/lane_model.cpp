@@ -226,3 +226,7 @@ extern "C" void fpvl_quat_from_rot(const float m[9], float q[4])
     const FpvQuat r = fpv_quat_from_rot(m);
     q[0] = r.w; q[1] = r.x; q[2] = r.y; q[3] = r.z;
 }
+
+// the noise generator's own elementary functions (no libm on either side)
+extern "C" void fpvl_sincos_2pi(float u, float* s, float* c) { fpv_sincos_2pi(u, s, c); }
+extern "C" float fpvl_log_normal_arg(float u) { return fpv_log_normal_arg(u); }

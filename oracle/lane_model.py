@@ -224,3 +224,18 @@ def quat_from_rot(R) -> np.ndarray:
     for i in range(R.shape[0]):
         L.fpvl_quat_from_rot(fp(R[i]), fp(q[i]))
     return q
+
+
+def noise_elementary(u: np.ndarray):
+    """(sin(2 pi u), cos(2 pi u), log(u)) in the generator's own fp32 arithmetic for an array of u in (0, 1)."""
+    L = lib()
+    L.fpvl_sincos_2pi.argtypes = [C.c_float, C.POINTER(C.c_float), C.POINTER(C.c_float)]
+    L.fpvl_log_normal_arg.argtypes = [C.c_float]
+    L.fpvl_log_normal_arg.restype = C.c_float
+    u = np.asarray(u, dtype=np.float32)
+    s, c, lg = np.zeros_like(u), np.zeros_like(u), np.zeros_like(u)
+    a, b = C.c_float(), C.c_float()
+    for i, x in enumerate(u):
+        L.fpvl_sincos_2pi(float(x), C.byref(a), C.byref(b))
+        s[i], c[i], lg[i] = a.value, b.value, L.fpvl_log_normal_arg(float(x))
+    return s, c, lg
