@@ -240,8 +240,13 @@ __device__ __forceinline__ float4 apply_stick_noise(const FpvK& K, const FpvBufD
 // OVR: the guidance call shape Drone.step(..., rotation_matrix=R, thrust_force=f) (components.py:230-232,
 // simulator.py:110): nine more floats and the thrust force per drone, read with a 36-byte lane stride - the
 // matrices arrive in the caller's [n][3][3] layout; this is the closed-loop guidance path, not the headline one.
+#ifdef FPV_EXP_STEP_WAVES
+#define FPV_EXP_STEP_ATTR __attribute__((amdgpu_waves_per_eu(FPV_EXP_STEP_WAVES)))
+#else
+#define FPV_EXP_STEP_ATTR
+#endif
 template <int BS, int DPL, bool BIG, bool NOISE = false, bool OBJ = false, bool KAHAN = false, bool OVR = false>
-__global__ __launch_bounds__(BS) void fpv_drone_step_kernel(const FpvK K, const FpvBufD B, const int64_t n)
+__global__ __launch_bounds__(BS) FPV_EXP_STEP_ATTR void fpv_drone_step_kernel(const FpvK K, const FpvBufD B, const int64_t n)
 {
     static_assert(!OVR || DPL == 1, "the guidance override is built for one drone per lane");
     const uint32_t base = blockIdx.x * (uint32_t)(BS * DPL) + threadIdx.x;    // n <= 2^28 (fpv_create)

@@ -439,12 +439,15 @@ FPV_HD bool fpv_collide_objects(const FpvK& K, const FpvObjects& T, const float 
             else near = fmaf(dx, dx, fmaf(dy, dy, dz * dz)) < rr * rr;
         }
         if (!FPV_WAVE_ANY(near)) continue;
-        float dist[4], nx[4], ny[4], nz[4];
+        // distances of all four motors first (the crash test needs them all, components.py:203-206); the radial
+        // length rr is kept, the NORMAL (a correctly rounded division per motor) is formed only for a motor that is
+        // actually in contact - the same arithmetic in the same order, evaluated lazily
+        float dist[4], rrm[4];
 #pragma unroll
         for (int m = 0; m < 4; ++m) {
             const float rx = mx[m] - ob.x, ry = my[m] - ob.y, rz = mz[m] - ob.z;
             if (ob.type == 0) {
-                dist[m] = mz[m]; nx[m] = 0.0f; ny[m] = 0.0f; nz[m] = 1.0f;
+                dist[m] = mz[m]; rrm[m] = 1.0f;
             } else if (ob.type == 1) {
                 const float rr = sqrtf(fmaf(rx, rx, ry * ry));
                 const float d2 = rr - ob.radius;
@@ -454,18 +457,11 @@ FPV_HD bool fpv_collide_objects(const FpvK& K, const FpvObjects& T, const float 
                     const float dh = fminf(fabsf(mz[m] - ob.z), fabsf(mz[m] - top));
                     dist[m] = sqrtf(fmaf(d2, d2, dh * dh));
                 }
-                if (ob.z < rz && rz < top) {                       // relative z against absolute bounds, as written
-                    const float inv = 1.0f / rr;
-                    nx[m] = rx * inv; ny[m] = ry * inv; nz[m] = 0.0f;
-                } else {
-                    nx[m] = 0.0f; ny[m] = 0.0f;
-                    nz[m] = (fabsf(rz - ob.z) < fabsf(rz - top)) ? -1.0f : 1.0f;
-                }
+                rrm[m] = rr;
             } else {
                 const float rr = sqrtf(fmaf(rx, rx, fmaf(ry, ry, rz * rz)));
-                const float inv = 1.0f / rr;
                 dist[m] = rr - ob.radius;
-                nx[m] = rx * inv; ny[m] = ry * inv; nz[m] = rz * inv;
+                rrm[m] = rr;
             }
         }
         if (dist[0] < 0.0f || dist[1] < 0.0f || dist[2] < 0.0f || dist[3] < 0.0f) { crashed = true; break; }
@@ -473,9 +469,23 @@ FPV_HD bool fpv_collide_objects(const FpvK& K, const FpvObjects& T, const float 
         for (int m = 0; m < 4; ++m) {
             const float d = dist[m] - K.motor_radius;
             if (d < 0.0f) {
-                const float vn = fmaf(vx, nx[m], fmaf(vy, ny[m], vz * nz[m]));
+                const float rx = mx[m] - ob.x, ry = my[m] - ob.y, rz = mz[m] - ob.z;
+                float nx = 0.0f, ny = 0.0f, nz = 1.0f;             // Ground: +z
+                if (ob.type == 1) {
+                    const float top = ob.z + ob.height;
+                    if (ob.z < rz && rz < top) {                   // relative z against absolute bounds, as written
+                        const float inv = 1.0f / rrm[m];
+                        nx = rx * inv; ny = ry * inv; nz = 0.0f;
+                    } else {
+                        nz = (fabsf(rz - ob.z) < fabsf(rz - top)) ? -1.0f : 1.0f;
+                    }
+                } else if (ob.type != 0) {
+                    const float inv = 1.0f / rrm[m];
+                    nx = rx * inv; ny = ry * inv; nz = rz * inv;
+                }
+                const float vn = fmaf(vx, nx, fmaf(vy, ny, vz * nz));
                 const float f = fmaf(-K.ground_k_m, d, -K.ground_c_m * vn);
-                acc[0] = fmaf(f, nx[m], acc[0]); acc[1] = fmaf(f, ny[m], acc[1]); acc[2] = fmaf(f, nz[m], acc[2]);
+                acc[0] = fmaf(f, nx, acc[0]); acc[1] = fmaf(f, ny, acc[1]); acc[2] = fmaf(f, nz, acc[2]);
             }
         }
     }
