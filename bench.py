@@ -172,8 +172,11 @@ def parse_args(argv=None):
     ap.add_argument("--racer", choices=["written", "omega_dt"], default=None,
                     help="time the Racer.step kernel instead (mode B; not the headline)")
     ap.add_argument("--no-gather", action="store_true", help="skip the done-mask all-gather (N > 1)")
-    ap.add_argument("--gather-block", type=int, default=64,
-                    help="steps of done masks bucketed into one all-gather (N > 1)")
+    ap.add_argument("--gather-block", type=int, default=0,
+                    help="steps of done masks bucketed into one all-gather (N > 1); 0 = sized to the run: every collective "
+                         "costs the launch stream ~25 us whatever its size (measured, profiles/r02_exp_gather_block.log), so long "
+                         "runs use 64-step buckets (8 MiB per rank, 1.5 %% of the time) and runs under 256 steps 16-step buckets, "
+                         "whose unfilled tail - gathered inside the timed region - stays small")
     ap.add_argument("--gather-returns", action="store_true",
                     help="N > 1: also all-gather the per-drone last episode return (fp32) once per bucket; turns on "
                          "episode bookkeeping (+16 B per env-step), so it is off for the headline numbers")
@@ -212,7 +215,7 @@ def run_stub(args, world, rank):
         tt = torch.tensor([elapsed], dtype=torch.float64)
         dist.all_reduce(tt, op=dist.ReduceOp.MAX)
         elapsed = float(tt.item())
-        last = gather.result((args.steps - 1) // args.gather_block)
+        last = gather.result((args.steps - 1) // args.gather_block)            # a flushed bucket holds only its filled rows
         ok = all(int(last[r, (args.steps - 1) % args.gather_block, 0]) == r * 1000 + args.steps - 1 for r in range(world))
     else:
         ok = True
@@ -239,6 +242,8 @@ def main(argv=None):
                                  f"run with --gpus {max(have, 1)} (or --force-dist to rehearse the collective path on one GPU)")
         raise SystemExit(spawn_ranks(args.gpus, sys.argv[1:] if argv is None else argv))
 
+    if args.gather_block <= 0:
+        args.gather_block = 64 if args.steps + args.warmup >= 256 else 16
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
@@ -298,6 +303,7 @@ def main(argv=None):
     words = (n + 63) // 64
     if multi and not args.no_gather:
         gather = DoneGather((words,), torch.int64, dev, block=args.gather_block)
+        gather.warm_up()                    # RCCL's first-use costs stay out of a short timed region
     returns_all, returns_work = None, None
     if gather is not None and args.gather_returns:
         returns_all = torch.zeros(dist.get_world_size() * n, dtype=torch.float32, device=dev)
@@ -362,8 +368,11 @@ def main(argv=None):
         gather.drain()
         if returns_work is not None:
             returns_work.wait()
-    fence()
+    # every rank stops its own clock when ITS work (kernels + its part of the collectives) is complete; the job's time
+    # is the MAX over ranks (all-reduced below), and the closing barrier follows the clock instead of sitting inside it
+    torch.cuda.synchronize()
     elapsed = time.perf_counter() - t0
+    fence()
     dev_ms = ev0.elapsed_time(ev1)
     n_launches = launches[0]
 

@@ -59,8 +59,9 @@ class DoneGather:
         ptr = g.row(t)        # tensor the kernel writes at step t
         ... launch the step ...
         g.step_done(t)        # enqueues the all-gather when step t closed a bucket
-        g.flush(t_last)       # gather a partially filled last bucket
-        g.result(b)           # [world, block, *shard] masks of bucket b (waits for it)
+        g.flush(t_last)       # gather a partially filled last bucket: only its filled rows travel
+        g.result(b)           # [world, rows, *shard] masks of bucket b (rows = block, or the filled rows
+                              # of a flushed bucket); waits for it
 
     Shards must be the same size on every rank (pad the last one)."""
 
@@ -75,6 +76,8 @@ class DoneGather:
         # flat concatenation: the one output shape both RCCL and gloo accept for all_gather_into_tensor
         self._flat = [torch.zeros(self.world * self.local[0].numel(), dtype=dtype, device=device) for _ in range(2)]
         self.gathered = [f.view((self.world,) + shape) for f in self._flat]
+        self._view = list(self.gathered)           # what result() returns per bucket (a flushed bucket is shorter)
+        self._row_numel = self.local[0][0].numel()
         self.pending: List[Optional[object]] = [None, None]
         self._row_ptrs = [[self.local[k][r].data_ptr() for r in range(self.block)] for k in range(2)]
 
@@ -96,8 +99,12 @@ class DoneGather:
             self._wait(b & 1)             # the bucket is about to be overwritten
         return self.local[b & 1][r]
 
-    def _launch(self, k: int) -> None:
-        self.pending[k] = self._dist.all_gather_into_tensor(self._flat[k], self.local[k].view(-1), group=self.group,
+    def _launch(self, k: int, rows: Optional[int] = None) -> None:
+        rows = self.block if rows is None else rows
+        m = rows * self._row_numel
+        out = self._flat[k][:self.world * m]
+        self._view[k] = out.view((self.world, rows) + tuple(self.local[k].shape[1:]))
+        self.pending[k] = self._dist.all_gather_into_tensor(out, self.local[k][:rows].reshape(-1), group=self.group,
                                                             async_op=True)
 
     def step_done(self, t: int) -> None:
@@ -105,13 +112,25 @@ class DoneGather:
             self._launch((t // self.block) & 1)
 
     def flush(self, t_last: int) -> None:
-        """Gather the bucket holding step t_last if it was not closed by step_done."""
-        if (t_last + 1) % self.block != 0:
-            self._launch((t_last // self.block) & 1)
+        """Gather the bucket holding step t_last if it was not closed by step_done: only the rows filled so
+        far are sent (a short run, or the tail of a long one, does not pay for a whole bucket)."""
+        rows = (t_last + 1) % self.block
+        if rows != 0:
+            self._launch((t_last // self.block) & 1, rows)
 
     def result(self, bucket: int) -> torch.Tensor:
         self._wait(bucket & 1)
-        return self.gathered[bucket & 1]
+        return self._view[bucket & 1]
+
+    def warm_up(self) -> None:
+        """Run both message shapes once (a whole bucket, a flushed tail) so that the backend's first-use costs -
+        communicator channels, buffer registration - are paid before a timed region; leaves the buckets zeroed."""
+        for k in range(2):
+            self._launch(k)
+            self._wait(k)
+            self._launch(k, 1)
+            self._wait(k)
+            self.local[k].zero_()
 
     def drain(self) -> None:
         self._wait(0)

@@ -68,7 +68,9 @@ def _worker(rank, world, port, n_total, steps, out_dir):
             if (t + 1) % block == 0:
                 seen.append(g.result(t // block).clone())         # [world, block, words]
         g.flush(steps - 1)
-        seen.append(g.result((steps - 1) // block).clone()[:, :steps % block])
+        tail = g.result((steps - 1) // block).clone()
+        assert tail.shape[1] == steps % block, "a flushed bucket ships only its filled rows"
+        seen.append(tail)
         g.drain()
         seen = [torch.cat(seen, dim=1).permute(1, 0, 2)]       # -> [steps, world, words]
         np.save(os.path.join(out_dir, f"gathered_{rank}.npy"), seen[0].contiguous().numpy())
