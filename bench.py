@@ -457,9 +457,9 @@ def main(argv=None):
         }
         if args.api == "rollout":
             # the k-step kernel is limited by instruction issue, not HBM.  VALU instructions executed per env-step,
-            # measured with rocprofv3 --pmc SQ_INSTS_VALU SQ_WAVES (profiles/r02_pmc_valu_counts.log): 7092 per wave
-            # for k = 32 (fp32 state), 10007 (fp16 state); packed-fp32 instructions count once but issue twice
-            inst = (10007.0 if args.fp16_state else 7092.0) / 32.0
+            # measured with rocprofv3 --pmc SQ_INSTS_VALU SQ_WAVES (profiles/r02_pmc_valu_counts.log): 6261 per wave
+            # for k = 32 (fp32 state), 10655 (fp16 state); the build has no packed-fp32 instructions (-fno-slp-vectorize)
+            inst = (10655.0 if args.fp16_state else 6261.0) / 32.0
             out["roofline"]["valu"] = {"valu_inst_per_env_step": inst, "source": "profiles/r02_pmc_valu_counts.log (fp32/fp16 drone kernels only)",
                                        "achieved_Glane_inst_per_s": inst * n * steps_per_launch / kernel_s / 1e9,
                                        "peak_Glane_inst_per_s": VALU_PEAK_GINST,

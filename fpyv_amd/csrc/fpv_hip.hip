@@ -641,14 +641,20 @@ __global__ __launch_bounds__(BS) void fpv_racer_rollout_kernel(const FpvK K, con
         if (PIDV) fpv_settle(s.dflt[k]);
     }
     if (out.track) { fpv_settle(out.ep_r); fpv_settle(__int_as_float(out.ep_l)); }
-    for (int t = 0; t < R.k; ++t) {
+    auto one_step = [&](int t, auto quiet_c) {                           // see fpv_drone_rollout_kernel
+        constexpr bool QUIET = decltype(quiet_c)::value;
         const float4 a = a_next;
         if (R.action_stride && t + 1 < R.k) { ap += R.action_stride; a_next = ld_action(reinterpret_cast<const float4*>(ap), i); }
-        const float reward = fpv_racer_step_lane<WIDE, PIDV ? 1 : 0>(K, s, a.x, a.y, a.z, a.w);
+        const float reward = fpv_racer_step_lane<WIDE, PIDV ? 1 : 0, !QUIET>(K, s, a.x, a.y, a.z, a.w);
         const bool done = !(fabsf(s.pz) <= K.ceiling);
         if ((K.flags & FPV_FLAG_AUTO_RESET) && done) fpv_racer_reset_lane(s);
-        out.step(i, t, reward, done);
+        out.template step<QUIET>(i, t, reward, done);
+    };
+    int t = 0;
+    if (!out.track && R.out_stride == 0) {
+        for (; t < R.k - 1; ++t) one_step(t, std::true_type{});
     }
+    for (; t < R.k; ++t) one_step(t, std::false_type{});
     uint32_t j = i;                                  // form the store addresses after the loop (VGPR pressure)
     asm volatile("" : "+v"(j));
     st_racer<WIDE, PIDV>(B.state, B.ld, j, s);

@@ -738,7 +738,7 @@ FPV_HD T fpv_pid_axis(const FpvPidK<T>& P, int i, T actual, T desired, bool firs
 // rounding would add up coherently (6e-5 over 1000 steps).  In float64 only the final rounding of q
 // to fp32 remains, which is incoherent: measured 7e-7 on the reference captures G7/G8 over the whole
 // 1000-step trajectory.  The racer_omega_dt variant (angle = omega*dt) is well conditioned in fp32.
-template <bool WIDE, int PIDV = 0>
+template <bool WIDE, int PIDV = 0, bool OUT = true>
 FPV_HD float fpv_racer_step_lane(const FpvK& K, FpvRacerState& s, float a0, float a1, float a2, float a3)
 {
     const float act[3] = {a0, a1, a2};
@@ -804,6 +804,7 @@ FPV_HD float fpv_racer_step_lane(const FpvK& K, FpvRacerState& s, float a0, floa
     s.vy = fmaf(K.r_damp, s.vy, f * R.r12);
     s.vz = fmaf(K.r_damp, s.vz, f * R.r22);
     s.px = fmaf(s.vx, K.r_dt, s.px); s.py = fmaf(s.vy, K.r_dt, s.py); s.pz = fmaf(s.vz, K.r_dt, s.pz);
+    if (!OUT) return 0.0f;                           // a k-step launch's quiet steps store no reward
     const float gx = s.px - K.goal[0], gy = s.py - K.goal[1], gz = s.pz - K.goal[2];
     return -sqrtf(fmaf(gx, gx, fmaf(gy, gy, gz * gz)));
 }
