@@ -1226,3 +1226,31 @@ def test_guidance_override_vs_reference_capture(params_1k):
     with pytest.raises(ValueError):
         env.step(np.zeros(4, np.float32), rotation_matrix=np.zeros((4, 3, 3)), thrust_force=1.0)
     assert env._buf.rotation_override is None and env._buf.thrust_override is None, "the override must not outlive its step"
+
+
+@pytest.mark.parametrize("seed", range(4))
+def test_random_drone_types_bitwise_and_1e5(params_1k, seed):
+    """Drone types far from params.yaml (tests/parity.py::random_drone_params: mass, X or rectangular frame, thrust
+    curve, drag, rates, low-pass constants, gravity, dt): the single-step kernel and the k-step kernel (which
+    picks the two-height ground flag only for the X frame) equal the host build bit for bit and hold 1e-5 against
+    the float64 oracle after 1000 steps."""
+    from parity import assert_parity_random_type, random_drone_params
+    rng = np.random.default_rng(1000 + seed)
+    p = random_drone_params(params_1k, rng)
+    n, steps = 333, 1000
+    acts = sticks.ema_noise(steps, range(n), seed=seed)
+    acts[..., 3] += np.float32(rng.uniform(-0.7, -0.3))
+    model = lane_model.initial_state(p, n)
+    a = torch.from_numpy(acts).to(DEV)
+    single, fused = _drone_batch(p, n), _drone_batch(p, n)
+    for e in (single, fused):
+        e.state[:, :n] = torch.from_numpy(model[:, :n]).to(DEV)
+    single.rollout(a, fused=False)
+    fused.rollout(a)
+    lane_model.run(p, model, acts)
+    got = single.state.cpu().numpy()
+    assert np.array_equal(got[:, :n].view(np.uint32), model[:, :n].view(np.uint32)), "kernel != lane model (bitwise)"
+    assert torch.equal(single.state, fused.state) and torch.equal(single.done_u8, fused.done_u8)
+    ref = oracle.drone_initial_state(n, p.init_position, p.init_velocity, p.init_orientation_deg)
+    oracle.drone_run(p, ref, acts.astype(np.float64))
+    assert_parity_random_type(got, ref, n, p, REL_TOL, f"random drone type {seed}")

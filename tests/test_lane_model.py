@@ -379,3 +379,21 @@ def test_square_frame_ground_flag_shortcut_is_exact(params_1k):
     assert np.array_equal(outs[0][1], outs[1][1])
     assert np.array_equal(outs[0][0].view(np.uint32), outs[1][0].view(np.uint32))
     assert 0.2 < outs[0][1][0].mean() < 0.8, "the first step must sit on the flip boundary"
+
+
+@pytest.mark.parametrize("seed", range(6))
+def test_random_drone_types_within_1e5(params_1k, seed):
+    """The 1e-5 bar on position / quaternion after 1000 steps for drone types far from params.yaml (mass, frame,
+    thrust curve, drag, rates, low-pass constants, gravity, dt 1/250 .. 1/2000 s, random initial pose)."""
+    from fpyv_amd import sticks
+    from parity import assert_parity_random_type, random_drone_params
+    rng = np.random.default_rng(1000 + seed)
+    p = random_drone_params(params_1k, rng)
+    n, steps = 333, 1000
+    acts = sticks.ema_noise(steps, range(n), seed=seed)
+    acts[..., 3] += np.float32(rng.uniform(-0.7, -0.3))
+    ref = oracle.drone_initial_state(n, p.init_position, p.init_velocity, p.init_orientation_deg)
+    oracle.drone_run(p, ref, acts.astype(np.float64))
+    s = lane_model.initial_state(p, n)
+    lane_model.run(p, s, acts)
+    assert_parity_random_type(s, ref, n, p, REL_TOL, f"random drone type {seed} (dt {p.dt:g}, max_rates {p.max_rates:.0f})")
