@@ -30,6 +30,7 @@ def main():
     ap.add_argument("--graph", action="store_true", help="also time the hipGraph-replayed rollout")
     ap.add_argument("--fused", action="store_true", help="also time the k-step kernel (fpv_step_n), k = ring span per launch")
     ap.add_argument("--racer", action="store_true", help="also time the Racer kernels (as written / omega*dt / components.PID)")
+    ap.add_argument("--ovr", action="store_true", help="also time the guidance-override step (rotation_matrix= / thrust_force=)")
     ap.add_argument("--out", default=None)
     a = ap.parse_args()
     dev = torch.device("cuda:0")
@@ -79,7 +80,17 @@ def main():
             for blk in ("1x128", "1x256"):
                 envs[tag + blk] = er
                 a.geom = list(a.geom) + [tag + blk]
-    variants = [(g, api) for g in a.geom for api in ("rollout", "step")]
+    if a.ovr:
+        eg = DroneBatch(p, a.n, device=dev, with_accel=False)
+        eg.reset()
+        ang = torch.rand(a.n, device=dev) * 0.3
+        zero, one = torch.zeros_like(ang), torch.ones_like(ang)
+        rot_over = torch.stack([ang.cos(), zero, ang.sin(), zero, one, zero, -ang.sin(), zero, ang.cos()], dim=1).contiguous()   # Ry
+        thrust_over = torch.full((a.n,), 7.4, device=dev)
+        eg._buf.rotation_override, eg._buf.thrust_override = rot_over.data_ptr(), thrust_over.data_ptr()
+        envs["ovr1x128"] = eg
+        a.geom = list(a.geom) + ["ovr1x128"]
+    variants = [(g, api) for g in a.geom for api in ("rollout", "step") if not (g.startswith("ovr") and api == "rollout")]
     if a.graph:
         variants += [(g, "graph") for g in a.geom if g[0].isdigit()]
     if a.fused:
@@ -91,7 +102,7 @@ def main():
             d, api = v
             e = envs[d]
             e.set_tuning(*[int(x) for x in d.replace("aos", "").replace("noise", "").replace("kahan", "").replace("obj", "")
-                           .replace("racerWC", "").replace("racerW", "").replace("racerD", "").lstrip("h").split("x")])
+                           .replace("racerWC", "").replace("racerW", "").replace("racerD", "").replace("ovr", "").lstrip("h").split("x")])
             torch.cuda.synchronize()
             ev0.record()
             done = 0
@@ -110,6 +121,9 @@ def main():
                     else:
                         for t in range(span):
                             e.step(acts[t], object_list=world, return_imu=False)
+                elif d.startswith("ovr"):
+                    for t in range(span):
+                        e._step_raw(acts[t])                   # the override pointers stay bound in e._buf
                 elif api == "graph":
                     e.rollout(acts[:span], graph=True)
                 elif api in ("rollout", "fused"):
@@ -124,7 +138,7 @@ def main():
                 times[v].append(ev0.elapsed_time(ev1) * 1e3 / a.launches)
     res = []
     for v in variants:
-        B = envs[v[0]].algorithmic_bytes() + (64 if v[0].startswith("aos") else 0) + (16 if v[0].startswith("noise") else 0) + (48 if v[0].startswith("kahan") else 0)
+        B = envs[v[0]].algorithmic_bytes() + (64 if v[0].startswith("aos") else 0) + (16 if v[0].startswith("noise") else 0) + (48 if v[0].startswith("kahan") else 0) + (40 if v[0].startswith("ovr") else 0)
         if v[1] == "fused":        # state traffic amortised over the ring span; reward/done only after the last step
             B = 16 + (B - 16) / min(a.ring, a.launches) if not v[0].startswith("noise") else (B - 16) / min(a.ring, a.launches)
         med, mn = statistics.median(times[v]), min(times[v])
