@@ -88,7 +88,11 @@ __device__ __forceinline__ T& row_at(T* row_base, uint32_t i)
 #else
 #define LDROW(st, r, ld, i) row_at(ROW(st, r, ld), i)
 #endif
-#if FPV_EXP_ST_NT
+#if FPV_EXP_ST_NT == 2       // write-through and drop from L2: global_store ... sc0 sc1
+#define STROW(st, r, ld, i, v) __hip_atomic_store(&row_at(ROW(st, r, ld), i), (v), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM)
+#elif FPV_EXP_ST_NT == 3     // agent scope: sc1
+#define STROW(st, r, ld, i, v) __hip_atomic_store(&row_at(ROW(st, r, ld), i), (v), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)
+#elif FPV_EXP_ST_NT
 #define STROW(st, r, ld, i, v) __builtin_nontemporal_store((v), &row_at(ROW(st, r, ld), i))
 #else
 #define STROW(st, r, ld, i, v) (row_at(ROW(st, r, ld), i) = (v))

@@ -15,6 +15,8 @@ VARIANTS = {
     "ld_nt": ["-DFPV_EXP_LD_NT=1"],
     "st_nt": ["-DFPV_EXP_ST_NT=1"],
     "ld_st_nt": ["-DFPV_EXP_LD_NT=1", "-DFPV_EXP_ST_NT=1"],
+    "st_sys": ["-DFPV_EXP_ST_NT=2"],          # state stores write through and leave L2 (sc0 sc1)
+    "st_agent": ["-DFPV_EXP_ST_NT=3"],        # agent-scope stores (sc1)
 }
 ap = argparse.ArgumentParser()
 ap.add_argument("--build", action="store_true")

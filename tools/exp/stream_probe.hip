@@ -17,6 +17,12 @@ __global__ void k_rows(float* x, size_t n, size_t ld) { size_t i = blockIdx.x * 
   for (int r = 0; r < 14; ++r) v[r] = x[r * ld + i];
 #pragma unroll
   for (int r = 0; r < 14; ++r) x[r * ld + i] = v[r] * 1.0001f; } }
+// the same 14 streams, but written to a SECOND set of rows (ping-pong state): no read->write turnaround on one address
+__global__ void k_rows_copy(float* y, const float* x, size_t n, size_t ld) { size_t i = blockIdx.x * (size_t)blockDim.x + threadIdx.x; if (i < n) { float v[14];
+#pragma unroll
+  for (int r = 0; r < 14; ++r) v[r] = x[r * ld + i];
+#pragma unroll
+  for (int r = 0; r < 14; ++r) y[r * ld + i] = v[r] * 1.0001f; } }
 typedef float v2 __attribute__((ext_vector_type(2)));
 // AoSoA planes: 3 float4 planes + 1 float2 plane per drone (56 B), one drone per lane
 __global__ void k_planes(v4* p0, v4* p1, v4* p2, v2* p3, size_t n) { size_t i = blockIdx.x * (size_t)blockDim.x + threadIdx.x; if (i < n) {
@@ -40,8 +46,9 @@ template <class F> double timeit(F f, int reps) {
   hipEvent_t a, b; CK(hipEventCreate(&a)); CK(hipEventCreate(&b)); std::vector<float> ts;
   for (int r = 0; r < 7; ++r) { CK(hipEventRecord(a)); for (int i = 0; i < reps; ++i) f(); CK(hipEventRecord(b)); CK(hipEventSynchronize(b)); float ms; CK(hipEventElapsedTime(&ms, a, b)); ts.push_back(ms / reps); }
   std::sort(ts.begin(), ts.end()); return ts[ts.size() / 2] * 1e-3; }
-int main() {
-  const size_t sizes[] = {59u << 20, 118u << 20};
+int main(int argc, char** argv) {
+  std::vector<size_t> sizes = {59u << 20, 118u << 20};                 // or: ./stream_probe <MiB> <MiB> ... (<= 1024)
+  if (argc > 1) { sizes.clear(); for (int i = 1; i < argc; ++i) sizes.push_back((size_t)atoi(argv[i]) << 20); }
   float* buf; float* buf2; float* sink; CK(hipMalloc(&buf, 1024u << 20)); CK(hipMalloc(&buf2, 1024u << 20)); CK(hipMalloc(&sink, 64));
   CK(hipMemset(buf, 0, 1024u << 20)); CK(hipMemset(buf2, 0, 1024u << 20));
   for (size_t bytes : sizes) {
@@ -62,6 +69,7 @@ int main() {
       t = timeit([&] { k_rows_tiled<256><<<nt / 256, 256>>>(buf, nt); }, reps); printf("%5zu MiB tiled W=256 bs=256     : %7.2f us  %7.1f GB/s (R+W)\n", bytes >> 20, t * 1e6, 2.0 * nt * 56 / t / 1e9);
       t = timeit([&] { k_rows_tiled<1024><<<nt / 128, 128>>>(buf, nt); }, reps); printf("%5zu MiB tiled W=1024 bs=128    : %7.2f us  %7.1f GB/s (R+W)\n", bytes >> 20, t * 1e6, 2.0 * nt * 56 / t / 1e9); }
     size_t nd = bytes / 56; size_t ld = ((nd + 63) / 64) * 64 + 256; if (14 * ld * 4 <= (1024u << 20)) {
-      for (int b2 : {128, 256}) { t = timeit([&] { k_rows<<<(nd + b2 - 1) / b2, b2>>>(buf, nd, ld); }, reps); printf("%5zu MiB 14-row rmw bs=%3d     : %7.2f us  %7.1f GB/s (R+W)\n", bytes >> 20, b2, t * 1e6, 2.0 * nd * 56 / t / 1e9); } }
+      for (int b2 : {128, 256}) { t = timeit([&] { k_rows<<<(nd + b2 - 1) / b2, b2>>>(buf, nd, ld); }, reps); printf("%5zu MiB 14-row rmw bs=%3d     : %7.2f us  %7.1f GB/s (R+W)\n", bytes >> 20, b2, t * 1e6, 2.0 * nd * 56 / t / 1e9); }
+      { bool flip = false; t = timeit([&] { flip = !flip; k_rows_copy<<<(nd + 127) / 128, 128>>>(flip ? buf2 : buf, flip ? buf : buf2, nd, ld); }, reps); printf("%5zu MiB 14-row ping-pong bs=128: %7.2f us  %7.1f GB/s (R+W)\n", bytes >> 20, t * 1e6, 2.0 * nd * 56 / t / 1e9); } }
   }
   return 0; }
