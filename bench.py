@@ -230,6 +230,9 @@ def run_stub(args, world, rank):
 
 
 def main(argv=None):
+    # multi-process GPU work on this pool needs dmabuf IPC (the host driver has no legacy IPC): without it RCCL fails
+    # with "hipIpcGetMemHandle: invalid argument".  Set before anything loads the HIP runtime.
+    os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
     args = parse_args(argv)
     in_rank = "WORLD_SIZE" in os.environ and "RANK" in os.environ
     if args.gpus > 1 and not in_rank:
