@@ -1245,10 +1245,10 @@ int fpv_rollout_graph(fpv_handle_t h, const fpv_buffers_t* b, int k, int64_t act
     if (rc != FPV_OK) return rc;
     if (k <= 0) return fail(FPV_EINVAL, "k must be positive");
     if (action_stride % 4) return fail(FPV_EALIGN, "action_stride must keep 16-byte alignment");
-    if (h->K.flags & (FPV_FLAG_STICK_NOISE | FPV_FLAG_FP16_STATE))
-        return fail(FPV_EINVAL, "fpv_rollout_graph replays frozen kernel arguments; stick noise and fp16 state need the "
-                                "per-launch step index - use fpv_step_n or fpv_rollout");
     if (b->rotation_override) return fail(FPV_EINVAL, "the guidance override is a per-step input: use fpv_step");
+    // a graph replays frozen kernel arguments, but stick noise and the fp16 rounding are keyed by the per-launch step
+    // index: such handles take the k-step kernel instead - the same k steps bit for bit, and cheaper than the replay
+    if (h->K.flags & (FPV_FLAG_STICK_NOISE | FPV_FLAG_FP16_STATE)) return fpv_step_n(h, b, k, action_stride, out_stride, stream);
     if ((rc = bind_device(h)) != FPV_OK) return rc;
     const FpvBufD d0 = to_device_view(b);
     // SHAPE of the graph: everything that selects kernels, grids and non-pointer arguments

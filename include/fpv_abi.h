@@ -246,7 +246,8 @@ int fpv_set_step_counter(fpv_handle_t h, uint32_t step);
  * batches (a 4096-drone step is ~2 us of kernel behind ~4 us of launch).  The graph is rebuilt only when
  * its SHAPE changes (k, strides, launch geometry, parameters, which optional buffers are present); new
  * buffer addresses alone are patched into the instantiated graph.  Frozen arguments mean no per-launch
- * step index, so handles with FPV_FLAG_STICK_NOISE or FPV_FLAG_FP16_STATE are refused (use fpv_step_n). */
+ * step index, so handles with FPV_FLAG_STICK_NOISE or FPV_FLAG_FP16_STATE are served by the k-step kernel
+ * (fpv_step_n: the same k steps bit for bit, and cheaper than a replay). */
 int fpv_rollout_graph(fpv_handle_t h, const fpv_buffers_t* b, int k, int64_t action_stride,
                       int64_t out_stride, void* stream);
 

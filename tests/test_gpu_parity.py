@@ -778,10 +778,19 @@ def test_graph_rollout_equals_plain_rollout(params_1k):
     torch.cuda.synchronize()
     assert torch.equal(e1.state, e2.state) and torch.equal(r1, r2) and torch.equal(e1.done_u8, e2.done_u8)
     assert e1.state_dict()["step_counter"] == e2.state_dict()["step_counter"] == 5 * k
-    noisy = DroneBatch(params_1k, 64, device=DEV, stick_noise=True)
-    noisy.reset()
-    with pytest.raises(_lib.FpvError, match="fpv_rollout"):
-        noisy.rollout(acts[:, :64].contiguous(), graph=True)
+    # stick-noise / fp16 handles are keyed by the per-launch step index, which a graph would freeze: they are served by
+    # the k-step kernel, with the same result as k plain launches
+    a64 = acts[:, :64].contiguous()
+    for kw in (dict(stick_noise=True, noise_seed=3), dict(fp16_state=True)):
+        g1, g2 = DroneBatch(params_1k, 64, device=DEV, **kw), DroneBatch(params_1k, 64, device=DEV, **kw)
+        g1.reset(); g2.reset()
+        for rep in range(2):
+            g1.rollout(a64, fused=False)
+            g2.rollout(a64, graph=True)
+        torch.cuda.synchronize()
+        assert torch.equal(g1.state, g2.state) and torch.equal(g1.done_u8, g2.done_u8)
+        if g1.state_h is not None:
+            assert torch.equal(g1.state_h.view(torch.int16), g2.state_h.view(torch.int16))
 
 
 def test_set_params_on_a_live_handle(params_1k):
