@@ -423,8 +423,14 @@ class DroneBatch(_Batch):
         params = as_drone_params(params, mode=MODE_DRONE)
         kw.setdefault("with_accel", True)
         super().__init__(params, num_envs, device, **kw)
+        # the scalar attributes callers of the reference's Drone read (components.py:86-142)
         self.dt = params.dt
-        self.max_rates = params.max_rates                      # components.py:87
+        self.max_rates = params.max_rates                      # :87
+        self.mass, self.gravity = params.mass, params.gravity  # :92, :97
+        self.throttle2thrust = params.thrust_from_stick        # :136  stick in [-1, 1] -> total thrust [N]
+        self.thrust2throttle = params.stick_from_thrust        # :137  thrust [N] -> stick, clipped to [-1, 1]
+        self.min_throttle_in_force = params.min_throttle_in_force   # :140
+        self.max_throttle_in_force = params.max_throttle_in_force   # :142
 
     def reset(self, position=None, velocity=None, ypr=None, mask=None) -> None:
         """Drone.reset: `ypr` is consumed as (roll, pitch, yaw) in degrees, like the reference
@@ -489,6 +495,15 @@ class DroneBatch(_Batch):
     @property
     def prev_thrust(self) -> torch.Tensor:
         return self.rows_f32(_lib.THRUST, _lib.THRUST + 1)[:, 0]
+
+    @property
+    def throttle(self) -> Optional[torch.Tensor]:
+        """[num_envs] throttle stick of the last step (Drone.throttle, components.py:186; simulator.py:161 prints it).
+        None before the first step or after a step driven purely by in-kernel stick noise (read `action_out` then)."""
+        a = getattr(self, "_keepalive", None)
+        if a is None or self._buf.action is None:
+            return None
+        return a[3] if self._buf.action_ld else a[:, 3]
 
 
 class RacerBatch(_Batch):

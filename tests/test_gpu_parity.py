@@ -1263,3 +1263,24 @@ def test_random_drone_types_bitwise_and_1e5(params_1k, seed):
     ref = oracle.drone_initial_state(n, p.init_position, p.init_velocity, p.init_orientation_deg)
     oracle.drone_run(p, ref, acts.astype(np.float64))
     assert_parity_random_type(got, ref, n, p, REL_TOL, f"random drone type {seed}")
+
+
+def test_reference_scalar_attributes_of_drone(params_1k):
+    """The attributes simulator.py reads off the Drone besides position / velocity / done (`throttle` :161,
+    `prev_rates` / `prev_thrust` :64-65) and the thrust-curve helpers of components.py:136-142, against the
+    constants captured from the reference."""
+    g = load_golden("params_golden")
+    env = _drone_batch(params_1k, 7)
+    env.reset()
+    assert env.throttle is None
+    a = torch.linspace(-1, 1, 28, device=DEV).reshape(7, 4).contiguous()
+    env.step(a, return_imu=False)
+    assert torch.equal(env.throttle, a[:, 3])
+    env.step(np.array([0.1, 0.2, 0.3, -0.25], dtype=np.float32), return_imu=False)      # broadcast sticks
+    assert torch.allclose(env.throttle, torch.full((7,), -0.25, device=DEV))
+    np.testing.assert_allclose(env.throttle2thrust(g["stick_samples"]), g["thrust_samples"], rtol=1e-10, atol=1e-12)
+    np.testing.assert_allclose(env.thrust2throttle(np.array([0.0, 5.0, 31.5, 60.0, 90.0])), g["thrust2throttle_samples"], rtol=1e-10, atol=1e-12)
+    assert abs(env.min_throttle_in_force - float(g["min_throttle_in_force"])) < 1e-10
+    assert abs(env.max_throttle_in_force - float(g["max_throttle_in_force"])) < 1e-10
+    assert env.mass == float(g["mass"]) and env.gravity == float(g["gravity"]) and env.max_rates == float(g["max_rates"])
+    assert env.prev_rates.shape == (7, 3) and env.prev_thrust.shape == (7,)
