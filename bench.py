@@ -182,6 +182,13 @@ def parse_args(argv=None):
                          "episode bookkeeping (+16 B per env-step), so it is off for the headline numbers")
     ap.add_argument("--force-dist", action="store_true",
                     help="rehearsal: run the RCCL process group + all-gather path even with one rank")
+    ap.add_argument("--rehearse-on-one-gpu", action="store_true",
+                    help="TEST ONLY (tests/test_gpu_parity.py): run the real N-rank path - shards, per-rank stick streams, kernels, "
+                         "bucketed done-mask all-gather, flush, MAX over ranks - with every rank on GPU 0 and the gloo backend (RCCL "
+                         "refuses two ranks on one device); the line is marked data=rehearsal and its value means nothing")
+    ap.add_argument("--dump-gathered", default=None,
+                    help="with --rehearse-on-one-gpu: rank 0 saves the gathered done masks of the last bucket and every rank its "
+                         "own final state to this directory (the test compares them with a single-process run)")
     ap.add_argument("--stub-step", action="store_true",
                     help="TEST ONLY (tests/test_bench_spawn.py): no GPU, gloo, a no-op step - exercises the spawn, rendezvous, "
                          "barrier, max-over-ranks and JSON plumbing; the line it prints is marked data=stub and measures nothing")
@@ -237,7 +244,7 @@ def main(argv=None):
     in_rank = "WORLD_SIZE" in os.environ and "RANK" in os.environ
     if args.gpus > 1 and not in_rank:
         # self-launch: nothing in this process has touched the GPU yet (device_count() does not initialise it)
-        if not args.stub_step:
+        if not args.stub_step and not args.rehearse_on_one_gpu:
             import torch
             have = torch.cuda.device_count()
             if have < args.gpus:
@@ -263,6 +270,8 @@ def main(argv=None):
 
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs a GPU: the stepper has no CPU path")
+    if args.rehearse_on_one_gpu:
+        local_rank = 0                                   # every rank on GPU 0 (at most 6 processes may share the card)
     if torch.cuda.device_count() <= local_rank:
         raise SystemExit(f"rank {rank} needs GPU {local_rank}, this node has {torch.cuda.device_count()}")
     torch.cuda.set_device(local_rank)
@@ -272,7 +281,10 @@ def main(argv=None):
         if "MASTER_ADDR" not in os.environ:
             os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT="29517", RANK="0", WORLD_SIZE="1")
         with stdout_to_stderr():
-            dist.init_process_group(backend="nccl", device_id=dev)
+            if args.rehearse_on_one_gpu:
+                dist.init_process_group(backend="gloo")
+            else:
+                dist.init_process_group(backend="nccl", device_id=dev)
             warm = torch.zeros(1, device=dev)
             dist.all_reduce(warm)
             torch.cuda.synchronize()
@@ -385,6 +397,13 @@ def main(argv=None):
         elapsed = float(t.item())
 
     assert bool(torch.isfinite(env.state).all()), "non-finite state after the benchmark"
+    if args.dump_gathered and gather is not None:
+        import numpy as np
+        os.makedirs(args.dump_gathered, exist_ok=True)
+        last_t = args.warmup + args.steps - 1
+        if rank == 0:        # [world, rows, words] masks of the bucket that holds the last step
+            np.save(os.path.join(args.dump_gathered, "gathered_last_bucket.npy"), gather.result(last_t // args.gather_block).cpu().numpy())
+        np.save(os.path.join(args.dump_gathered, f"state_rank{rank}.npy"), env.state.cpu().numpy())
 
     # the same kernel with its state far outside the 256 MiB Infinity Cache (2^23 drones: 470 MB of state):
     # what a GPU-filling population sees; the 2^20-drone state (59 MB) lives in that cache between steps
@@ -439,7 +458,7 @@ def main(argv=None):
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": elapsed * 1e3 / args.steps,
             "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
-            "dtype": "f32", "data": "synthetic",
+            "dtype": "f32", "data": "rehearsal (every rank on GPU 0, gloo): not a measurement" if args.rehearse_on_one_gpu else "synthetic",
             "state_storage": "f16(v,q,rates,thrust)+f32(p)" if args.fp16_state else "f32",
             "config": {"workload": cfg_name
                        + f"{n} drones/GPU, EMA-noise sticks (noise_smooth_test profile), fp32 math, dt=1ms, "

@@ -1284,3 +1284,40 @@ def test_reference_scalar_attributes_of_drone(params_1k):
     assert abs(env.max_throttle_in_force - float(g["max_throttle_in_force"])) < 1e-10
     assert env.mass == float(g["mass"]) and env.gravity == float(g["gravity"]) and env.max_rates == float(g["max_rates"])
     assert env.prev_rates.shape == (7, 3) and env.prev_thrust.shape == (7,)
+
+
+def test_two_ranks_rehearsed_on_one_gpu(params_1k, tmp_path):
+    """The real N-rank path of bench.py at world size 2 - self-launched ranks, per-rank stick streams, the step kernels,
+    the bucketed asynchronous done-mask all-gather with its flush, MAX over ranks, one JSON line - with both ranks on
+    GPU 0 over gloo (RCCL refuses two ranks on one device; the driver's multi-GPU run uses RCCL).  Every rank's final
+    state and the gathered masks of the last bucket must equal a single-process run of the same shards, bit for bit."""
+    import json
+    import os
+    import subprocess
+    import sys
+    from conftest import REPO
+    n, steps, warm, ring = 4096, 40, 8, 8
+    env = {k: v for k, v in os.environ.items() if k not in ("RANK", "LOCAL_RANK", "WORLD_SIZE", "MASTER_ADDR", "MASTER_PORT", "LOCAL_WORLD_SIZE")}
+    r = subprocess.run([sys.executable, os.path.join(REPO, "bench.py"), "--gpus", "2", "--rehearse-on-one-gpu", "--steps", str(steps),
+                        "--warmup", str(warm), "--drones-per-gpu", str(n), "--ring", str(ring), "--preheat-s", "0", "--no-cpu-baseline",
+                        "--dump-gathered", str(tmp_path)], capture_output=True, text=True, timeout=600, env=env)
+    assert r.returncode == 0, r.stderr[-3000:]
+    lines = [ln for ln in r.stdout.splitlines() if ln.strip()]
+    assert len(lines) == 1, lines
+    out = json.loads(lines[0])
+    assert out["n_gpus"] == 2 and out["steps"] == steps and out["data"].startswith("rehearsal")
+    assert out["config"]["global_drones"] == 2 * n and "allgather(done_bits x16 steps)" in out["config"]["parallelism"]
+    gathered = np.load(tmp_path / "gathered_last_bucket.npy")              # [world, rows, words]
+    total, block = warm + steps, 16
+    first = (total - 1) // block * block
+    assert gathered.shape == (2, total - first, n // 64)
+    p = load_params(fps=1000, ceiling=100.0)
+    for rank in range(2):
+        acts = sticks.ema_noise_device(ring, n, DEV, seed=1234 + rank)
+        ref = _drone_batch(p, n, auto_reset=True, with_accel=False, with_done_bits=True)
+        ref.reset()
+        for t in range(total):
+            ref.step(acts[t % ring], return_imu=False)
+            if t >= first:
+                assert np.array_equal(ref.done_bits.cpu().numpy(), gathered[rank, t - first]), f"rank {rank} step {t}"
+        assert np.array_equal(ref.state.cpu().numpy().view(np.uint32), np.load(tmp_path / f"state_rank{rank}.npy").view(np.uint32))
