@@ -12,7 +12,8 @@ BEFORE the timed region into a ring of action batches, so every timed step reads
 16.8 MB action batch from HBM.  A "step" is one pass of the hot path over the batch: with
 `--api step` (the headline) one kernel launch through the C ABI per step (fpv_step: what a closed
 policy loop pays); with `--api rollout` the k-step kernel (fpv_step_n) advances a whole ring span per
-launch with the drones held in registers (open-loop sticks: 21 + 112/k bytes per env-step).
+launch with the drones held in registers (open-loop sticks: 16 + 117/k bytes per env-step - the action row every
+step, the 112-byte state round trip and the 5 bytes of reward/done once per launch).
 With N > 1 GPUs the drones are sharded contiguously (weak scaling: 2^20 per GPU) and each step's
 bit-packed done mask is all-gathered over RCCL, asynchronously, bucketed and double-buffered.
 
@@ -112,10 +113,13 @@ def cpu_baseline(params, seconds_budget=12.0):
                                "tile whose state stays in its L1/L2, and there is no shared write"}
 
 
-def spawn_ranks(n_ranks, argv, port=None, python=sys.executable):
+def spawn_ranks(n_ranks, argv, port=None, python=sys.executable, wall_limit_s=1500.0):
     """`bench.py --gpus N` outside torchrun: start N fresh child processes (one rank per GPU) BEFORE this
-    process touches the GPU, forward rank 0's stdout (the one JSON line), return the worst exit code.
-    Never re-execs: the parent only waits."""
+    process touches the GPU, forward rank 0's stdout (the one JSON line), return the first non-zero exit code.
+    Never re-execs: the parent only watches.  ALL children are polled together: the first rank that exits non-zero
+    (no GPU, an import error, the non-finite-state assert) ends the job at once - its siblings would otherwise sit in
+    the rendezvous, an all-gather or a barrier until the backend's own 10-30 min timeout - and `wall_limit_s` bounds
+    the whole run (exit code 124, like timeout(1))."""
     import socket
     if port is None:
         with socket.socket() as s:
@@ -127,10 +131,38 @@ def spawn_ranks(n_ranks, argv, port=None, python=sys.executable):
                    MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), HSA_ENABLE_IPC_MODE_LEGACY="0")
         procs.append(subprocess.Popen([python, os.path.abspath(__file__)] + list(argv), env=env,
                                       stdout=(None if r == 0 else subprocess.DEVNULL)))
-    rc = 0
-    for p in procs:
-        rc = max(rc, abs(p.wait()))
-    return rc
+
+    def stop(ps):
+        for q in ps:                       # exactly the PIDs started above: terminate, then kill what ignores it
+            if q.poll() is None:
+                q.terminate()
+        t_end = time.monotonic() + 10.0
+        for q in ps:
+            try:
+                q.wait(timeout=max(0.1, t_end - time.monotonic()))
+            except subprocess.TimeoutExpired:
+                q.kill()
+                q.wait()
+
+    deadline = time.monotonic() + wall_limit_s
+    live = dict(enumerate(procs))
+    while live:
+        for r, q in list(live.items()):
+            code = q.poll()
+            if code is None:
+                continue
+            del live[r]
+            if code != 0:
+                print(f"bench.py: rank {r} exited with {code}; stopping the other {len(live)} rank(s)", file=sys.stderr)
+                stop(list(live.values()))
+                return abs(code) or 1
+        if live and time.monotonic() > deadline:
+            print(f"bench.py: ranks {sorted(live)} still running after {wall_limit_s:.0f} s; stopping them", file=sys.stderr)
+            stop(list(live.values()))
+            return 124
+        if live:
+            time.sleep(0.05)
+    return 0
 
 
 class stdout_to_stderr:
@@ -158,7 +190,6 @@ def parse_args(argv=None):
                          "GPU has left its idle clocks (the timed region is only K x ~25 us)")
     ap.add_argument("--drones-per-gpu", type=int, default=1 << 20)
     ap.add_argument("--ring", type=int, default=32, help="distinct pre-generated action batches")
-    ap.add_argument("--dpl", type=int, default=0, help="drones per lane (0 = library default)")
     ap.add_argument("--api", choices=["rollout", "step", "rollout-launches"], default="step",
                     help="step (headline): one Python env.step() = one launch per step; rollout: the k-step kernel "
                          "(fpv_step_n), one launch per ring span; rollout-launches: k single-step launches from one C call")
@@ -189,10 +220,48 @@ def parse_args(argv=None):
     ap.add_argument("--dump-gathered", default=None,
                     help="with --rehearse-on-one-gpu: rank 0 saves the gathered done masks of the last bucket and every rank its "
                          "own final state to this directory (the test compares them with a single-process run)")
+    ap.add_argument("--spawn-timeout-s", type=float, default=1500.0,
+                    help="self-launched ranks (--gpus N outside a launcher): wall-clock limit of the whole job")
+    ap.add_argument("--stub-fail-rank", type=int, default=-1,
+                    help="TEST ONLY (tests/test_bench_spawn.py): this rank exits 1 before it joins the process group")
     ap.add_argument("--stub-step", action="store_true",
                     help="TEST ONLY (tests/test_bench_spawn.py): no GPU, gloo, a no-op step - exercises the spawn, rendezvous, "
                          "barrier, max-over-ranks and JSON plumbing; the line it prints is marked data=stub and measures nothing")
     return ap.parse_args(argv)
+
+
+def collective_report(dist, world_env, rank, dev, gather, local_ms_per_step):
+    """What lets a reader of the N-rank line verify that the collective really spanned N ranks without trusting the
+    headline number: the world size the process group reports once it is up, the backend and its library version, an
+    all-gather of every rank's id (must come back as 0..N-1, in order) and of every rank's own ms per step."""
+    import torch
+    out = {"backend": None, "world_env": world_env, "world_seen": 1, "rank_ids_gathered": [0], "library_version": None}
+    if dist is None or not dist.is_initialized():
+        return out
+    world = dist.get_world_size()
+    out["backend"], out["world_seen"] = str(dist.get_backend()), world
+    ids = torch.full((1,), rank, dtype=torch.int64, device=dev)
+    got = torch.empty(world, dtype=torch.int64, device=dev)
+    dist.all_gather_into_tensor(got, ids)
+    ms = torch.tensor([local_ms_per_step], dtype=torch.float64, device=dev)
+    all_ms = torch.empty(world, dtype=torch.float64, device=dev)
+    dist.all_gather_into_tensor(all_ms, ms)
+    out["rank_ids_gathered"] = [int(x) for x in got.cpu()]
+    per = [float(x) for x in all_ms.cpu()]
+    out["per_rank_ms_per_step"] = {"min": min(per), "max": max(per), "all": per}
+    if out["backend"] == "nccl":
+        try:
+            out["library_version"] = "RCCL/NCCL " + ".".join(str(v) for v in torch.cuda.nccl.version())
+        except Exception as e:                      # noqa: BLE001  (a missing version query must not cost the line)
+            out["library_version"] = f"unavailable ({type(e).__name__})"
+    else:
+        out["library_version"] = f"torch {torch.__version__} {out['backend']}"
+    if gather is not None:
+        row_bytes = gather.local[0][0].numel() * gather.local[0].element_size()
+        out["gather"] = {"block_steps": gather.block, "bytes_per_bucket": gather.block * row_bytes,
+                         "bytes_per_step_per_rank": row_bytes, "collectives_launched": gather.launched,
+                         "what": "bit-packed done mask, one 64-bit word per 64 drones, all_gather_into_tensor(async_op=True), double-buffered"}
+    return out
 
 
 def run_stub(args, world, rank):
@@ -216,9 +285,10 @@ def run_stub(args, world, rank):
     if gather is not None:
         gather.flush(args.steps - 1)
         gather.drain()
-        dist.barrier()
-    elapsed = time.perf_counter() - t0
+    local = time.perf_counter() - t0
+    elapsed = local
     if world > 1:
+        dist.barrier()
         tt = torch.tensor([elapsed], dtype=torch.float64)
         dist.all_reduce(tt, op=dist.ReduceOp.MAX)
         elapsed = float(tt.item())
@@ -226,9 +296,11 @@ def run_stub(args, world, rank):
         ok = all(int(last[r, (args.steps - 1) % args.gather_block, 0]) == r * 1000 + args.steps - 1 for r in range(world))
     else:
         ok = True
+    coll = collective_report(dist if world > 1 else None, world, rank, "cpu", gather, local * 1e3 / max(args.steps, 1))
     if rank == 0:
         print(json.dumps({"metric": "stub", "value": 0.0, "unit": "env-steps/s", "n_gpus": world, "steps": args.steps,
-                          "warmup": args.warmup, "data": "stub", "gather_ok": bool(ok), "ms_per_step": elapsed * 1e3 / max(args.steps, 1)}),
+                          "warmup": args.warmup, "data": "stub", "gather_ok": bool(ok), "ms_per_step": elapsed * 1e3 / max(args.steps, 1),
+                          "collective": coll}),
               flush=True)
     if world > 1:
         dist.barrier()
@@ -250,7 +322,7 @@ def main(argv=None):
             if have < args.gpus:
                 raise SystemExit(f"bench.py --gpus {args.gpus} needs {args.gpus} GPUs on this node, found {have}; "
                                  f"run with --gpus {max(have, 1)} (or --force-dist to rehearse the collective path on one GPU)")
-        raise SystemExit(spawn_ranks(args.gpus, sys.argv[1:] if argv is None else argv))
+        raise SystemExit(spawn_ranks(args.gpus, sys.argv[1:] if argv is None else argv, wall_limit_s=args.spawn_timeout_s))
 
     if args.gather_block <= 0:
         args.gather_block = 64 if args.steps + args.warmup >= 256 else 16
@@ -259,12 +331,15 @@ def main(argv=None):
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     if world != args.gpus:
         raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}")
+    if rank == args.stub_fail_rank:
+        raise SystemExit(1)                                  # TEST ONLY: a rank that dies before the rendezvous
     if args.stub_step:
         raise SystemExit(run_stub(args, world, rank))
 
     import torch
     import torch.distributed as dist
     from fpyv_amd import load_params, sticks
+    from fpyv_amd import _lib as _lib_mod
     from fpyv_amd.dist import DoneGather
     from fpyv_amd.env import DroneBatch, RacerBatch
 
@@ -305,8 +380,6 @@ def main(argv=None):
                           track_episodes=bool(multi and args.gather_returns))
 
     env = make_env(n, multi)
-    if args.dpl:
-        env.set_tuning(args.dpl)
     env.reset()
 
     total = args.steps + args.warmup
@@ -391,10 +464,13 @@ def main(argv=None):
     dev_ms = ev0.elapsed_time(ev1)
     n_launches = launches[0]
 
+    local_elapsed = elapsed
+    coll = None
     if multi:
         t = torch.tensor([elapsed], dtype=torch.float64, device=dev)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = float(t.item())
+        coll = collective_report(dist, world, rank, dev, gather, local_elapsed * 1e3 / args.steps)
 
     assert bool(torch.isfinite(env.state).all()), "non-finite state after the benchmark"
     if args.dump_gathered and gather is not None:
@@ -413,6 +489,28 @@ def main(argv=None):
         big = make_env(nb, False)
         big.reset()
         acts_b = sticks.ema_noise_device(4, nb, dev, seed=99)
+        launch_bytes = big.algorithmic_bytes() * nb                        # what one launch of the step kernel moves
+        # the box's own streaming ceiling, measured in THIS process around the kernel run: a plain copy that reads and
+        # writes the same number of bytes per launch as the step kernel (1.1 GB, nothing survives in the 256 MiB cache),
+        # once with 16 bytes per lane (what the guide's 6.29 TB/s "achievable" figure is) and once with the step
+        # kernel's own access shape, one dword per lane
+        L = _lib_mod.lib()
+        cf = (launch_bytes // 8) // 1024 * 1024                            # floats copied per launch: read + write = launch_bytes
+        src = torch.empty(cf, dtype=torch.float32, device=dev).normal_()
+        dst = torch.empty_like(src)
+
+        def time_copy(fn, reps=40):
+            for _ in range(5):
+                _lib_mod.check(fn(dst.data_ptr(), src.data_ptr(), cf, torch.cuda.current_stream().cuda_stream))
+            c0, c1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            c0.record()
+            for _ in range(reps):
+                _lib_mod.check(fn(dst.data_ptr(), src.data_ptr(), cf, torch.cuda.current_stream().cuda_stream))
+            c1.record()
+            torch.cuda.synchronize()
+            return 8.0 * cf / (c0.elapsed_time(c1) * 1e-3 / reps) / 1e9      # GB/s, read + write
+
+        copy_before = time_copy(L.fpv_diag_stream_copy_wide)
         run_on(big, acts_b, 20, 0, None)
         torch.cuda.synchronize()
         e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
@@ -422,10 +520,18 @@ def main(argv=None):
         e1.record()
         torch.cuda.synchronize()
         us = e0.elapsed_time(e1) * 1e3 / kb
-        gbs = big.algorithmic_bytes() * nb / (us * 1e-6) / 1e9
+        copy_after = time_copy(L.fpv_diag_stream_copy_wide)
+        copy_dword = time_copy(L.fpv_diag_stream_copy)
+        gbs = launch_bytes / (us * 1e-6) / 1e9
+        ceiling = max(copy_before, copy_after)
         beyond = {"drones": nb, "state_MB": round(big.state.numel() * 4 / 1e6 + (big.state_h.numel() * 2 / 1e6 if big.state_h is not None else 0)),
-                  "avg_launch_us": us, "achieved": gbs, "frac": gbs / HBM_PEAK_GBS, "env_steps_per_s": nb / (us * 1e-6)}
-        del big, acts_b
+                  "avg_launch_us": us, "achieved": gbs, "frac": gbs / HBM_PEAK_GBS, "env_steps_per_s": nb / (us * 1e-6),
+                  "copy_ceiling_GBs": ceiling, "frac_of_copy_ceiling": gbs / ceiling,
+                  "copy_GBs": {"float4_before": copy_before, "float4_after": copy_after, "dword": copy_dword,
+                               "bytes_per_launch": 8 * cf,
+                               "what": "fpv_diag_stream_copy_wide / fpv_diag_stream_copy: dst[i] = src[i], read + write bytes equal to one "
+                                       "step-kernel launch at 2^23 drones, same process, before and after the kernel run"}}
+        del big, acts_b, src, dst
 
     if rank == 0:
         state_bytes = env.algorithmic_bytes()                                # 133 B fp32 / 89 B fp16 state
@@ -466,8 +572,7 @@ def main(argv=None):
                        "drones_per_gpu": n, "global_drones": n * world, "action_ring": ring, "api": args.api,
                        "steps_per_launch": steps_per_launch,
                        "parallelism": f"shard{world}" + ("+allgather(done_bits x" + str(args.gather_block) + " steps"
-                                                              + (", last_return" if args.gather_returns else "") + ")" if gather is not None else ""),
-                       "drones_per_lane": args.dpl or "default"},
+                                                              + (", last_return" if args.gather_returns else "") + ")" if gather is not None else "")},
             "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": achieved / HBM_PEAK_GBS, "traffic": traffic, "traffic_source": traffic_src,
                          "kernel": kernel, "algorithmic_bytes_per_env_step": bytes_per_step,
@@ -477,15 +582,41 @@ def main(argv=None):
                          "frac_beyond_mall": beyond["frac"] if beyond else None, "beyond_mall": beyond,
                          "note": "avg = HIP-event time over the timed region / launches (includes inter-launch gaps)"},
         }
+        if coll is not None:
+            out["collective"] = coll
         if args.api == "rollout":
-            # the k-step kernel is limited by instruction issue, not HBM.  VALU instructions executed per env-step,
-            # measured with rocprofv3 --pmc SQ_INSTS_VALU SQ_WAVES (profiles/r02_pmc_valu_counts.log): 6261 per wave
-            # for k = 32 (fp32 state), 10655 (fp16 state); the build has no packed-fp32 instructions (-fno-slp-vectorize)
-            inst = (10655.0 if args.fp16_state else 6261.0) / 32.0
-            out["roofline"]["valu"] = {"valu_inst_per_env_step": inst, "source": "profiles/r02_pmc_valu_counts.log (fp32/fp16 drone kernels only)",
-                                       "achieved_Glane_inst_per_s": inst * n * steps_per_launch / kernel_s / 1e9,
-                                       "peak_Glane_inst_per_s": VALU_PEAK_GINST,
-                                       "frac": inst * n * steps_per_launch / kernel_s / 1e9 / VALU_PEAK_GINST}
+            # the k-step kernel is limited by instruction issue, not HBM: price it against the vector-ALU issue peak.
+            # VALU instructions per wave come from a counter-only rocprofv3 pass (tools/pmc_valu.py ->
+            # profiles/pmc_valu.json) and are used ONLY for the configuration they were measured on - same kernel sources
+            # (hash), same kernel family, same steps per launch, quiet steps (no per-step mask rows) - otherwise the line
+            # says so instead of quoting a stale count
+            out["roofline"]["hbm_view"] = {k: out["roofline"][k] for k in ("achieved", "peak", "unit", "frac")}
+            valu, why = None, None
+            vp = os.path.join(REPO, "profiles", "pmc_valu.json")
+            fam = "racer" if args.racer else "fp16" if args.fp16_state else "f32"
+            if not os.path.isfile(vp):
+                why = "profiles/pmc_valu.json is missing (run tools/pmc_valu.py on the GPU box)"
+            else:
+                vj = json.load(open(vp))
+                ent = vj.get("kernels", {}).get(fam)
+                if vj.get("kernel_source_sha256_16") != kernel_source_hash():
+                    why = "stale: profiles/pmc_valu.json was measured on different kernel sources (re-run tools/pmc_valu.py)"
+                elif ent is None or gather is not None or abs(steps_per_launch - ent["steps_per_launch"]) > 1e-9 or n != vj.get("drones"):
+                    why = "profiles/pmc_valu.json holds no count for this configuration (kernel family / steps per launch / per-step mask rows)"
+                else:
+                    inst = ent["valu_per_wave"] / ent["steps_per_launch"]
+                    rate = inst * n * steps_per_launch / kernel_s / 1e9
+                    valu = {"valu_inst_per_env_step": inst, "salu_inst_per_env_step": ent.get("salu_per_wave", 0) / ent["steps_per_launch"],
+                            "source": vj.get("source"), "kernel": ent.get("kernel"),
+                            "achieved_Glane_inst_per_s": rate, "peak_Glane_inst_per_s": VALU_PEAK_GINST, "frac": rate / VALU_PEAK_GINST}
+            out["roofline"]["valu"] = valu
+            out["roofline"]["valu_unavailable"] = why
+            out["roofline"]["bound"] = "valu"
+            if valu is not None:
+                out["roofline"].update(achieved=valu["achieved_Glane_inst_per_s"], peak=VALU_PEAK_GINST, unit="G lane-instructions/s",
+                                       frac=valu["frac"])
+            out["roofline"]["note"] = ("bound = vector-ALU issue (256 CUs x 4 SIMD-32 x 2.4 GHz = 78.6 T lane-instructions/s); "
+                                       "`hbm_view` keeps the algorithmic-bytes figures of the same run; " + out["roofline"]["note"])
         if not args.no_cpu_baseline and world == 1:
             out["cpu_baseline"] = cpu_baseline(params)
         print(json.dumps(out), flush=True)

@@ -17,7 +17,7 @@
 #include "fpv_math.h"
 
 // Returns 0 or an FPV_E* code; *why receives a static message on failure.
-static inline int fpv_derive_constants(const fpv_params_t* P, FpvK* K, bool* big_angle, const char** why)
+static inline int fpv_derive_constants(const fpv_params_t* P, FpvK* K, const char** why)
 {
     *why = "";
     if (P->struct_size != sizeof(fpv_params_t)) { *why = "fpv_params_t.struct_size does not match this library"; return FPV_EINVAL; }
@@ -115,9 +115,9 @@ static inline int fpv_derive_constants(const fpv_params_t* P, FpvK* K, bool* big
     K->noise.id_lo = (uint32_t)P->drone_id_offset; K->noise.id_hi = (uint32_t)(P->drone_id_offset >> 32);
     K->flags = P->flags;
     // |rates| <= max_rates always (clip + convex low-pass from 0), so the largest half-angle of one
-    // step is known here; beyond pi/4 the short polynomial is no longer exact to fp32.
+    // step is known here: up to 0.03 rad two series terms are exact to fp32, up to pi/4 the five-term
+    // polynomials, beyond that the angle is reduced first (fpv_sincos3)
     const double half_max = 0.5 * (M_PI / 180.0) * P->dt * P->max_rates;
-    *big_angle = half_max > 0.78;
-    K->tiny_angle = half_max <= 0.03 ? 1u : 0u;
+    K->angle_mode = half_max <= 0.03 ? FPV_ANGLE_TINY : half_max <= 0.78 ? FPV_ANGLE_SMALL : FPV_ANGLE_REDUCED;
     return FPV_OK;
 }

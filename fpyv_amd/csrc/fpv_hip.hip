@@ -22,6 +22,7 @@
 #include <stdlib.h>
 #include <string.h>
 
+#include <mutex>
 #include <new>
 #include <string>
 #include <vector>
@@ -34,7 +35,14 @@
 
 namespace {
 
-constexpr int kBlock = 256;   // reset / diag kernels: 4 wave64 per workgroup
+constexpr int kBlock = 256;   // reset / pid / diag kernels: 4 wave64 per workgroup
+// step and k-step kernels: 128-thread workgroups (2 wave64), the fastest of 64/128/256/512/1024 in every measurement
+// (profiles/r01_exp10_shapes_clean.log, r02_sweep_geometry.log); -DFPV_EXP_BLOCK=N rebuilds them all for an A/B
+#ifndef FPV_EXP_BLOCK
+#define FPV_EXP_BLOCK 128
+#endif
+constexpr int kStepBlock = FPV_EXP_BLOCK;
+static_assert(kStepBlock % 64 == 0 && kStepBlock >= 64 && kStepBlock <= 1024, "whole wave64s");
 
 struct FpvBufD {
     float* state;
@@ -53,11 +61,11 @@ struct FpvBufD {
     float* pos_comp;       // [6][ld] Kahan compensation of p and v, or null
     float* noise_state;    // FPV_FLAG_STICK_NOISE: [4][ld] EMA stick-noise state
     float4* action_out;    // [n] applied action or null
-    uint32_t step;         // launch index of the handle: Philox counter word
+    uint64_t step;         // 64-bit step index of this launch (the handle's launch counter): Philox counter words 2, 3
     int64_t action_ld;     // 0: action is [n][4] rows; > 0: action is [4][action_ld] SoA (a GEMM's [4, n] output)
     FpvObjects objs;       // the step's object_list (count 0 = none); only the OBJ instantiation reads it
     uint16_t* state_h;     // FPV_FLAG_FP16_STATE: [5][ld] half2 pair rows + [ld] thrust halves
-    uint32_t seed;         // stochastic-rounding seed of this launch
+    uint32_t seed;         // stochastic-rounding base seed (fpv_buffers_t.rounding_seed); step t rounds with fpv_round_seed(seed, step + t)
     const float* rot_over;     // [n][9] guidance override of the attitude (Drone.step rotation_matrix=) or null
     const float* thrust_over;  // [n] thrust_force= of the same call (NaN = this drone is not overridden)
 };
@@ -244,69 +252,53 @@ __device__ __forceinline__ float4 apply_stick_noise(const FpvK& K, const FpvBufD
 // OVR: the guidance call shape Drone.step(..., rotation_matrix=R, thrust_force=f) (components.py:230-232,
 // simulator.py:110): nine more floats and the thrust force per drone, read with a 36-byte lane stride - the
 // matrices arrive in the caller's [n][3][3] layout; this is the closed-loop guidance path, not the headline one.
+// One drone per lane, kStepBlock threads per workgroup: 2 / 4 drones per lane and 256-thread workgroups lost every
+// measurement of rounds 1-2 (profiles/r01_exp10_shapes_clean.log, r02_sweep_geometry.log) and were removed in round 3.
 #ifdef FPV_EXP_STEP_WAVES
 #define FPV_EXP_STEP_ATTR __attribute__((amdgpu_waves_per_eu(FPV_EXP_STEP_WAVES)))
 #else
 #define FPV_EXP_STEP_ATTR
 #endif
-template <int BS, int DPL, bool BIG, bool NOISE = false, bool OBJ = false, bool KAHAN = false, bool OVR = false>
-__global__ __launch_bounds__(BS) FPV_EXP_STEP_ATTR void fpv_drone_step_kernel(const FpvK K, const FpvBufD B, const int64_t n)
+template <bool NOISE = false, bool OBJ = false, bool KAHAN = false, bool OVR = false>
+__global__ __launch_bounds__(kStepBlock) FPV_EXP_STEP_ATTR void fpv_drone_step_kernel(const FpvK K, const FpvBufD B, const int64_t n)
 {
-    static_assert(!OVR || DPL == 1, "the guidance override is built for one drone per lane");
-    const uint32_t base = blockIdx.x * (uint32_t)(BS * DPL) + threadIdx.x;    // n <= 2^28 (fpv_create)
-    // one drone per lane: lanes past the end leave at once (a ballot over the remaining lanes still
-    // yields the right done bits: exited lanes contribute 0, and a wave whose lane 0 is gone is empty)
-    if (DPL == 1 && base >= n) return;
-    FpvDroneState s[DPL];
-    float4 a[DPL];
-    bool live[DPL];
+    const uint32_t i = blockIdx.x * (uint32_t)kStepBlock + threadIdx.x;    // n <= 2^28 (fpv_create)
+    // lanes past the end leave at once (a ballot over the remaining lanes still yields the right done bits:
+    // exited lanes contribute 0, and a wave whose lane 0 is gone is empty)
+    if (i >= n) return;
+    FpvDroneState s;
     float ro[9] = {1.f, 0.f, 0.f, 0.f, 1.f, 0.f, 0.f, 0.f, 1.f}, to = 0.0f;
-    // issue every load of every drone of this lane before the first use
+    // issue every load of this lane before the first use
+    float4 a = (!NOISE || B.action) ? ld_action_any(B.action, B.action_ld, i) : make_float4(0.f, 0.f, 0.f, 0.f);
+    ld_drone(B.state, B.ld, i, s);
+    if (NOISE) a = apply_stick_noise(K, B, i, a);
+    if (OVR) {
 #pragma unroll
-    for (int j = 0; j < DPL; ++j) {
-        const uint32_t i = base + (uint32_t)j * BS;
-        live[j] = i < n;
-        if (live[j]) {
-            a[j] = (!NOISE || B.action) ? ld_action_any(B.action, B.action_ld, i) : make_float4(0.f, 0.f, 0.f, 0.f);
-            ld_drone(B.state, B.ld, i, s[j]);
-            if (NOISE) a[j] = apply_stick_noise(K, B, i, a[j]);
-            if (OVR) {
-#pragma unroll
-                for (int k = 0; k < 9; ++k) ro[k] = B.rot_over[(int64_t)i * 9 + k];     // 64-bit index: 36 * i can pass 2^32
-                to = B.thrust_over[i];
-            }
-        }
+        for (int k = 0; k < 9; ++k) ro[k] = B.rot_over[(int64_t)i * 9 + k];     // 64-bit index: 36 * i can pass 2^32
+        to = B.thrust_over[i];
     }
     // keep every vector load ahead of the scalar (kernarg) loads of the physics constants: without
     // this fence the compiler parks the last four row loads behind an s_waitcnt on those constants
     // (+1.4 % per launch, A/B in one process)
     __builtin_amdgcn_sched_barrier(0);
+    float kc[6];
+    if (KAHAN) {
 #pragma unroll
-    for (int j = 0; j < DPL; ++j) {
-        const uint32_t i = base + (uint32_t)j * BS;
-        FpvStepOut o;
-        o.done = false; o.reward = 0.0f; o.ax = o.ay = o.az = 0.0f;
-        if (live[j]) {
-            float kc[6];
-            if (KAHAN) {
-#pragma unroll
-                for (int k = 0; k < 6; ++k) kc[k] = row_at(ROW(B.pos_comp, k, B.ld), i);
-            }
-            o = fpv_drone_step_lane<BIG, OBJ>(K, s[j], a[j].x, a[j].y, a[j].z, a[j].w, B.wx, B.wy, B.wz, &B.objs,
-                                              KAHAN ? kc : nullptr, OVR ? ro : nullptr, to);
-            if (KAHAN) {
-                const bool rst = (K.flags & FPV_FLAG_AUTO_RESET) && o.done;
-#pragma unroll
-                for (int k = 0; k < 6; ++k) row_at(ROW(B.pos_comp, k, B.ld), i) = rst ? 0.0f : kc[k];
-            }
-            if (B.accel) {
-                row_at(ROW(B.accel, 0, B.ld), i) = o.ax; row_at(ROW(B.accel, 1, B.ld), i) = o.ay; row_at(ROW(B.accel, 2, B.ld), i) = o.az;
-            }
-            if ((K.flags & FPV_FLAG_AUTO_RESET) && o.done) fpv_drone_reset_lane(K, s[j]);
-            st_drone(B.state, B.ld, i, s[j]);
-        }
-        emit_outputs(B, i, live[j], o.reward, o.done);
+        for (int k = 0; k < 6; ++k) kc[k] = row_at(ROW(B.pos_comp, k, B.ld), i);
     }
+    const FpvStepOut o = fpv_drone_step_lane<OBJ>(K, s, a.x, a.y, a.z, a.w, B.wx, B.wy, B.wz, &B.objs,
+                                                  KAHAN ? kc : nullptr, OVR ? ro : nullptr, to);
+    if (KAHAN) {
+        const bool rst = (K.flags & FPV_FLAG_AUTO_RESET) && o.done;
+#pragma unroll
+        for (int k = 0; k < 6; ++k) row_at(ROW(B.pos_comp, k, B.ld), i) = rst ? 0.0f : kc[k];
+    }
+    if (B.accel) {
+        row_at(ROW(B.accel, 0, B.ld), i) = o.ax; row_at(ROW(B.accel, 1, B.ld), i) = o.ay; row_at(ROW(B.accel, 2, B.ld), i) = o.az;
+    }
+    if ((K.flags & FPV_FLAG_AUTO_RESET) && o.done) fpv_drone_reset_lane(K, s);
+    st_drone(B.state, B.ld, i, s);
+    emit_outputs(B, i, true, o.reward, o.done);
 }
 
 // k steps of Drone.step in ONE launch (fpv_step_n): the loop `for i in range(time_steps): drone.step(...)`
@@ -324,16 +316,16 @@ __global__ __launch_bounds__(BS) FPV_EXP_STEP_ATTR void fpv_drone_step_kernel(co
 #else
 #define FPV_EXP_ROLL_ATTR
 #endif
-template <int BS, bool BIG, bool NOISE, bool OBJ, bool KAHAN, bool SQ = false>
-__global__ __launch_bounds__(BS) FPV_EXP_ROLL_ATTR void fpv_drone_rollout_kernel(const FpvK K, const FpvBufD B, const int64_t n, const FpvRoll R)
+template <bool NOISE, bool OBJ, bool KAHAN, bool SQ = false>
+__global__ __launch_bounds__(kStepBlock) FPV_EXP_ROLL_ATTR void fpv_drone_rollout_kernel(const FpvK K, const FpvBufD B, const int64_t n, const FpvRoll R)
 {
     static_assert(!(SQ && OBJ), "the two-height ground flag does not feed the object pass");
-    const uint32_t i = blockIdx.x * (uint32_t)BS + threadIdx.x;
+    const uint32_t i = blockIdx.x * (uint32_t)kStepBlock + threadIdx.x;
     if (i >= n) return;
     FpvDroneState s;
     const bool has_action = !NOISE || B.action;
     const float* ap = reinterpret_cast<const float*>(B.action);
-    float4 a_next = has_action ? ld_action_any(reinterpret_cast<const float4*>(ap), B.action_ld, i) : make_float4(0.f, 0.f, 0.f, 0.f);
+    float4 a_next = has_action ? ld_action(reinterpret_cast<const float4*>(ap), i) : make_float4(0.f, 0.f, 0.f, 0.f);   // rows only (fpv_step_n)
     ld_drone(B.state, B.ld, i, s);
     float ns[4] = {0.f, 0.f, 0.f, 0.f}, kc[6] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
     if (NOISE) {
@@ -362,10 +354,10 @@ __global__ __launch_bounds__(BS) FPV_EXP_ROLL_ATTR void fpv_drone_rollout_kernel
         av[0] = a_next.x; av[1] = a_next.y; av[2] = a_next.z; av[3] = a_next.w;
         if (has_action && R.action_stride && t + 1 < R.k) {
             ap += R.action_stride;
-            a_next = ld_action_any(reinterpret_cast<const float4*>(ap), B.action_ld, i);
+            a_next = ld_action(reinterpret_cast<const float4*>(ap), i);
         }
-        if (NOISE) fpv_stick_noise(K.noise, B.step + (uint32_t)t, (uint64_t)i, ns, av);
-        o = fpv_drone_step_lane<BIG, OBJ, !QUIET, SQ && QUIET>(K, s, av[0], av[1], av[2], av[3], B.wx, B.wy, B.wz, &B.objs, KAHAN ? kc : nullptr);
+        if (NOISE) fpv_stick_noise(K.noise, B.step + (uint64_t)t, (uint64_t)i, ns, av);
+        o = fpv_drone_step_lane<OBJ, !QUIET, SQ && QUIET>(K, s, av[0], av[1], av[2], av[3], B.wx, B.wy, B.wz, &B.objs, KAHAN ? kc : nullptr);
         const bool rst = (K.flags & FPV_FLAG_AUTO_RESET) && o.done;
         if (KAHAN && rst) {
 #pragma unroll
@@ -405,12 +397,11 @@ __global__ __launch_bounds__(BS) FPV_EXP_ROLL_ATTR void fpv_drone_rollout_kernel
 // wave transposes its 64 x 16 tile through LDS (row pitch 17 words: conflict-free writes) and
 // stores it as 4 fully coalesced 1-KiB float4 instructions.  This is the one place on the path
 // where LDS staging pays; the SoA state rows never need it.
-template <int BS, bool BIG>
-__global__ __launch_bounds__(BS) void fpv_drone_step_aos_kernel(const FpvK K, const FpvBufD B, const int64_t n)
+__global__ __launch_bounds__(kStepBlock) void fpv_drone_step_aos_kernel(const FpvK K, const FpvBufD B, const int64_t n)
 {
     constexpr int kPitch = 17;
-    __shared__ float tile[BS / 64][64 * kPitch];
-    const uint32_t i = blockIdx.x * (uint32_t)BS + threadIdx.x;
+    __shared__ float tile[kStepBlock / 64][64 * kPitch];
+    const uint32_t i = blockIdx.x * (uint32_t)kStepBlock + threadIdx.x;
     const bool live = i < n;
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     FpvStepOut o;
@@ -419,7 +410,7 @@ __global__ __launch_bounds__(BS) void fpv_drone_step_aos_kernel(const FpvK K, co
         FpvDroneState s;
         const float4 a = ld_action(B.action, i);
         ld_drone(B.state, B.ld, i, s);
-        o = fpv_drone_step_lane<BIG>(K, s, a.x, a.y, a.z, a.w, B.wx, B.wy, B.wz);
+        o = fpv_drone_step_lane<false>(K, s, a.x, a.y, a.z, a.w, B.wx, B.wy, B.wz);
         if (B.accel) {
             row_at(ROW(B.accel, 0, B.ld), i) = o.ax; row_at(ROW(B.accel, 1, B.ld), i) = o.ay; row_at(ROW(B.accel, 2, B.ld), i) = o.az;
         }
@@ -495,10 +486,9 @@ __device__ __forceinline__ void st_thrust_pair_h(const FpvBufD& B, uint32_t i, b
     if (live && !(i & 1u)) row_at(const_cast<uint32_t*>(thrust_row_h(B)), i >> 1) = mine | (other << 16);
 }
 
-template <int BS, bool BIG>
-__global__ __launch_bounds__(BS) void fpv_drone_step_h_kernel(const FpvK K, const FpvBufD B, const int64_t n)
+__global__ __launch_bounds__(kStepBlock) void fpv_drone_step_h_kernel(const FpvK K, const FpvBufD B, const int64_t n)
 {
-    const uint32_t i = blockIdx.x * (uint32_t)BS + threadIdx.x;
+    const uint32_t i = blockIdx.x * (uint32_t)kStepBlock + threadIdx.x;
     const bool live = i < n;                 // no early exit: the thrust-pair exchange needs whole lane pairs
     FpvStepOut o;
     o.done = false; o.reward = 0.0f; o.ax = o.ay = o.az = 0.0f;
@@ -508,12 +498,12 @@ __global__ __launch_bounds__(BS) void fpv_drone_step_h_kernel(const FpvK K, cons
         const float4 a = ld_action(B.action, i);
         ld_drone_h(B, i, s);
         __builtin_amdgcn_sched_barrier(0);       // loads first, constants after (see fpv_drone_step_kernel)
-        o = fpv_drone_step_lane<BIG>(K, s, a.x, a.y, a.z, a.w, B.wx, B.wy, B.wz);
+        o = fpv_drone_step_lane<false>(K, s, a.x, a.y, a.z, a.w, B.wx, B.wy, B.wz);
         if (B.accel) {
             row_at(ROW(B.accel, 0, B.ld), i) = o.ax; row_at(ROW(B.accel, 1, B.ld), i) = o.ay; row_at(ROW(B.accel, 2, B.ld), i) = o.az;
         }
         if ((K.flags & FPV_FLAG_AUTO_RESET) && o.done) fpv_drone_reset_lane(K, s);
-        th = st_drone_h(B, i, B.seed, s);
+        th = st_drone_h(B, i, fpv_round_seed(B.seed, B.step), s);
     }
     st_thrust_pair_h(B, i, live, th);
     emit_outputs(B, i, live, o.reward, o.done);
@@ -521,10 +511,9 @@ __global__ __launch_bounds__(BS) void fpv_drone_step_h_kernel(const FpvK K, cons
 
 // k steps of the fp16-storage kernel in one launch: the state is rounded to binary16 and widened again
 // after EVERY step, in registers, exactly as k single-step launches would do through HBM.
-template <int BS, bool BIG>
-__global__ __launch_bounds__(BS) void fpv_drone_rollout_h_kernel(const FpvK K, const FpvBufD B, const int64_t n, const FpvRoll R)
+__global__ __launch_bounds__(kStepBlock) void fpv_drone_rollout_h_kernel(const FpvK K, const FpvBufD B, const int64_t n, const FpvRoll R)
 {
-    const uint32_t i = blockIdx.x * (uint32_t)BS + threadIdx.x;
+    const uint32_t i = blockIdx.x * (uint32_t)kStepBlock + threadIdx.x;
     const bool live = i < n;
     uint32_t th = 0;
     FpvStepOut o;
@@ -544,9 +533,9 @@ __global__ __launch_bounds__(BS) void fpv_drone_rollout_h_kernel(const FpvK K, c
             constexpr bool QUIET = decltype(quiet_c)::value;
             const float4 a = a_next;
             if (R.action_stride && t + 1 < R.k) { ap += R.action_stride; a_next = ld_action(reinterpret_cast<const float4*>(ap), i); }
-            o = fpv_drone_step_lane<BIG, false, !QUIET>(K, s, a.x, a.y, a.z, a.w, B.wx, B.wy, B.wz);
+            o = fpv_drone_step_lane<false, !QUIET>(K, s, a.x, a.y, a.z, a.w, B.wx, B.wy, B.wz);
             if ((K.flags & FPV_FLAG_AUTO_RESET) && o.done) fpv_drone_reset_lane(K, s);
-            fpv_pack_half(s, B.seed + (uint32_t)t, (uint32_t)i, h);       // the HBM round trip of a single step, in registers
+            fpv_pack_half(s, fpv_round_seed(B.seed, B.step + (uint64_t)t), (uint32_t)i, h);       // the HBM round trip of a single step, in registers
             if (QUIET || t + 1 < R.k) fpv_unpack_half(h, s);
             out.template step<QUIET>(i, t, o.reward, o.done);
         };
@@ -610,10 +599,10 @@ __device__ __forceinline__ void st_racer(float* __restrict__ st, int64_t ld, uin
 // Racer.step.  WIDE = as written (omega radians per step: float64 rate loop, six extra (hi, lo) rows);
 // PIDV = components.PID semantics (three extra rows).  The 181-byte variant (neither) is the
 // racer_omega_dt one.
-template <int BS, bool WIDE, bool PIDV>
-__global__ __launch_bounds__(BS) void fpv_racer_step_kernel(const FpvK K, const FpvBufD B, const int64_t n)
+template <bool WIDE, bool PIDV>
+__global__ __launch_bounds__(kStepBlock) void fpv_racer_step_kernel(const FpvK K, const FpvBufD B, const int64_t n)
 {
-    const uint32_t i = blockIdx.x * (uint32_t)BS + threadIdx.x;
+    const uint32_t i = blockIdx.x * (uint32_t)kStepBlock + threadIdx.x;
     if (i >= n) return;
     FpvRacerState s;
     const float4 a = ld_action(B.action, i);
@@ -626,10 +615,10 @@ __global__ __launch_bounds__(BS) void fpv_racer_step_kernel(const FpvK K, const 
     emit_outputs(B, i, true, reward, done);
 }
 
-template <int BS, bool WIDE, bool PIDV>
-__global__ __launch_bounds__(BS) void fpv_racer_rollout_kernel(const FpvK K, const FpvBufD B, const int64_t n, const FpvRoll R)
+template <bool WIDE, bool PIDV>
+__global__ __launch_bounds__(kStepBlock) void fpv_racer_rollout_kernel(const FpvK K, const FpvBufD B, const int64_t n, const FpvRoll R)
 {
-    const uint32_t i = blockIdx.x * (uint32_t)BS + threadIdx.x;
+    const uint32_t i = blockIdx.x * (uint32_t)kStepBlock + threadIdx.x;
     if (i >= n) return;
     FpvRacerState s;
     ld_racer<WIDE, PIDV>(B.state, B.ld, i, s);
@@ -684,9 +673,9 @@ __global__ __launch_bounds__(kBlock) void fpv_reset_kernel(const FpvK K, const F
         if (ypr) {
             const float d2r_half = 0.5f * 0.017453292519943295f;
             float sr, cr, sp, cp, sy, cy;
-            fpv_sincos_full(ypr[3 * i] * d2r_half, &sr, &cr);
-            fpv_sincos_full(ypr[3 * i + 1] * d2r_half, &sp, &cp);
-            fpv_sincos_full(ypr[3 * i + 2] * d2r_half, &sy, &cy);
+            fpv_sincos_reduced(ypr[3 * i] * d2r_half, &sr, &cr);
+            fpv_sincos_reduced(ypr[3 * i + 1] * d2r_half, &sp, &cp);
+            fpv_sincos_reduced(ypr[3 * i + 2] * d2r_half, &sy, &cy);
             s.q.w = fmaf(cy * cp, cr, sy * sp * sr);
             s.q.x = fmaf(cy * cp, sr, -(sy * sp * cr));
             s.q.y = fmaf(cy * sp, cr, sy * cp * sr);
@@ -753,6 +742,15 @@ __global__ __launch_bounds__(kBlock) void fpv_diag_copy_kernel(float* __restrict
     if (i < n) dst[i] = src[i];
 }
 
+// The same copy with 16 bytes per lane: the chip's streaming ceiling on this box (the guide's "achievable HBM" figure is
+// a float4 copy), timed by bench.py next to the step kernel at 2^23 drones.
+__global__ __launch_bounds__(kBlock) void fpv_diag_copy4_kernel(fpv_v4f* __restrict__ dst, const fpv_v4f* __restrict__ src,
+                                                                const int64_t n4)
+{
+    const int64_t i = (int64_t)blockIdx.x * kBlock + threadIdx.x;
+    if (i < n4) dst[i] = src[i];
+}
+
 thread_local std::string g_err;
 
 int fail(int code, const std::string& msg)
@@ -775,16 +773,14 @@ struct fpv_env {
     int64_t n;
     int device;
     int mode;
-    int dpl;        // drones per lane (1, 2 or 4)
-    int block;      // threads per workgroup of the drone step kernel (128 or 256)
-    uint32_t launches;   // counts step launches; feeds the stochastic-rounding seed
+    uint64_t launches;   // 64-bit step index: counts the steps launched so far; keys the stick-noise stream (Philox
+                         // counter words 2 and 3) and the stochastic rounding (fpv_round_seed)
     // cached hipGraph of the last fpv_rollout_graph call (launch-bound small batches): rebuilt when the
     // SHAPE key changes, re-pointed node by node when only buffer addresses change
     hipGraph_t graph = nullptr;
     hipGraphExec_t graph_exec = nullptr;
     std::vector<hipGraphNode_t> graph_nodes;
     std::string graph_shape_key, graph_ptr_key;
-    bool big_angle;
 };
 
 namespace {
@@ -879,129 +875,108 @@ FpvBufD to_device_view(const fpv_buffers_t* b)
     return d;
 }
 
-int bind_device(const fpv_env* h)
-{
-    int cur = -1;
-    hipError_t e = hipGetDevice(&cur);
-    if (e != hipSuccess) return hip_fail(e, "hipGetDevice");
-    if (cur != h->device) {
-        e = hipSetDevice(h->device);
-        if (e != hipSuccess) return hip_fail(e, "hipSetDevice");
+// Scoped device binding: makes `device` current for the launch and puts the caller's device back on the way out, so
+// a single-process host with one handle per GPU ("one process with 8 handles") never finds its thread's
+// current device changed by an fpv_* call.  No HIP call at all when the device is already current.
+struct DeviceGuard {
+    int prev = -1, rc = FPV_OK;
+    bool switched = false;
+    explicit DeviceGuard(int device)
+    {
+        hipError_t e = hipGetDevice(&prev);
+        if (e != hipSuccess) { rc = hip_fail(e, "hipGetDevice"); return; }
+        if (prev != device) {
+            e = hipSetDevice(device);
+            if (e != hipSuccess) { rc = hip_fail(e, "hipSetDevice"); return; }
+            switched = true;
+        }
     }
-    return FPV_OK;
-}
+    ~DeviceGuard() { if (switched) (void)hipSetDevice(prev); }
+    DeviceGuard(const DeviceGuard&) = delete;
+    DeviceGuard& operator=(const DeviceGuard&) = delete;
+};
 
 // ---- kernel selection: every step kernel has the signature (FpvK, FpvBufD, int64_t) ----------------
 typedef void (*StepKernel)(const FpvK, const FpvBufD, const int64_t);
 struct KernelChoice { StepKernel func; unsigned grid, block; };
 
-template <bool BIG, bool NOISE, bool OBJ, bool KAHAN>
-StepKernel feature_kernel(int block, int dpl)
+StepKernel drone_kernel(bool noise, bool obj, bool kahan)
 {
-    if (!NOISE && !OBJ && !KAHAN && dpl == 2) return block == 256 ? fpv_drone_step_kernel<256, 2, BIG> : fpv_drone_step_kernel<128, 2, BIG>;
-    if (!NOISE && !OBJ && !KAHAN && dpl == 4) return block == 256 ? fpv_drone_step_kernel<256, 4, BIG> : fpv_drone_step_kernel<128, 4, BIG>;
-    return block == 256 ? fpv_drone_step_kernel<256, 1, BIG, NOISE, OBJ, KAHAN> : fpv_drone_step_kernel<128, 1, BIG, NOISE, OBJ, KAHAN>;
-}
-
-template <bool BIG>
-StepKernel drone_kernel(int block, int dpl, bool noise, bool obj, bool kahan)
-{
-    // optional features of the one-drone-per-lane kernel are independent template switches
-    // (in-kernel stick noise x object_list collisions x Kahan rows), each combination its own
-    // instantiation, so the plain kernel keeps its register budget
+    // optional features of the step kernel are independent template switches (in-kernel stick noise x object_list
+    // collisions x Kahan rows), each combination its own instantiation, so the plain kernel keeps its register budget
     switch ((noise ? 4 : 0) | (obj ? 2 : 0) | (kahan ? 1 : 0)) {
-        case 0: return feature_kernel<BIG, false, false, false>(block, dpl);
-        case 1: return feature_kernel<BIG, false, false, true>(block, dpl);
-        case 2: return feature_kernel<BIG, false, true, false>(block, dpl);
-        case 3: return feature_kernel<BIG, false, true, true>(block, dpl);
-        case 4: return feature_kernel<BIG, true, false, false>(block, dpl);
-        case 5: return feature_kernel<BIG, true, false, true>(block, dpl);
-        case 6: return feature_kernel<BIG, true, true, false>(block, dpl);
-        default: return feature_kernel<BIG, true, true, true>(block, dpl);
+        case 0: return fpv_drone_step_kernel<false, false, false>;
+        case 1: return fpv_drone_step_kernel<false, false, true>;
+        case 2: return fpv_drone_step_kernel<false, true, false>;
+        case 3: return fpv_drone_step_kernel<false, true, true>;
+        case 4: return fpv_drone_step_kernel<true, false, false>;
+        case 5: return fpv_drone_step_kernel<true, false, true>;
+        case 6: return fpv_drone_step_kernel<true, true, false>;
+        default: return fpv_drone_step_kernel<true, true, true>;
     }
 }
 
-StepKernel racer_kernel(int block, bool wide, bool pidv)
+StepKernel racer_kernel(bool wide, bool pidv)
 {
-    switch ((block == 256 ? 4 : 0) | (wide ? 2 : 0) | (pidv ? 1 : 0)) {
-        case 0: return fpv_racer_step_kernel<128, false, false>;
-        case 1: return fpv_racer_step_kernel<128, false, true>;
-        case 2: return fpv_racer_step_kernel<128, true, false>;
-        case 3: return fpv_racer_step_kernel<128, true, true>;
-        case 4: return fpv_racer_step_kernel<256, false, false>;
-        case 5: return fpv_racer_step_kernel<256, false, true>;
-        case 6: return fpv_racer_step_kernel<256, true, false>;
-        default: return fpv_racer_step_kernel<256, true, true>;
-    }
+    return wide ? (pidv ? fpv_racer_step_kernel<true, true> : fpv_racer_step_kernel<true, false>)
+                : (pidv ? fpv_racer_step_kernel<false, true> : fpv_racer_step_kernel<false, false>);
 }
 
-// ---- k-step kernels (fpv_step_n): signature (FpvK, FpvBufD, int64_t, FpvRoll); 128-thread workgroups ----
+// ---- k-step kernels (fpv_step_n): signature (FpvK, FpvBufD, int64_t, FpvRoll) ----
 typedef void (*RollKernel)(const FpvK, const FpvBufD, const int64_t, const FpvRoll);
 
-template <bool BIG>
 RollKernel drone_rollout_kernel(bool noise, bool obj, bool kahan, bool sq)
 {
     switch ((noise ? 4 : 0) | (obj ? 2 : 0) | (kahan ? 1 : 0)) {
-        case 0: return sq ? fpv_drone_rollout_kernel<128, BIG, false, false, false, true> : fpv_drone_rollout_kernel<128, BIG, false, false, false>;
-        case 1: return sq ? fpv_drone_rollout_kernel<128, BIG, false, false, true, true> : fpv_drone_rollout_kernel<128, BIG, false, false, true>;
-        case 2: return fpv_drone_rollout_kernel<128, BIG, false, true, false>;
-        case 3: return fpv_drone_rollout_kernel<128, BIG, false, true, true>;
-        case 4: return sq ? fpv_drone_rollout_kernel<128, BIG, true, false, false, true> : fpv_drone_rollout_kernel<128, BIG, true, false, false>;
-        case 5: return sq ? fpv_drone_rollout_kernel<128, BIG, true, false, true, true> : fpv_drone_rollout_kernel<128, BIG, true, false, true>;
-        case 6: return fpv_drone_rollout_kernel<128, BIG, true, true, false>;
-        default: return fpv_drone_rollout_kernel<128, BIG, true, true, true>;
+        case 0: return sq ? fpv_drone_rollout_kernel<false, false, false, true> : fpv_drone_rollout_kernel<false, false, false>;
+        case 1: return sq ? fpv_drone_rollout_kernel<false, false, true, true> : fpv_drone_rollout_kernel<false, false, true>;
+        case 2: return fpv_drone_rollout_kernel<false, true, false>;
+        case 3: return fpv_drone_rollout_kernel<false, true, true>;
+        case 4: return sq ? fpv_drone_rollout_kernel<true, false, false, true> : fpv_drone_rollout_kernel<true, false, false>;
+        case 5: return sq ? fpv_drone_rollout_kernel<true, false, true, true> : fpv_drone_rollout_kernel<true, false, true>;
+        case 6: return fpv_drone_rollout_kernel<true, true, false>;
+        default: return fpv_drone_rollout_kernel<true, true, true>;
     }
 }
 
 RollKernel choose_rollout_kernel(const fpv_env* h, const FpvBufD& d)
 {
-    const bool big = h->big_angle;
     if (h->mode != FPV_MODE_DRONE) {
         const bool wide = h->K.r_wide != 0, pidv = h->K.r_pid_variant != 0;
-        return wide ? (pidv ? fpv_racer_rollout_kernel<128, true, true> : fpv_racer_rollout_kernel<128, true, false>)
-                    : (pidv ? fpv_racer_rollout_kernel<128, false, true> : fpv_racer_rollout_kernel<128, false, false>);
+        return wide ? (pidv ? fpv_racer_rollout_kernel<true, true> : fpv_racer_rollout_kernel<true, false>)
+                    : (pidv ? fpv_racer_rollout_kernel<false, true> : fpv_racer_rollout_kernel<false, false>);
     }
-    if (h->K.flags & FPV_FLAG_FP16_STATE) return big ? fpv_drone_rollout_h_kernel<128, true> : fpv_drone_rollout_h_kernel<128, false>;
+    if (h->K.flags & FPV_FLAG_FP16_STATE) return fpv_drone_rollout_h_kernel;
     const bool noise = (h->K.flags & FPV_FLAG_STICK_NOISE) != 0, obj = d.objs.count > 0, kahan = d.pos_comp != nullptr;
     const bool sq = !obj && h->K.motor_square && !(h->K.flags & FPV_FLAG_GROUND);      // X frame, no ground springs
-    return big ? drone_rollout_kernel<true>(noise, obj, kahan, sq) : drone_rollout_kernel<false>(noise, obj, kahan, sq);
+    return drone_rollout_kernel(noise, obj, kahan, sq);
 }
 
 KernelChoice choose_kernel(const fpv_env* h, const FpvBufD& d)
 {
     KernelChoice c;
-    c.block = (unsigned)h->block;
-    int64_t per_block = h->block;
-    const bool big = h->big_angle;
+    c.block = (unsigned)kStepBlock;
     if (h->mode != FPV_MODE_DRONE) {
-        c.func = racer_kernel(h->block, h->K.r_wide != 0, h->K.r_pid_variant != 0);
+        c.func = racer_kernel(h->K.r_wide != 0, h->K.r_pid_variant != 0);
     } else if (h->K.flags & FPV_FLAG_FP16_STATE) {
-        c.func = h->block == 256 ? (big ? fpv_drone_step_h_kernel<256, true> : fpv_drone_step_h_kernel<256, false>)
-                                 : (big ? fpv_drone_step_h_kernel<128, true> : fpv_drone_step_h_kernel<128, false>);
+        c.func = fpv_drone_step_h_kernel;
     } else if (d.obs_aos) {
-        c.func = h->block == 256 ? (big ? fpv_drone_step_aos_kernel<256, true> : fpv_drone_step_aos_kernel<256, false>)
-                                 : (big ? fpv_drone_step_aos_kernel<128, true> : fpv_drone_step_aos_kernel<128, false>);
+        c.func = fpv_drone_step_aos_kernel;
     } else {
         const bool noise = (h->K.flags & FPV_FLAG_STICK_NOISE) != 0, obj = d.objs.count > 0, kahan = d.pos_comp != nullptr;
-        const int dpl = (noise || obj || kahan || d.rot_over) ? 1 : h->dpl;
-        per_block = (int64_t)h->block * dpl;
-        if (d.rot_over) {                   // guidance override: plain or object-list kernel, 128 threads (check_buffers)
-            c.block = 128; per_block = 128;
-            c.func = obj ? (big ? fpv_drone_step_kernel<128, 1, true, false, true, false, true> : fpv_drone_step_kernel<128, 1, false, false, true, false, true>)
-                         : (big ? fpv_drone_step_kernel<128, 1, true, false, false, false, true> : fpv_drone_step_kernel<128, 1, false, false, false, false, true>);
-        } else {
-            c.func = big ? drone_kernel<true>(h->block, dpl, noise, obj, kahan) : drone_kernel<false>(h->block, dpl, noise, obj, kahan);
-        }
+        if (d.rot_over)                     // guidance override: plain or object-list kernel (check_buffers)
+            c.func = obj ? fpv_drone_step_kernel<false, true, false, true> : fpv_drone_step_kernel<false, false, false, true>;
+        else
+            c.func = drone_kernel(noise, obj, kahan);
     }
-    c.grid = (unsigned)((h->n + per_block - 1) / per_block);
+    c.grid = (unsigned)((h->n + kStepBlock - 1) / kStepBlock);
     return c;
 }
 
 int launch_step(fpv_env* h, const FpvBufD& d_in, hipStream_t s)
 {
     FpvBufD d = d_in;
-    d.step = h->launches;
-    d.seed = d_in.seed + h->launches++;
+    d.step = h->launches++;
     const KernelChoice c = choose_kernel(h, d);
     hipLaunchKernelGGL(c.func, dim3(c.grid), dim3(c.block), 0, s, h->K, d, h->n);
     const hipError_t e = hipGetLastError();
@@ -1065,14 +1040,13 @@ int fpv_create(const fpv_params_t* params, int64_t n, int device, fpv_handle_t* 
         return fail(FPV_ENODEV, std::string("no HIP device available: ") + (e != hipSuccess ? hipGetErrorString(e) : "device count is 0"));
     if (device < 0 || device >= count) return fail(FPV_ENODEV, "device index out of range");
     FpvK K;
-    bool big = false;
     const char* why = "";
-    const int rc = fpv_derive_constants(params, &K, &big, &why);
+    const int rc = fpv_derive_constants(params, &K, &why);
     if (rc != FPV_OK) return fail(rc, why);
     fpv_env* h = new (std::nothrow) fpv_env;
     if (!h) return fail(FPV_EINVAL, "out of host memory");
     h->K = K; h->P = *params; h->n = n; h->device = device; h->mode = (int)params->mode;
-    h->dpl = 1; h->block = 128; h->big_angle = big; h->launches = 0;
+    h->launches = 0;
     *out = h;
     return FPV_OK;
 }
@@ -1092,32 +1066,24 @@ int fpv_set_params(fpv_handle_t h, const fpv_params_t* params)
     if ((params->flags ^ h->P.flags) & (FPV_FLAG_FP16_STATE | FPV_FLAG_STICK_NOISE))
         return fail(FPV_EINVAL, "FPV_FLAG_FP16_STATE / FPV_FLAG_STICK_NOISE cannot change on a live handle (buffer layout differs)");
     FpvK K;
-    bool big = false;
     const char* why = "";
-    const int rc = fpv_derive_constants(params, &K, &big, &why);
+    const int rc = fpv_derive_constants(params, &K, &why);
     if (rc != FPV_OK) return fail(rc, why);
-    h->K = K; h->P = *params; h->big_angle = big;
+    h->K = K; h->P = *params;
     return FPV_OK;
 }
 
-int fpv_set_step_counter(fpv_handle_t h, uint32_t step)
+int fpv_set_step_counter(fpv_handle_t h, uint64_t step)
 {
     if (!h) return fail(FPV_EINVAL, "null handle");
     h->launches = step;
     return FPV_OK;
 }
 
-int fpv_set_tuning(fpv_handle_t h, int drones_per_lane, int block_threads)
+int fpv_get_step_counter(fpv_handle_t h, uint64_t* step)
 {
-    if (!h) return fail(FPV_EINVAL, "null handle");
-    if (drones_per_lane == 0) drones_per_lane = 1;
-    if (block_threads == 0) block_threads = 128;
-    if (drones_per_lane != 1 && drones_per_lane != 2 && drones_per_lane != 4)
-        return fail(FPV_EINVAL, "drones_per_lane must be 0, 1, 2 or 4");
-    if (block_threads != 128 && block_threads != 256)
-        return fail(FPV_EINVAL, "block_threads must be 0, 128 or 256");
-    h->dpl = drones_per_lane;
-    h->block = block_threads;
+    if (!h || !step) return fail(FPV_EINVAL, "null argument");
+    *step = h->launches;
     return FPV_OK;
 }
 
@@ -1138,7 +1104,8 @@ int fpv_reset(fpv_handle_t h, const fpv_buffers_t* b, const uint8_t* mask, const
 {
     int rc = check_buffers(h, b, false);
     if (rc != FPV_OK) return rc;
-    if ((rc = bind_device(h)) != FPV_OK) return rc;
+    const DeviceGuard dev(h->device);
+    if (dev.rc != FPV_OK) return dev.rc;
     const dim3 grid((unsigned)((h->n + kBlock - 1) / kBlock));
     hipLaunchKernelGGL(fpv_reset_kernel, grid, dim3(kBlock), 0, (hipStream_t)stream, h->K, to_device_view(b),
                        h->mode, mask, position, velocity, ypr_deg, h->n);
@@ -1151,7 +1118,8 @@ int fpv_step(fpv_handle_t h, const fpv_buffers_t* b, void* stream)
 {
     int rc = check_buffers(h, b, true);
     if (rc != FPV_OK) return rc;
-    if ((rc = bind_device(h)) != FPV_OK) return rc;
+    const DeviceGuard dev(h->device);
+    if (dev.rc != FPV_OK) return dev.rc;
     return launch_step(h, to_device_view(b), (hipStream_t)stream);
 }
 
@@ -1163,7 +1131,8 @@ int fpv_rollout(fpv_handle_t h, const fpv_buffers_t* b, int k, int64_t action_st
     if (k < 0) return fail(FPV_EINVAL, "k must be >= 0");
     if (action_stride % 4) return fail(FPV_EALIGN, "action_stride must keep 16-byte alignment");
     if (b->rotation_override) return fail(FPV_EINVAL, "the guidance override is a per-step input: use fpv_step");
-    if ((rc = bind_device(h)) != FPV_OK) return rc;
+    const DeviceGuard dev(h->device);
+    if (dev.rc != FPV_OK) return dev.rc;
     FpvBufD d = to_device_view(b);
     const float* a0 = b->action;
     for (int t = 0; t < k; ++t) {
@@ -1188,6 +1157,19 @@ int fpv_diag_stream_copy(float* dst, const float* src, int64_t n_floats, void* s
     return FPV_OK;
 }
 
+int fpv_diag_stream_copy_wide(float* dst, const float* src, int64_t n_floats, void* stream)
+{
+    if (!dst || !src || n_floats <= 0) return fail(FPV_EINVAL, "bad argument");
+    if (n_floats % 4 || ((uintptr_t)dst & 15) || ((uintptr_t)src & 15)) return fail(FPV_EALIGN, "n_floats must be a multiple of 4 and both pointers 16-byte aligned");
+    const int64_t n4 = n_floats / 4;
+    const dim3 grid((unsigned)((n4 + kBlock - 1) / kBlock));
+    hipLaunchKernelGGL(fpv_diag_copy4_kernel, grid, dim3(kBlock), 0, (hipStream_t)stream, reinterpret_cast<fpv_v4f*>(dst),
+                       reinterpret_cast<const fpv_v4f*>(src), n4);
+    const hipError_t e = hipGetLastError();
+    if (e != hipSuccess) return hip_fail(e, "diag wide copy launch");
+    return FPV_OK;
+}
+
 int fpv_step_n(fpv_handle_t h, const fpv_buffers_t* b, int k, int64_t action_stride, int64_t out_stride, void* stream)
 {
     int rc = check_buffers(h, b, true);
@@ -1196,17 +1178,18 @@ int fpv_step_n(fpv_handle_t h, const fpv_buffers_t* b, int k, int64_t action_str
     if (k == 0) return FPV_OK;
     if (action_stride % 4) return fail(FPV_EALIGN, "action_stride must keep 16-byte alignment");
     if (b->obs_aos) return fail(FPV_EINVAL, "fpv_step_n does not write obs_aos rows (a per-step observation is a closed-loop need: use fpv_step)");
+    if (b->action_ld) return fail(FPV_EINVAL, "fpv_step_n reads action rows [n][4] only (SoA sticks are a policy's per-step output, a closed-loop need: use fpv_step or fpv_rollout)");
     if (b->rotation_override) return fail(FPV_EINVAL, "the guidance override is a per-step input: use fpv_step");
-    if ((rc = bind_device(h)) != FPV_OK) return rc;
+    const DeviceGuard dev(h->device);
+    if (dev.rc != FPV_OK) return dev.rc;
     FpvBufD d = to_device_view(b);
     d.step = h->launches;
-    d.seed = d.seed + h->launches;
-    h->launches += (uint32_t)k;
+    h->launches += (uint64_t)k;
     FpvRoll R;
     R.k = k; R.pad = 0; R.action_stride = action_stride; R.out_stride = out_stride; R.bits_stride = b->done_bits_stride;
     const RollKernel f = choose_rollout_kernel(h, d);
-    const unsigned grid = (unsigned)((h->n + 127) / 128);
-    hipLaunchKernelGGL(f, dim3(grid), dim3(128), 0, (hipStream_t)stream, h->K, d, h->n, R);
+    const unsigned grid = (unsigned)((h->n + kStepBlock - 1) / kStepBlock);
+    hipLaunchKernelGGL(f, dim3(grid), dim3(kStepBlock), 0, (hipStream_t)stream, h->K, d, h->n, R);
     const hipError_t e = hipGetLastError();
     if (e != hipSuccess) return hip_fail(e, "k-step kernel launch");
     return FPV_OK;
@@ -1249,12 +1232,13 @@ int fpv_rollout_graph(fpv_handle_t h, const fpv_buffers_t* b, int k, int64_t act
     // a graph replays frozen kernel arguments, but stick noise and the fp16 rounding are keyed by the per-launch step
     // index: such handles take the k-step kernel instead - the same k steps bit for bit, and cheaper than the replay
     if (h->K.flags & (FPV_FLAG_STICK_NOISE | FPV_FLAG_FP16_STATE)) return fpv_step_n(h, b, k, action_stride, out_stride, stream);
-    if ((rc = bind_device(h)) != FPV_OK) return rc;
+    const DeviceGuard dev(h->device);
+    if (dev.rc != FPV_OK) return dev.rc;
     const FpvBufD d0 = to_device_view(b);
     // SHAPE of the graph: everything that selects kernels, grids and non-pointer arguments
     const KernelChoice c0 = choose_kernel(h, d0);
     std::string shape(reinterpret_cast<const char*>(&h->K), sizeof(h->K));
-    const int64_t meta[9] = {k, action_stride, out_stride, h->dpl, h->block, h->n, b->ld, b->action_ld, b->done_bits_stride};
+    const int64_t meta[7] = {k, action_stride, out_stride, h->n, b->ld, b->action_ld, b->done_bits_stride};
     shape.append(reinterpret_cast<const char*>(meta), sizeof(meta));
     shape.append(reinterpret_cast<const char*>(&c0.func), sizeof(c0.func));
     shape.append(reinterpret_cast<const char*>(&d0.objs), sizeof(d0.objs));
@@ -1306,21 +1290,18 @@ int fpv_rollout_graph(fpv_handle_t h, const fpv_buffers_t* b, int k, int64_t act
     }
     const hipError_t e = hipGraphLaunch(h->graph_exec, (hipStream_t)stream);
     if (e != hipSuccess) return hip_fail(e, "hipGraphLaunch");
-    h->launches += (uint32_t)k;
+    h->launches += (uint64_t)k;
     return FPV_OK;
 }
 
 namespace {
-int bind_device_index(int device)
+int check_device_index(int device)
 {
     int count = 0;
-    hipError_t e = hipGetDeviceCount(&count);
+    const hipError_t e = hipGetDeviceCount(&count);
     if (e != hipSuccess || count <= 0)
         return fail(FPV_ENODEV, std::string("no HIP device available: ") + (e != hipSuccess ? hipGetErrorString(e) : "device count is 0"));
     if (device < 0 || device >= count) return fail(FPV_ENODEV, "device index out of range");
-    int cur = -1;
-    if ((e = hipGetDevice(&cur)) != hipSuccess) return hip_fail(e, "hipGetDevice");
-    if (cur != device && (e = hipSetDevice(device)) != hipSuccess) return hip_fail(e, "hipSetDevice");
     return FPV_OK;
 }
 }  // namespace
@@ -1329,8 +1310,10 @@ int fpv_pid_reset(float* pid_state, int64_t ld, int64_t n, const uint8_t* mask, 
 {
     if (!pid_state) return fail(FPV_EINVAL, "pid_state is null");
     if (n <= 0 || ld < n) return fail(FPV_EINVAL, "need 0 < n <= ld");
-    const int rc = bind_device_index(device);
+    const int rc = check_device_index(device);
     if (rc != FPV_OK) return rc;
+    const DeviceGuard dev(device);
+    if (dev.rc != FPV_OK) return dev.rc;
     hipLaunchKernelGGL(fpv_pid_reset_kernel, dim3((unsigned)((n + kBlock - 1) / kBlock)), dim3(kBlock), 0, (hipStream_t)stream,
                        pid_state, ld, n, mask);
     const hipError_t e = hipGetLastError();
@@ -1348,8 +1331,10 @@ int fpv_pid_call(const fpv_pid_params_t* params, float* pid_state, int64_t ld, i
     if (!(params->integral_clip >= 0) || !(params->min_output <= params->max_output)
         || !(params->derivative_transition_rate >= 0 && params->derivative_transition_rate <= 1))
         return fail(FPV_EPARAM, "components.PID constants: integral_clip >= 0, min_output <= max_output, derivative_transition_rate in [0, 1]");
-    const int rc = bind_device_index(device);
+    const int rc = check_device_index(device);
     if (rc != FPV_OK) return rc;
+    const DeviceGuard dev(device);
+    if (dev.rc != FPV_OK) return dev.rc;
     FpvPidK<float> P;
     memset(&P, 0, sizeof(P));
     P.dt = (float)params->dt; P.inv_dt = (float)(1.0 / params->dt);
@@ -1375,27 +1360,42 @@ struct Rccl {
     int (*CommDestroy)(NcclComm) = nullptr;
     int (*AllGather)(const void*, void*, size_t, int, NcclComm, hipStream_t) = nullptr;
     const char* (*GetErrorString)(int) = nullptr;
+    int (*GetVersion)(int*) = nullptr;
     std::string why;
 };
 
+// Opened once per process, under std::call_once: two host threads (one per GPU) may call fpv_comm_* at the same
+// time.  The table is filled in a local and published whole; a failure leaves lib == nullptr and `why` set.
 Rccl* rccl()
 {
     static Rccl R;
-    if (R.lib || !R.why.empty()) return &R;
-    const char* env = getenv("FPV_RCCL_PATH");
-    if (env && *env) R.lib = dlopen(env, RTLD_NOW | RTLD_LOCAL);
-    // reuse a copy the process already has (PyTorch links its own as "librccl.so"), else load the system one
-    if (!R.lib) R.lib = dlopen("librccl.so", RTLD_NOW | RTLD_NOLOAD);
-    if (!R.lib) R.lib = dlopen("librccl.so.1", RTLD_NOW | RTLD_NOLOAD);
-    if (!R.lib) R.lib = dlopen("librccl.so.1", RTLD_NOW | RTLD_LOCAL);
-    if (!R.lib) R.lib = dlopen("/opt/rocm/lib/librccl.so.1", RTLD_NOW | RTLD_LOCAL);
-    if (!R.lib) { R.why = std::string("librccl not found: ") + dlerror(); return &R; }
-    R.GetUniqueId = reinterpret_cast<int (*)(NcclId*)>(dlsym(R.lib, "ncclGetUniqueId"));
-    R.CommInitRank = reinterpret_cast<int (*)(NcclComm*, int, NcclId, int)>(dlsym(R.lib, "ncclCommInitRank"));
-    R.CommDestroy = reinterpret_cast<int (*)(NcclComm)>(dlsym(R.lib, "ncclCommDestroy"));
-    R.AllGather = reinterpret_cast<int (*)(const void*, void*, size_t, int, NcclComm, hipStream_t)>(dlsym(R.lib, "ncclAllGather"));
-    R.GetErrorString = reinterpret_cast<const char* (*)(int)>(dlsym(R.lib, "ncclGetErrorString"));
-    if (!R.GetUniqueId || !R.CommInitRank || !R.CommDestroy || !R.AllGather) { R.why = "librccl lacks the ncclGetUniqueId/CommInitRank/CommDestroy/AllGather symbols"; R.lib = nullptr; }
+    static std::once_flag once;
+    std::call_once(once, [] {
+        Rccl T;
+        const char* env = getenv("FPV_RCCL_PATH");
+        if (env && *env) T.lib = dlopen(env, RTLD_NOW | RTLD_LOCAL);
+        // reuse a copy the process already has (PyTorch links its own as "librccl.so"), else load the system one
+        if (!T.lib) T.lib = dlopen("librccl.so", RTLD_NOW | RTLD_NOLOAD);
+        if (!T.lib) T.lib = dlopen("librccl.so.1", RTLD_NOW | RTLD_NOLOAD);
+        if (!T.lib) T.lib = dlopen("librccl.so.1", RTLD_NOW | RTLD_LOCAL);
+        if (!T.lib) T.lib = dlopen("/opt/rocm/lib/librccl.so.1", RTLD_NOW | RTLD_LOCAL);
+        if (!T.lib) {
+            const char* msg = dlerror();
+            T.why = std::string("librccl not found: ") + (msg ? msg : "dlopen failed without a message");
+        } else {
+            T.GetUniqueId = reinterpret_cast<int (*)(NcclId*)>(dlsym(T.lib, "ncclGetUniqueId"));
+            T.CommInitRank = reinterpret_cast<int (*)(NcclComm*, int, NcclId, int)>(dlsym(T.lib, "ncclCommInitRank"));
+            T.CommDestroy = reinterpret_cast<int (*)(NcclComm)>(dlsym(T.lib, "ncclCommDestroy"));
+            T.AllGather = reinterpret_cast<int (*)(const void*, void*, size_t, int, NcclComm, hipStream_t)>(dlsym(T.lib, "ncclAllGather"));
+            T.GetErrorString = reinterpret_cast<const char* (*)(int)>(dlsym(T.lib, "ncclGetErrorString"));
+            T.GetVersion = reinterpret_cast<int (*)(int*)>(dlsym(T.lib, "ncclGetVersion"));
+            if (!T.GetUniqueId || !T.CommInitRank || !T.CommDestroy || !T.AllGather) {
+                T.why = "librccl lacks the ncclGetUniqueId/CommInitRank/CommDestroy/AllGather symbols";
+                T.lib = nullptr;
+            }
+        }
+        R = T;
+    });
     return &R;
 }
 
@@ -1430,8 +1430,10 @@ int fpv_comm_create(const uint8_t id[FPV_COMM_ID_BYTES], int world_size, int ran
     if (world_size <= 0 || rank < 0 || rank >= world_size) return fail(FPV_EINVAL, "need 0 <= rank < world_size");
     Rccl* R = rccl();
     if (!R->lib) return fail(FPV_EHIP, R->why);
-    int rc = bind_device_index(device);
+    int rc = check_device_index(device);
     if (rc != FPV_OK) return rc;
+    const DeviceGuard dev(device);
+    if (dev.rc != FPV_OK) return dev.rc;
     NcclId u;
     memcpy(u.internal, id, FPV_COMM_ID_BYTES);
     NcclComm c = nullptr;
@@ -1441,6 +1443,19 @@ int fpv_comm_create(const uint8_t id[FPV_COMM_ID_BYTES], int world_size, int ran
     if (!h) { (void)R->CommDestroy(c); return fail(FPV_EINVAL, "out of host memory"); }
     h->comm = c; h->world = world_size; h->rank = rank; h->device = device;
     *out = h;
+    return FPV_OK;
+}
+
+int fpv_comm_info(fpv_comm_t c, int* world_size, int* rank, int* rccl_version)
+{
+    if (!c) return fail(FPV_EINVAL, "null communicator");
+    if (world_size) *world_size = c->world;
+    if (rank) *rank = c->rank;
+    if (rccl_version) {
+        *rccl_version = 0;
+        Rccl* R = rccl();
+        if (R->lib && R->GetVersion) (void)R->GetVersion(rccl_version);
+    }
     return FPV_OK;
 }
 
@@ -1459,9 +1474,9 @@ int allgather(fpv_comm_t c, const void* send, void* recv, int64_t count, int dty
     if (count <= 0) return fail(FPV_EINVAL, "count per rank must be positive");
     Rccl* R = rccl();
     if (!R->lib) return fail(FPV_EHIP, R->why);
-    int rc = bind_device_index(c->device);
-    if (rc != FPV_OK) return rc;
-    rc = R->AllGather(send, recv, (size_t)count, dtype, c->comm, (hipStream_t)stream);
+    const DeviceGuard dev(c->device);
+    if (dev.rc != FPV_OK) return dev.rc;
+    const int rc = R->AllGather(send, recv, (size_t)count, dtype, c->comm, (hipStream_t)stream);
     if (rc != kNcclSuccess) return rccl_fail(rc, "ncclAllGather");
     return FPV_OK;
 }

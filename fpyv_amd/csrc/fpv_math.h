@@ -71,7 +71,7 @@ struct FpvK {
     uint32_t flags;
     uint32_t r_wide;        // Racer: attitude increment in float64 (Racer.step as written: angle = omega per step)
     uint32_t r_pid_variant; // 0: racer_drone_test.PID.step, 1: components.PID.__call__
-    uint32_t tiny_angle;    // 1: no step can turn by more than 0.03 rad of half-angle: two-term sin/cos suffice
+    uint32_t angle_mode;    // FPV_ANGLE_*: which sin/cos form the largest possible half-angle of one step needs (fpv_sincos3)
     uint32_t motor_square;  // 1: the motors sit at (+-c, +-c) (the reference's X frame, components.py:120-125): the ground
     float motor_c;          //    flag needs two heights instead of four (see fpv_drone_step_lane)
     double r_ang_k_d;       // r_ang_k in double (the racer_omega_dt variant multiplies by the exact dt)
@@ -96,15 +96,22 @@ FPV_HD void fpv_sincos_small(float x, float* s, float* c)
     *c = fmaf(x2, pc, 1.0f);
 }
 
-// Full-range sin/cos (library range reduction): used when one step can rotate by more than 90
-// degrees about an axis (half-angle > pi/4) and by the Racer, whose per-step angle is unbounded.
-FPV_HD void fpv_sincos_full(float x, float* s, float* c)
+// sin and cos of an angle of any size a step can produce (|x| up to ~1e3 rad) in fp32 WITHOUT a library call: two-part
+// Cody-Waite reduction by pi/2 (k * C1 is exact inside the fma, so the first step rounds once; C2 = pi/2 - fl(pi/2)
+// restores the bits fl() dropped; the neglected third part is k * 1e-15), then the short polynomials on |r| <= pi/4 and
+// the quadrant swap.  The same instructions on the host and on gfx950, so the big-angle step, the fp32 Racer and the
+// reset kernel agree with the host build bit for bit (round 2 called sincosf here: device libm != host libm).
+FPV_HD void fpv_sincos_reduced(float x, float* s, float* c)
 {
-#if defined(__HIP_DEVICE_COMPILE__)
-    sincosf(x, s, c);
-#else
-    *s = sinf(x); *c = cosf(x);
-#endif
+    const float k = rintf(x * 0.63661977f);                // 2/pi
+    float r = fmaf(-k, 1.57079637e+00f, x);                // fl(pi/2) = 0x3fc90fdb
+    r = fmaf(-k, -4.37113883e-08f, r);                     // pi/2 - fl(pi/2)
+    float sr, cr;
+    fpv_sincos_small(r, &sr, &cr);
+    const int q = (int)k & 3;
+    const float ss = (q & 1) ? cr : sr, cs = (q & 1) ? sr : cr;
+    *s = (q & 2) ? -ss : ss;
+    *c = ((q + 1) & 2) ? -cs : cs;
 }
 
 // sin and cos for |x| <= 0.03 (half-angles of one step at dt <= 1/60 s and 200 deg/s): two terms each,
@@ -116,14 +123,23 @@ FPV_HD void fpv_sincos_tiny(float x, float* s, float* c)
     *c = fmaf(x2, fmaf(x2, 4.1666667e-2f, -0.5f), 1.0f);
 }
 
-// BIG: library range reduction (compile-time kernel choice); otherwise `tiny` (wave-uniform, from the
-// host-known bound on the half-angle) picks the two-term or the five-term polynomial
-template <bool BIG>
-FPV_HD void fpv_sincos(float x, bool tiny, float* s, float* c)
+// The three half-angles of one step's attitude increment.  `mode` is wave-uniform and comes from the host-known bound
+// on the half-angle (fpv_derive_constants): 0 = two-term series (<= 0.03 rad), 1 = five-term polynomials (<= pi/4),
+// 2 = range reduction first (a step that can turn by more than 90 degrees about an axis).  ONE uniform branch covers
+// all three axes; every kernel carries all three forms (round 2 built a second instantiation of every kernel for
+// mode 2 and tested `tiny` once per axis).
+#define FPV_ANGLE_TINY 0u
+#define FPV_ANGLE_SMALL 1u
+#define FPV_ANGLE_REDUCED 2u
+FPV_HD void fpv_sincos3(uint32_t mode, float x0, float x1, float x2, float s[3], float c[3])
 {
-    if (BIG) fpv_sincos_full(x, s, c);
-    else if (tiny) fpv_sincos_tiny(x, s, c);
-    else fpv_sincos_small(x, s, c);
+    if (mode == FPV_ANGLE_TINY) {
+        fpv_sincos_tiny(x0, &s[0], &c[0]); fpv_sincos_tiny(x1, &s[1], &c[1]); fpv_sincos_tiny(x2, &s[2], &c[2]);
+    } else if (mode == FPV_ANGLE_SMALL) {
+        fpv_sincos_small(x0, &s[0], &c[0]); fpv_sincos_small(x1, &s[1], &c[1]); fpv_sincos_small(x2, &s[2], &c[2]);
+    } else {
+        fpv_sincos_reduced(x0, &s[0], &c[0]); fpv_sincos_reduced(x1, &s[1], &c[1]); fpv_sincos_reduced(x2, &s[2], &c[2]);
+    }
 }
 
 // Rotation matrix columns from a unit quaternion (helper_functions.py:100-117).
@@ -262,6 +278,13 @@ FPV_HD uint32_t fpv_mix32(uint32_t x)
     return x;
 }
 
+// stochastic-rounding seed of step index `step` (64-bit launch counter of the handle): base + step for step < 2^32
+// (= ABI <= 3), the high word folded in beyond that so that the rounding noise does not repeat either
+FPV_HD uint32_t fpv_round_seed(uint32_t base, uint64_t step)
+{
+    return base + (uint32_t)step + (uint32_t)(step >> 32) * 0x9e3779b1u;
+}
+
 struct FpvHalfState { uint16_t v[3], q[4], r[3], t; };   // the 11 binary16 values of one drone
 
 // storage order: FIVE half2 rows (low half first): (vx,vy) (vz,qw) (qx,qy) (qz,rx) (ry,rz), then ONE row of
@@ -363,11 +386,14 @@ FPV_HD float fpv_log_normal_arg(float u)
 }
 
 // four standard normals from one Philox block (Box-Muller on two uniform pairs in (0,1))
-FPV_HD void fpv_normal4(uint32_t seed_lo, uint32_t seed_hi, uint32_t drone_lo, uint32_t drone_hi, uint32_t step,
-                        float z[4])
+// The Philox counter is (global drone id: 64 bits, step index: 64 bits): for step < 2^32 the fourth word is 0, i.e.
+// the streams of ABI <= 3 (32-bit step, fourth word constant 0) are reproduced bit for bit, and beyond 2^32 steps
+// (5.5 h at the k-step kernel's rate) the stream continues instead of repeating.
+FPV_HD void fpv_normal4(uint32_t seed_lo, uint32_t seed_hi, uint32_t drone_lo, uint32_t drone_hi, uint32_t step_lo,
+                        uint32_t step_hi, float z[4])
 {
     uint32_t r[4];
-    fpv_philox4x32_10(drone_lo, drone_hi, step, 0u, seed_lo, seed_hi, r);
+    fpv_philox4x32_10(drone_lo, drone_hi, step_lo, step_hi, seed_lo, seed_hi, r);
     const float u0 = ((float)(r[0] >> 8) + 0.5f) * 5.9604644775390625e-08f;    // 2^-24, in (0,1)
     const float u1 = ((float)(r[1] >> 8) + 0.5f) * 5.9604644775390625e-08f;
     const float u2 = ((float)(r[2] >> 8) + 0.5f) * 5.9604644775390625e-08f;
@@ -381,11 +407,11 @@ FPV_HD void fpv_normal4(uint32_t seed_lo, uint32_t seed_hi, uint32_t drone_lo, u
 }
 
 // advance the EMA state ns[4] and perturb the action in place
-FPV_HD void fpv_stick_noise(const FpvNoiseK& N, uint32_t step, uint64_t local_id, float ns[4], float a[4])
+FPV_HD void fpv_stick_noise(const FpvNoiseK& N, uint64_t step, uint64_t local_id, float ns[4], float a[4])
 {
     const uint64_t gid = (((uint64_t)N.id_hi << 32) | N.id_lo) + local_id;
     float z[4];
-    fpv_normal4(N.seed_lo, N.seed_hi, (uint32_t)gid, (uint32_t)(gid >> 32), step, z);
+    fpv_normal4(N.seed_lo, N.seed_hi, (uint32_t)gid, (uint32_t)(gid >> 32), (uint32_t)step, (uint32_t)(step >> 32), z);
 #pragma unroll
     for (int k = 0; k < 4; ++k) {
         ns[k] = fmaf(z[k], N.tau, ns[k] * N.omtau);
@@ -498,7 +524,7 @@ FPV_HD bool fpv_collide_objects(const FpvK& K, const FpvObjects& T, const float 
 // test that once per launch); the ground flag then comes from two motor heights instead of four, bit for bit the
 // same flag.  The single-step kernels are HBM-bound and keep the four-height form (SQ = false): there the extra
 // uniform test costs more than the 14 instructions it saves.
-template <bool BIG, bool OBJ = false, bool OUT = true, bool SQ = false>
+template <bool OBJ = false, bool OUT = true, bool SQ = false>
 FPV_HD FpvStepOut fpv_drone_step_lane(const FpvK& K, FpvDroneState& s, float a0, float a1, float a2, float a3,
                                       float wx, float wy, float wz, const FpvObjects* objs = nullptr,
                                       float* kahan = nullptr, const float* rot_over = nullptr, float thrust_over = 0.0f)
@@ -615,11 +641,9 @@ FPV_HD FpvStepOut fpv_drone_step_lane(const FpvK& K, FpvDroneState& s, float a0,
     }
 
     // attitude: q <- q (x) conj(q_E)^2, q_E = qz(psi) qy(theta) qx(phi)     kinematics.py:27-30 (x2)
-    float sr, cr, sp, cp, sy, cy;
-    const bool tiny = K.tiny_angle != 0u;
-    fpv_sincos<BIG>(s.rx * K.half_k, tiny, &sr, &cr);
-    fpv_sincos<BIG>(s.ry * K.half_k, tiny, &sp, &cp);
-    fpv_sincos<BIG>(s.rz * K.half_k, tiny, &sy, &cy);
+    float sn[3], cs[3];
+    fpv_sincos3(K.angle_mode, s.rx * K.half_k, s.ry * K.half_k, s.rz * K.half_k, sn, cs);
+    const float sr = sn[0], cr = cs[0], sp = sn[1], cp = cs[1], sy = sn[2], cy = cs[2];
     const float ew = fmaf(cy * cp, cr, sy * sp * sr);
     const float ex = fmaf(cy * cp, sr, -(sy * sp * cr));
     const float ey = fmaf(cy * sp, cr, sy * cp * sr);
@@ -781,9 +805,9 @@ FPV_HD float fpv_racer_step_lane(const FpvK& K, FpvRacerState& s, float a0, floa
             s.w[i] = fmaf(tq, K.rf.dt_over_I[i], s.w[i]);                   // :98
         }
         float sa, ca, sb, cb, sc, cc;
-        fpv_sincos_full(0.5f * s.w[0] * K.r_ang_k, &sa, &ca);
-        fpv_sincos_full(0.5f * s.w[1] * K.r_ang_k, &sb, &cb);
-        fpv_sincos_full(0.5f * s.w[2] * K.r_ang_k, &sc, &cc);
+        fpv_sincos_reduced(0.5f * s.w[0] * K.r_ang_k, &sa, &ca);
+        fpv_sincos_reduced(0.5f * s.w[1] * K.r_ang_k, &sb, &cb);
+        fpv_sincos_reduced(0.5f * s.w[2] * K.r_ang_k, &sc, &cc);
         // qx*qy = (ca cb, sa cb, ca sb, sa sb); then * qz
         const float w1 = ca * cb, x1 = sa * cb, y1 = ca * sb, z1 = sa * sb;
         const float dw = fmaf(w1, cc, -z1 * sc), dx = fmaf(x1, cc, y1 * sc);

@@ -79,6 +79,7 @@ class DoneGather:
         self._view = list(self.gathered)           # what result() returns per bucket (a flushed bucket is shorter)
         self._row_numel = self.local[0][0].numel()
         self.pending: List[Optional[object]] = [None, None]
+        self.launched = 0                          # collectives enqueued so far (warm-up included)
         self._row_ptrs = [[self.local[k][r].data_ptr() for r in range(self.block)] for k in range(2)]
 
     def row_ptr(self, t: int) -> int:
@@ -106,6 +107,7 @@ class DoneGather:
         self._view[k] = out.view((self.world, rows) + tuple(self.local[k].shape[1:]))
         self.pending[k] = self._dist.all_gather_into_tensor(out, self.local[k][:rows].reshape(-1), group=self.group,
                                                             async_op=True)
+        self.launched += 1
 
     def step_done(self, t: int) -> None:
         if (t + 1) % self.block == 0:

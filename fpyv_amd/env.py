@@ -70,7 +70,10 @@ class _Batch:
             self.state = torch.zeros((self.rows, self.ld), **f32)
             self.state_h = None
         self.reward = torch.zeros(self.n, **f32)
-        self.done_u8 = torch.zeros(self.n, dtype=torch.uint8, device=self.device)
+        # the kernel writes one byte, exactly 0 or 1, per drone: a torch.bool tensor is that byte array, so `done` is
+        # the kernel's own output (done[N] bool) and `done_u8` the same memory seen as uint8
+        self.done = torch.zeros(self.n, dtype=torch.bool, device=self.device)
+        self.done_u8 = self.done.view(torch.uint8)
         self.accel = torch.zeros((3, self.ld), **f32) if with_accel else None
         self.done_bits = (torch.zeros(_round_up(self.n, 64) // 64, dtype=torch.int64, device=self.device)
                           if with_done_bits else None)
@@ -178,12 +181,17 @@ class _Batch:
         return action.data_ptr()
 
     def set_step_counter(self, step: int) -> None:
-        """Step index keying the stick-noise stream / stochastic rounding (counts launches from 0)."""
-        _lib.check(self._L.fpv_set_step_counter(self._handle, int(step) & 0xFFFFFFFF))
-        self._steps_launched = int(step) & 0xFFFFFFFF
+        """64-bit step index keying the stick-noise stream / stochastic rounding (counts the steps launched, from 0)."""
+        if not 0 <= int(step) < 2 ** 64:
+            raise ValueError("the step counter is an unsigned 64-bit integer")
+        _lib.check(self._L.fpv_set_step_counter(self._handle, int(step)))
+        self._steps_launched = int(step)
 
-    def set_tuning(self, drones_per_lane: int = 0, block_threads: int = 0) -> None:
-        _lib.check(self._L.fpv_set_tuning(self._handle, int(drones_per_lane), int(block_threads)))
+    def step_counter(self) -> int:
+        """The handle's own 64-bit step counter (fpv_get_step_counter)."""
+        v = C.c_uint64()
+        _lib.check(self._L.fpv_get_step_counter(self._handle, C.byref(v)))
+        return int(v.value)
 
     def set_params(self, params: DroneParams, auto_reset: Optional[bool] = None) -> None:
         flags_auto = bool(self._cparams.flags & _lib.FPV_FLAG_AUTO_RESET) if auto_reset is None else auto_reset
@@ -192,7 +200,7 @@ class _Batch:
         self.params, self._cparams = params, cp
 
     # -- checkpoint / resume (the reference has none; state is just tensors here) ------------------
-    _CKPT_TENSORS = ("state", "state_h", "reward", "done_u8", "ep_return", "ep_length", "last_return",
+    _CKPT_TENSORS = ("state", "state_h", "reward", "done", "ep_return", "ep_length", "last_return",
                      "last_length", "noise_state", "pos_comp")
 
     def state_dict(self) -> Dict[str, Any]:
@@ -206,6 +214,8 @@ class _Batch:
     def load_state_dict(self, d: Dict[str, Any]) -> None:
         if d["num_envs"] != self.n or d["mode"] != self.mode:
             raise ValueError("checkpoint was taken from a batch of different size or mode")
+        if "done_u8" in d and "done" not in d:        # checkpoints written before the bool view existed
+            d = dict(d, done=d["done_u8"].bool())
         for k in self._CKPT_TENSORS:
             if k in d:
                 if getattr(self, k, None) is None:
@@ -267,7 +277,7 @@ class _Batch:
         rc = self._fpv_step(self._handle, self._buf_ref, self._stream())
         if rc < 0:
             _lib.check(rc)
-        self._steps_launched = (self._steps_launched + 1) & 0xFFFFFFFF
+        self._steps_launched = (self._steps_launched + 1) & 0xFFFFFFFFFFFFFFFF
 
     def set_done_bits_target(self, target: Any = None, stride_words: int = 0) -> None:
         """Where the kernel writes the bit-packed done mask (one wave ballot per 64 drones):
@@ -328,9 +338,9 @@ class _Batch:
         saved = (b.reward, b.done)
         if rewards is not None or dones is not None:
             out_stride = self.n
-            for t, dt_ in ((rewards, torch.float32), (dones, torch.uint8)):
-                if t is not None and (t.shape != (k, self.n) or t.dtype != dt_ or not t.is_contiguous()):
-                    raise ValueError("rewards must be float32 [k, n], dones uint8 [k, n], contiguous")
+            for t, dts in ((rewards, (torch.float32,)), (dones, (torch.uint8, torch.bool))):
+                if t is not None and (t.shape != (k, self.n) or t.dtype not in dts or not t.is_contiguous()):
+                    raise ValueError("rewards must be float32 [k, n], dones uint8 or bool [k, n], contiguous")
             b.reward = rewards.data_ptr() if rewards is not None else None
             b.done = dones.data_ptr() if dones is not None else None
         try:
@@ -346,7 +356,8 @@ class _Batch:
             else:
                 fn = self._L.fpv_rollout
             _lib.check(fn(self._handle, C.byref(b), int(k), stride, out_stride, self._stream()))
-            self._steps_launched = (self._steps_launched + int(k)) & 0xFFFFFFFF
+            self._steps_launched = (self._steps_launched + int(k)) & 0xFFFFFFFFFFFFFFFF
+            self._keepalive = actions               # what `throttle` reports: the last step's sticks
         finally:
             b.reward, b.done = saved
 
@@ -369,11 +380,6 @@ class _Batch:
     def rotation_matrix(self) -> torch.Tensor:
         """[num_envs, 3, 3], computed from the quaternion (helper_functions.py:100-117)."""
         return quat_to_matrix(self.quaternion)
-
-    @property
-    def done(self) -> torch.Tensor:
-        return self.done_u8.bool()
-
 
 def as_drone_params(params: Any, mode: int, default_fps: Optional[float] = None) -> DroneParams:
     """DroneParams | params.yaml-shaped dict (what the reference passes to Drone(), components.py:73) |
@@ -431,12 +437,28 @@ class DroneBatch(_Batch):
         self.thrust2throttle = params.stick_from_thrust        # :137  thrust [N] -> stick, clipped to [-1, 1]
         self.min_throttle_in_force = params.min_throttle_in_force   # :140
         self.max_throttle_in_force = params.max_throttle_in_force   # :142
+        self._force_multiplier_pid = None
+
+    @property
+    def force_multiplier_pid(self):
+        """Drone.force_multiplier_pid (components.py:143-145): the guidance PID built from the params' `drone.
+        force_multiplier_pid` gains with min_output / max_output REPLACED by the 5 %-throttle and full-throttle forces,
+        dt = 1/fps; one controller per drone (fpyv_amd.pid.PID, HIP kernel fpv_pid_kernel).  Created on first use -
+        a fresh controller is in its reset state - and reset by reset() like the reference does (:166)."""
+        if self._force_multiplier_pid is None:
+            from .pid import PID
+            kw = dict(self.params.force_multiplier_pid)
+            kw["min_output"], kw["max_output"] = self.min_throttle_in_force, self.max_throttle_in_force   # :143-144
+            self._force_multiplier_pid = PID(**kw, dt=self.dt, num_envs=self.n, device=self.device)         # :145
+        return self._force_multiplier_pid
 
     def reset(self, position=None, velocity=None, ypr=None, mask=None) -> None:
         """Drone.reset: `ypr` is consumed as (roll, pitch, yaw) in degrees, like the reference
         (components.py:150-154).  Arguments broadcast from [3] or are per drone [num_envs, 3];
         None uses params.init_*."""
         self._reset_raw(mask=mask, position=position, velocity=velocity, ypr=ypr)
+        if self._force_multiplier_pid is not None:
+            self._force_multiplier_pid.reset(mask)                  # components.py:166
 
     def step(self, action, wind_velocity_vector=None, object_list=(), rotation_matrix=None, thrust_force=None,
              return_imu: bool = True):
@@ -451,13 +473,15 @@ class DroneBatch(_Batch):
         reference, `thrust_force` without `rotation_matrix` is ignored."""
         if action is None and not self.stick_noise:
             raise ValueError("action=None reads a physical joystick in the reference; pass stick values")
-        self._set_override(rotation_matrix, thrust_force)
-        self._set_objects(object_list)
         try:
+            self._set_override(rotation_matrix, thrust_force)
+            self._set_objects(object_list)
             self._step_raw(action, wind_velocity_vector)
         finally:
-            if rotation_matrix is not None:
-                self._buf.rotation_override = self._buf.thrust_override = None
+            # whatever raised (a bad object row, too many objects, a bad action): the next plain step() must not
+            # inherit this call's guidance matrix
+            self._buf.rotation_override = self._buf.thrust_override = None
+            self._override_keep = None
         if not return_imu:
             return None
         R = self.rotation_matrix
@@ -503,6 +527,8 @@ class DroneBatch(_Batch):
         a = getattr(self, "_keepalive", None)
         if a is None or self._buf.action is None:
             return None
+        if a.dim() == 3:                             # a rollout's [k, num_envs, 4] batch: its last step
+            return a[-1, :, 3]
         return a[3] if self._buf.action_ld else a[:, 3]
 
 
@@ -570,7 +596,7 @@ class FpvVecEnv:
         if self.batch.last_return is not None:
             info["episode_return"] = self.batch.last_return
             info["episode_length"] = self.batch.last_length
-        return self.obs, self.batch.reward, self.batch.done_u8, info
+        return self.obs, self.batch.reward, self.batch.done, info
 
     def close(self) -> None:
         self.batch.close()

@@ -139,6 +139,10 @@ class DroneParams:
     # in-kernel stick noise (tests/noise_smooth_test.py:5-11): x_s <- (1 - tau) x_s + tau N(0,1)
     noise_transition: float = 0.1
     noise_gain: float = 1.0
+    # drone.force_multiplier_pid of params.yaml (:55-62): kwargs of the guidance PID (components.py:143-145); its
+    # min_output / max_output are replaced by the 5 % / full throttle forces when the drone builds the controller
+    force_multiplier_pid: Dict[str, float] = dataclasses.field(default_factory=lambda: dict(
+        kP=0.1, kI=2.0, kD=0.05, integral_clip=100.0, min_output=0.05, max_output=40.0, derivative_transition_rate=0.2))
     # ordered object_list for the collision pass (components.py:198-214): tuples
     # (type, x, y, z, radius, height) with type 0 = Ground, 1 = Cylinder, 2 = Target sphere; max 8
     objects: tuple = ()
@@ -237,6 +241,8 @@ def params_from_dict(cfg: Dict[str, Any], yaml_dir: str = _DATA_DIR, mode: Any =
         ground_spring=float(st.get("ground_spring", 100.0)),
         ground_damping=float(st.get("ground_damping", 0.0)),
     )
+    if "force_multiplier_pid" in drone:                                          # params.yaml:55-62
+        p.force_multiplier_pid = {k: float(v) for k, v in drone["force_multiplier_pid"].items()}
     # 5 % throttle floor / full throttle, components.py:139-142
     p.min_throttle_in_force = float(p.thrust_from_stick(-1 + 5 / 100 * 2))
     p.max_throttle_in_force = float(p.thrust_from_stick(1.0))

@@ -10,6 +10,7 @@ from __future__ import annotations
 import ctypes as C
 from typing import Any, Optional
 
+import numpy as np
 import torch
 
 from . import _lib
@@ -55,18 +56,25 @@ class PID:
 
     def __call__(self, current, target) -> torch.Tensor:
         """error = current - target (components.py:44); returns the clipped output, [num_envs] on the device."""
-        cur = torch.as_tensor(current, dtype=torch.float32, device=self.device).expand(self.n).contiguous()
-        tgt_ptr, tgt_scalar = None, 0.0
-        if torch.is_tensor(target) and target.numel() > 1:
-            tgt = target.to(device=self.device, dtype=torch.float32).expand(self.n).contiguous()
+        cur = self._per_drone(current)
+        tgt, tgt_ptr, tgt_scalar = None, None, 0.0
+        if np.ndim(target) == 0 or (hasattr(target, "numel") and target.numel() == 1) or np.size(target) == 1:
+            tgt_scalar = float(target.reshape(-1)[0]) if hasattr(target, "reshape") else float(target)
+        else:                                        # one target per drone: tensor, ndarray, list
+            tgt = self._per_drone(target)
             tgt_ptr = tgt.data_ptr()
-        else:
-            tgt, tgt_scalar = None, float(target)
         _lib.check(self._L.fpv_pid_call(C.byref(self._params()), self.state.data_ptr(), self.ld, self.n, cur.data_ptr(),
                                         tgt_ptr, tgt_scalar, self.output.data_ptr(), self.error.data_ptr(), self._dev,
                                         self._stream()))
         self._keep = (cur, tgt)
         return self.output
+
+    def _per_drone(self, x) -> torch.Tensor:
+        t = x if torch.is_tensor(x) else torch.as_tensor(np.asarray(x, dtype=np.float32))
+        t = t.to(device=self.device, dtype=torch.float32).reshape(-1)
+        if t.numel() not in (1, self.n):
+            raise ValueError(f"expected a scalar or {self.n} values, got {t.numel()}")
+        return t.expand(self.n).contiguous()
 
     @property
     def integral(self) -> torch.Tensor:

@@ -15,7 +15,8 @@
  *     the library never allocates, frees or copies device state.
  *   - `stream` is a hipStream_t (NULL = default stream).  Calls only enqueue work; asynchronous
  *     kernel faults surface at the caller's next synchronisation.
- *   - a handle is bound to one device and is not thread-safe; use one per GPU / host thread.
+ *   - a handle is bound to one device and is not thread-safe; use one per GPU / host thread.  Every call makes the
+ *     handle's device current for its own launches and restores the caller's current device before returning.
  */
 #ifndef FPV_ABI_H
 #define FPV_ABI_H
@@ -26,7 +27,10 @@
 extern "C" {
 #endif
 
-#define FPV_ABI_VERSION 3
+/* 4: 64-bit step counter (fpv_set_step_counter takes uint64_t, fpv_get_step_counter added; the stick-noise stream is
+ *    unchanged below 2^32 steps and no longer repeats beyond); fpv_set_tuning removed (2 / 4 drones per lane and
+ *    256-thread workgroups lost every measurement); fpv_comm_info added; fpv_step_n reads action rows only. */
+#define FPV_ABI_VERSION 4
 
 enum {
     FPV_OK = 0,
@@ -153,7 +157,8 @@ typedef struct fpv_buffers {
     const float* action;     /* [n][4] = roll, pitch, yaw, throttle per drone (components.py:181-186), 16-byte aligned;
                                 or, when action_ld > 0, SoA [4][action_ld] */
     float* reward;           /* [n] */
-    uint8_t* done;           /* [n] 0/1  (Drone.done, components.py:236-240) */
+    uint8_t* done;           /* [n] one byte per drone, exactly 0 or 1 (Drone.done, components.py:236-240): a C99 bool /
+                                numpy.bool_ / torch.bool array can be passed as it is */
     uint64_t* done_bits;     /* [ceil(n/64)] bit i%64 of word i/64 = done[i]; 8-byte aligned */
     float* accel;            /* [3][ld] R_new @ acc, the third value Drone.step returns (components.py:248) */
     float* ep_return;        /* [n] running episode return (read-modify-write) */
@@ -161,7 +166,8 @@ typedef struct fpv_buffers {
     float* last_return;      /* [n] written when a lane reports done */
     int32_t* last_length;    /* [n] */
     float wind[3];           /* wind_velocity_vector of this step (kinematics.py:35: ADDED to v) */
-    uint32_t rounding_seed;  /* FPV_FLAG_FP16_STATE: mixed with the handle's launch counter for the stochastic rounding */
+    uint32_t rounding_seed;  /* FPV_FLAG_FP16_STATE: mixed with the handle's 64-bit step counter for the stochastic rounding
+                                (step t of the handle rounds with rounding_seed + t, the counter's high word folded in) */
     uint16_t* state_h;       /* FPV_FLAG_FP16_STATE: [FPV_HALF_PAIR_ROWS][ld] half2 pairs (4 bytes each) + [ld] thrust halves,
                                 8-byte aligned; else unused */
     float* pos_comp;         /* [6][ld] Kahan compensation of the p and v accumulations, or NULL (plain fp32 sums).
@@ -234,13 +240,17 @@ int fpv_rollout(fpv_handle_t h, const fpv_buffers_t* b, int k, int64_t action_st
  * loop `for i in range(time_steps): drone.step(...)` of src/core/simulator.py:83-156 without the
  * 112-byte state round trip per step: (16 + 5 + 112/k) B per env-step instead of 133 B.
  * Supported: drone mode (fp32 or fp16 state; stick noise, objects, Kahan rows in any combination) and
- * racer mode; obs_aos is refused (an observation row per step is a closed-loop need: use fpv_step). */
+ * racer mode; obs_aos and SoA sticks (action_ld > 0) are refused: an observation row per step and a policy's
+ * [4, n] output are closed-loop needs - use fpv_step (or fpv_rollout). */
 int fpv_step_n(fpv_handle_t h, const fpv_buffers_t* b, int k, int64_t action_stride,
                int64_t out_stride, void* stream);
 
-/* The step index that keys the stick-noise stream (and the stochastic rounding) counts launches of a
- * handle from 0; set it to resume / replay a run. */
-int fpv_set_step_counter(fpv_handle_t h, uint32_t step);
+/* The 64-bit step index that keys the stick-noise stream (Philox4x32-10 counter = global drone id, step index; key =
+ * noise_seed) and the stochastic rounding counts the steps a handle has launched, from 0: set it to resume / replay a
+ * run, read it to checkpoint one.  2^64 steps do not wrap in practice (2^32 took 5.5 h at the k-step kernel's rate,
+ * which is why the 32-bit counter of ABI <= 3 was widened); streams below 2^32 steps are those of ABI <= 3 bit for bit. */
+int fpv_set_step_counter(fpv_handle_t h, uint64_t step);
+int fpv_get_step_counter(fpv_handle_t h, uint64_t* step);
 
 /* Same k steps as fpv_rollout, replayed from a hipGraph cached in the handle: for small, launch-bound
  * batches (a 4096-drone step is ~2 us of kernel behind ~4 us of launch).  The graph is rebuilt only when
@@ -254,10 +264,6 @@ int fpv_rollout_graph(fpv_handle_t h, const fpv_buffers_t* b, int k, int64_t act
 /* Replace the drone type of a live handle (e.g. domain randomisation between episodes). */
 int fpv_set_params(fpv_handle_t h, const fpv_params_t* params);
 
-/* Launch geometry: drones per lane in {1,2,4} and threads per workgroup in {128,256}; 0 restores
- * the built-in choice (1 drone per lane, 128 threads - the fastest measured on MI355X). */
-int fpv_set_tuning(fpv_handle_t h, int drones_per_lane, int block_threads);
-
 /* Row stride (in floats) to allocate for n drones: n rounded up to 64, padded so that the stride in
  * bytes is at least 1 KiB past a multiple of 8 KiB (strides at or near a multiple of 8 KiB put all 14
  * rows on the same HBM channel/bank set).  Any ld >= n that is a multiple of 4 is accepted by fpv_step. */
@@ -266,6 +272,9 @@ int64_t fpv_recommended_ld(int64_t n);
 /* Diagnostics only: dst[i] = src[i] for n_floats fp32 values with the step kernel's access shape
  * (one dword per lane); a known-byte-count launch for calibrating rocprofv3 byte counters. */
 int fpv_diag_stream_copy(float* dst, const float* src, int64_t n_floats, void* stream);
+/* the same copy with 16 bytes per lane (n_floats a multiple of 4, 16-byte aligned pointers): the streaming ceiling of
+ * the chip on this box - bench.py times it beside the step kernel at 2^23 drones (roofline.beyond_mall.copy_ceiling_GBs) */
+int fpv_diag_stream_copy_wide(float* dst, const float* src, int64_t n_floats, void* stream);
 
 /* ---- multi-GPU: contiguous shards, one process (or thread) per GPU, RCCL over xGMI ---------------------------
  * The physics needs no collective (drones are independent); the only exchange of the path is the all-gather of the
@@ -280,6 +289,9 @@ int fpv_comm_unique_id(uint8_t id[FPV_COMM_ID_BYTES]);
 /* every rank: join the communicator (ncclCommInitRank) on `device`; collective - returns when all ranks joined */
 int fpv_comm_create(const uint8_t id[FPV_COMM_ID_BYTES], int world_size, int rank, int device, fpv_comm_t* out);
 void fpv_comm_destroy(fpv_comm_t c);
+/* what the communicator was created with, and the RCCL version (ncclGetVersion: e.g. 22105) actually loaded - lets a
+ * benchmark line certify "RCCL saw N ranks"; any out pointer may be NULL */
+int fpv_comm_info(fpv_comm_t c, int* world_size, int* rank, int* rccl_version);
 /* all-gather of the bit-packed done masks: every rank contributes words_per_rank 64-bit words (its
  * fpv_buffers_t.done_bits, or a whole [steps][words] bucket of them) and receives world_size * words_per_rank words,
  * rank r's block at recv + r * words_per_rank.  Enqueued on `stream`; equal shard sizes on every rank. */

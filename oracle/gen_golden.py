@@ -142,6 +142,12 @@ def main():
     save("g1_zero_10k", dt=1e-3, actions=sticks.zeros(10000, 1), init_position=[p0], init_velocity=[v0],
          init_ypr=[o0], wind=np.zeros(3), **stack([c]))
 
+    # ---- G1 at the DEFAULT fps = 60 of config/params.yaml:2 - BASELINE configs[0] to the letter: "1 drone, params.yaml
+    #      defaults, 10 k steps of zero stick input" (166.7 s of flight; the drone climbs to ~3.4 km) ----
+    c, _ = run_drone(Drone, P60, sticks.zeros(10000, 1)[:, 0], p0, v0, o0, stride=100)
+    save("g1_zero_10k_fps60", dt=1 / 60, actions=sticks.zeros(10000, 1), init_position=[p0], init_velocity=[v0],
+         init_ypr=[o0], wind=np.zeros(3), **stack([c]))
+
     # ---- G1b: default fps = 60 (large per-step angles), sin/cos sticks, 600 steps ----
     ids = [0, 1024, 2048, 3072]
     a = sticks.sinusoid(600, 4096, 1 / 60, amplitude=0.8, drone_ids=ids)

@@ -43,9 +43,8 @@ int fpvl_run(const fpv_params_t* P, int64_t n, int steps, float* st, int64_t ld,
              int per_step, const float wind[3], float* accel, uint8_t* done, float* reward)
 {
     FpvK K;
-    bool big = false;
     const char* why = "";
-    const int rc = fpv_derive_constants(P, &K, &big, &why);
+    const int rc = fpv_derive_constants(P, &K, &why);
     if (rc != FPV_OK) return rc;
     // the two-height ground flag of the k-step kernels' X-frame loop (fpv_drone_step_lane<.., SQ = true>) is used
     // here whenever its precondition holds, unless a test asks for the four-height form
@@ -67,14 +66,11 @@ int fpvl_run(const fpv_params_t* P, int64_t n, int steps, float* st, int64_t ld,
                 const float* ro = g_rot_over ? g_rot_over + i * 9 : nullptr;
                 const float to = g_rot_over ? g_thrust_over[i] : 0.0f;
                 if (g_objs.count > 0)
-                    o = big ? fpv_drone_step_lane<true, true>(K, s, a[0], a[1], a[2], a[3], wind[0], wind[1], wind[2], &g_objs, kp, ro, to)
-                            : fpv_drone_step_lane<false, true>(K, s, a[0], a[1], a[2], a[3], wind[0], wind[1], wind[2], &g_objs, kp, ro, to);
+                    o = fpv_drone_step_lane<true>(K, s, a[0], a[1], a[2], a[3], wind[0], wind[1], wind[2], &g_objs, kp, ro, to);
                 else if (sq)
-                    o = big ? fpv_drone_step_lane<true, false, true, true>(K, s, a[0], a[1], a[2], a[3], wind[0], wind[1], wind[2], nullptr, kp, ro, to)
-                            : fpv_drone_step_lane<false, false, true, true>(K, s, a[0], a[1], a[2], a[3], wind[0], wind[1], wind[2], nullptr, kp, ro, to);
+                    o = fpv_drone_step_lane<false, true, true>(K, s, a[0], a[1], a[2], a[3], wind[0], wind[1], wind[2], nullptr, kp, ro, to);
                 else
-                    o = big ? fpv_drone_step_lane<true>(K, s, a[0], a[1], a[2], a[3], wind[0], wind[1], wind[2], nullptr, kp, ro, to)
-                            : fpv_drone_step_lane<false>(K, s, a[0], a[1], a[2], a[3], wind[0], wind[1], wind[2], nullptr, kp, ro, to);
+                    o = fpv_drone_step_lane<false>(K, s, a[0], a[1], a[2], a[3], wind[0], wind[1], wind[2], nullptr, kp, ro, to);
                 if (g_pos_comp) {
                     const bool rst = (K.flags & FPV_FLAG_AUTO_RESET) && o.done;
                     for (int k = 0; k < 6; ++k) g_pos_comp[k * ld + i] = rst ? 0.0f : kc[k];
@@ -131,16 +127,16 @@ int fpvl_run(const fpv_params_t* P, int64_t n, int steps, float* st, int64_t ld,
 }  // extern "C"
 
 // fp16-storage variant: pos [3][ld] fp32, sh = [5][ld] half2 pairs (uint32) followed by [ld] thrust halves;
-// every step goes through the same unpack -> step -> pack (stochastic rounding keyed by seed0 + t) as
+// every step goes through the same unpack -> step -> pack (stochastic rounding keyed by
+// fpv_round_seed(seed0, step0 + t): the buffer's rounding_seed and the handle's 64-bit step counter) as
 // fpv_drone_step_h_kernel.
 extern "C" int fpvl_run_h(const fpv_params_t* P, int64_t n, int steps, float* pos, uint32_t* sh, int64_t ld,
                           const float* actions, int per_step, const float wind[3], uint32_t seed0,
-                          uint8_t* done, float* reward)
+                          uint8_t* done, float* reward, uint64_t step0)
 {
     FpvK K;
-    bool big = false;
     const char* why = "";
-    const int rc = fpv_derive_constants(P, &K, &big, &why);
+    const int rc = fpv_derive_constants(P, &K, &why);
     if (rc != FPV_OK) return rc;
     uint16_t* thrust = reinterpret_cast<uint16_t*>(sh + FPV_HALF_PAIR_ROWS * ld);
     for (int64_t i = 0; i < n; ++i) {
@@ -155,10 +151,9 @@ extern "C" int fpvl_run_h(const fpv_params_t* P, int64_t n, int steps, float* po
             h.t = thrust[i];
             fpv_unpack_half(h, s);
             const float* a = actions + ((per_step ? (int64_t)t * n : 0) + i) * 4;
-            o = big ? fpv_drone_step_lane<true>(K, s, a[0], a[1], a[2], a[3], wind[0], wind[1], wind[2])
-                    : fpv_drone_step_lane<false>(K, s, a[0], a[1], a[2], a[3], wind[0], wind[1], wind[2]);
+            o = fpv_drone_step_lane<false>(K, s, a[0], a[1], a[2], a[3], wind[0], wind[1], wind[2]);
             if ((K.flags & FPV_FLAG_AUTO_RESET) && o.done) fpv_drone_reset_lane(K, s);
-            fpv_pack_half(s, seed0 + (uint32_t)t, (uint32_t)i, h);
+            fpv_pack_half(s, fpv_round_seed(seed0, step0 + (uint64_t)t), (uint32_t)i, h);
             pos[0 * ld + i] = s.px; pos[1 * ld + i] = s.py; pos[2 * ld + i] = s.pz;
             fpv_join_pairs(h, w);
             for (int k = 0; k < FPV_HALF_PAIR_ROWS; ++k) sh[k * ld + i] = w[k];
@@ -177,18 +172,17 @@ extern "C" float fpvl_f16_to_f32(uint16_t h) { return fpv_f16_to_f32(h); }
 // stick-noise generator on the host: ns [4][ld] EMA state advanced `steps` times from step index
 // step0; applied [steps][n][4] receives clip(base + gain * x_s) (base = 0 when base_actions is NULL)
 extern "C" int fpvl_stick_noise(const fpv_params_t* P, int64_t n, int steps, float* ns, int64_t ld,
-                                const float* base_actions, float* applied, uint32_t step0)
+                                const float* base_actions, float* applied, uint64_t step0)
 {
     FpvK K;
-    bool big = false;
     const char* why = "";
-    const int rc = fpv_derive_constants(P, &K, &big, &why);
+    const int rc = fpv_derive_constants(P, &K, &why);
     if (rc != FPV_OK) return rc;
     for (int t = 0; t < steps; ++t)
         for (int64_t i = 0; i < n; ++i) {
             float s[4], a[4];
             for (int k = 0; k < 4; ++k) { s[k] = ns[k * ld + i]; a[k] = base_actions ? base_actions[((int64_t)t * n + i) * 4 + k] : 0.0f; }
-            fpv_stick_noise(K.noise, step0 + (uint32_t)t, (uint64_t)i, s, a);
+            fpv_stick_noise(K.noise, step0 + (uint64_t)t, (uint64_t)i, s, a);
             for (int k = 0; k < 4; ++k) { ns[k * ld + i] = s[k]; if (applied) applied[((int64_t)t * n + i) * 4 + k] = a[k]; }
         }
     return FPV_OK;
@@ -203,6 +197,8 @@ extern "C" void fpvl_philox(const uint32_t ctr[4], const uint32_t key[2], uint32
 extern "C" uint32_t fpvl_lane_offset(uint32_t i, uint32_t elem_bytes) { return fpv_lane_offset(i, elem_bytes); }
 extern "C" int64_t fpvl_max_drones(void) { return FPV_MAX_DRONES; }
 extern "C" void fpvl_sincos_wide(double x, double* s, double* c) { fpv_sincos_wide(x, s, c); }
+extern "C" void fpvl_sincos_reduced(float x, float* s, float* c) { fpv_sincos_reduced(x, s, c); }
+extern "C" uint32_t fpvl_round_seed(uint32_t base, uint64_t step) { return fpv_round_seed(base, step); }
 
 // components.PID in the kernel's fp32 arithmetic over a sequence: k[8] = kP, kI, kD, dt, integral_clip,
 // min_output, max_output, derivative_transition_rate; st[4] = integral, prev_derivative, previous_error, is_first

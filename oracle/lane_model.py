@@ -119,15 +119,16 @@ def run(p, state: np.ndarray, actions: np.ndarray, steps: Optional[int] = None, 
 
 
 def run_h(p, pos: np.ndarray, sh: np.ndarray, actions: np.ndarray, steps: Optional[int] = None,
-          wind=(0.0, 0.0, 0.0), seed0: int = 0, n: Optional[int] = None, auto_reset: bool = False):
+          wind=(0.0, 0.0, 0.0), seed0: int = 0, n: Optional[int] = None, auto_reset: bool = False, step0: int = 0):
     """fp16-storage variant: pos [3, ld] float32 and sh [11 * ld] uint16 (binary16 bits in the layout of
     fpv_abi.h: five half2 pair rows, then one row of thrust halves), advanced in place exactly like
-    fpv_drone_step_h_kernel.  Returns (done [n], reward [n])."""
+    fpv_drone_step_h_kernel; step t rounds with fpv_round_seed(seed0, step0 + t) (seed0 = the buffer's rounding_seed,
+    step0 = the handle's 64-bit step counter; for step0 + t < 2^32 that is seed0 + step0 + t).  Returns (done [n], reward [n])."""
     L = lib()
     if not hasattr(L, "_h_ready"):
         L.fpvl_run_h.argtypes = [C.POINTER(abi.FpvParams), C.c_int64, C.c_int, C.POINTER(C.c_float),
                                  C.c_void_p, C.c_int64, C.POINTER(C.c_float), C.c_int,
-                                 C.POINTER(C.c_float), C.c_uint32, C.POINTER(C.c_uint8), C.POINTER(C.c_float)]
+                                 C.POINTER(C.c_float), C.c_uint32, C.POINTER(C.c_uint8), C.POINTER(C.c_float), C.c_uint64]
         L.fpvl_run_h.restype = C.c_int
         L.fpvl_f32_to_f16.argtypes = [C.c_float, C.c_uint32, C.c_int]
         L.fpvl_f32_to_f16.restype = C.c_uint16
@@ -148,7 +149,8 @@ def run_h(p, pos: np.ndarray, sh: np.ndarray, actions: np.ndarray, steps: Option
     cp = abi.pack_params(p, auto_reset=auto_reset, fp16_state=True)
     fp = lambda a: a.ctypes.data_as(C.POINTER(C.c_float))  # noqa: E731
     rc = L.fpvl_run_h(C.byref(cp), n, steps, fp(pos), sh.ctypes.data, ld, fp(actions),
-                      int(per_step), fp(w), seed0, done.ctypes.data_as(C.POINTER(C.c_uint8)), fp(reward))
+                      int(per_step), fp(w), int(seed0) & 0xFFFFFFFF, done.ctypes.data_as(C.POINTER(C.c_uint8)), fp(reward),
+                      int(step0) & (2 ** 64 - 1))
     if rc != 0:
         raise RuntimeError(f"fpvl_run_h failed with {rc}")
     return done, reward
@@ -177,7 +179,7 @@ def stick_noise(p, n: int, steps: int, noise_seed: int = 0, drone_id_offset: int
     """Host build of the in-kernel generator.  Returns (applied [steps, n, 4] fp32, ns [4, ld] fp32)."""
     L = lib()
     L.fpvl_stick_noise.argtypes = [C.POINTER(abi.FpvParams), C.c_int64, C.c_int, C.POINTER(C.c_float), C.c_int64,
-                                   C.c_void_p, C.POINTER(C.c_float), C.c_uint32]
+                                   C.c_void_p, C.POINTER(C.c_float), C.c_uint64]
     L.fpvl_stick_noise.restype = C.c_int
     ld = (n + 63) // 64 * 64 if ns is None else ns.shape[1]
     ns = np.zeros((4, ld), dtype=np.float32) if ns is None else ns
@@ -185,10 +187,31 @@ def stick_noise(p, n: int, steps: int, noise_seed: int = 0, drone_id_offset: int
     base = None if base_actions is None else np.ascontiguousarray(base_actions, dtype=np.float32)
     cp = abi.pack_params(p, stick_noise=True, noise_seed=noise_seed, drone_id_offset=drone_id_offset)
     fp = lambda a: a.ctypes.data_as(C.POINTER(C.c_float))  # noqa: E731
-    rc = L.fpvl_stick_noise(C.byref(cp), n, steps, fp(ns), ld, None if base is None else base.ctypes.data, fp(applied), step0)
+    rc = L.fpvl_stick_noise(C.byref(cp), n, steps, fp(ns), ld, None if base is None else base.ctypes.data, fp(applied),
+                            int(step0) & (2 ** 64 - 1))
     if rc != 0:
         raise RuntimeError(f"fpvl_stick_noise failed with {rc}")
     return applied, ns
+
+
+def sincos_reduced(x: np.ndarray):
+    """(sin x, cos x) in the kernel's own fp32 arithmetic for angles of any size (fpv_sincos_reduced)."""
+    L = lib()
+    L.fpvl_sincos_reduced.argtypes = [C.c_float, C.POINTER(C.c_float), C.POINTER(C.c_float)]
+    x = np.asarray(x, dtype=np.float32)
+    s, c = np.zeros_like(x), np.zeros_like(x)
+    a, b = C.c_float(), C.c_float()
+    for i, v in enumerate(x):
+        L.fpvl_sincos_reduced(float(v), C.byref(a), C.byref(b))
+        s[i], c[i] = a.value, b.value
+    return s, c
+
+
+def round_seed(base: int, step: int) -> int:
+    L = lib()
+    L.fpvl_round_seed.argtypes = [C.c_uint32, C.c_uint64]
+    L.fpvl_round_seed.restype = C.c_uint32
+    return int(L.fpvl_round_seed(int(base) & 0xFFFFFFFF, int(step) & (2 ** 64 - 1)))
 
 
 def philox(ctr, key):

@@ -28,11 +28,13 @@ def philox4x32_10(ctr, key):
 
 
 def normal4(seed, drone_ids, step):
-    """[n, 4] float64 standard normals for global drone ids `drone_ids` at step index `step`."""
+    """[n, 4] float64 standard normals for global drone ids `drone_ids` at the 64-bit step index `step`
+    (Philox counter = drone id low, high, step low, high; the high word is 0 below 2^32 steps)."""
     ids = np.asarray(drone_ids, dtype=np.uint64)
     n = ids.shape[0]
+    step = int(step) & (2 ** 64 - 1)
     ctr = np.stack([(ids & np.uint64(0xFFFFFFFF)).astype(np.uint32), (ids >> np.uint64(32)).astype(np.uint32),
-                    np.full(n, step, dtype=np.uint32), np.zeros(n, dtype=np.uint32)], axis=-1)
+                    np.full(n, step & 0xFFFFFFFF, dtype=np.uint32), np.full(n, step >> 32, dtype=np.uint32)], axis=-1)
     key = np.broadcast_to(np.array([seed & 0xFFFFFFFF, (seed >> 32) & 0xFFFFFFFF], dtype=np.uint32), (n, 2))
     r = philox4x32_10(ctr, key)
     u = ((r >> np.uint32(8)).astype(np.float64) + 0.5) * 2.0 ** -24

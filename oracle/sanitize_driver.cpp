@@ -18,9 +18,9 @@ extern "C" {
 int fpvl_run(const fpv_params_t* P, int64_t n, int steps, float* st, int64_t ld, const float* actions, int per_step,
              const float wind[3], float* accel, uint8_t* done, float* reward);
 int fpvl_run_h(const fpv_params_t* P, int64_t n, int steps, float* pos, uint32_t* sh, int64_t ld, const float* actions,
-               int per_step, const float wind[3], uint32_t seed0, uint8_t* done, float* reward);
+               int per_step, const float wind[3], uint32_t seed0, uint8_t* done, float* reward, uint64_t step0);
 int fpvl_stick_noise(const fpv_params_t* P, int64_t n, int steps, float* ns, int64_t ld, const float* base_actions,
-                     float* applied, uint32_t step0);
+                     float* applied, uint64_t step0);
 void fpvl_set_objects(const fpv_objects_t* t);
 void fpvl_set_pos_comp(float* c);
 void fpvl_set_override(const float* rot, const float* thrust);
@@ -131,14 +131,14 @@ int main()
             std::vector<uint32_t> sh(((size_t)FPV_HALF_ROWS_TOTAL_HALVES * ld + 1) / 2, 0u);
             std::vector<uint8_t> done((size_t)n);
             for (int64_t i = 0; i < n; ++i) { pos[2 * ld + i] = 0.5f; sh[(size_t)1 * ld + i] = 0x3c000000u; }     // qw = 1.0 (high half of pair row 1)
-            if (fpvl_run_h(&P, n, steps, pos.data(), sh.data(), ld, acts.data(), 1, wind, 9u, done.data(), rew.data()) != 0) return 2;
+            if (fpvl_run_h(&P, n, steps, pos.data(), sh.data(), ld, acts.data(), 1, wind, 9u, done.data(), rew.data(), 0xfffffffeull) != 0) return 2;       // crosses 2^32 steps
         }
         // ---- lane model, stick noise ----
         {
             fpv_params_t P = abi_params(FPV_MODE_DRONE, FPV_FLAG_STICK_NOISE);
             std::vector<float> ns((size_t)4 * ld, 0.0f), applied((size_t)steps * n * 4);
-            if (fpvl_stick_noise(&P, n, steps, ns.data(), ld, acts.data(), applied.data(), 3u) != 0) return 2;
-            if (fpvl_stick_noise(&P, n, steps, ns.data(), ld, nullptr, nullptr, 40u) != 0) return 2;
+            if (fpvl_stick_noise(&P, n, steps, ns.data(), ld, acts.data(), applied.data(), 0xfffffffdull) != 0) return 2;     // crosses 2^32 steps
+            if (fpvl_stick_noise(&P, n, steps, ns.data(), ld, nullptr, nullptr, 40ull) != 0) return 2;
         }
         // ---- lane model, racer: fp32 omega*dt / as written (float64) x both PID semantics ----
         for (int variant = 0; variant < 4; ++variant) {

@@ -27,6 +27,37 @@ def test_self_launch_world2_gloo_stub():
     assert len(lines) == 1, f"rank 0 must print exactly one line, got {lines}"
     out = json.loads(lines[0])
     assert out["n_gpus"] == 2 and out["steps"] == 150 and out["data"] == "stub" and out["gather_ok"] is True
+    # the self-certifying part of an N-rank line: what the process group itself reports
+    c = out["collective"]
+    assert c["world_seen"] == 2 and c["world_env"] == 2 and c["backend"] == "gloo" and c["rank_ids_gathered"] == [0, 1]
+    assert len(c["per_rank_ms_per_step"]["all"]) == 2 and c["per_rank_ms_per_step"]["min"] <= c["per_rank_ms_per_step"]["max"]
+    words = (1000 + 63) // 64
+    assert c["gather"]["block_steps"] == 64 and c["gather"]["bytes_per_bucket"] == 64 * words * 8
+    assert c["gather"]["collectives_launched"] == 150 // 64 + 1          # two whole buckets + the flushed tail
+    assert c["library_version"]
+
+
+def test_a_rank_that_dies_early_ends_the_job_at_once():
+    """rank 1 exits 1 before init_process_group; rank 0 would wait in the rendezvous for the backend's own
+    timeout (10-30 min).  The parent polls every child, stops the survivors and returns the failing code - quickly."""
+    import time
+    t0 = time.monotonic()
+    r = subprocess.run([sys.executable, BENCH, "--gpus", "2", "--steps", "50", "--stub-step", "--stub-fail-rank", "1",
+                        "--drones-per-gpu", "1000"], capture_output=True, text=True, timeout=300, env=_clean_env())
+    took = time.monotonic() - t0
+    assert r.returncode == 1, (r.returncode, r.stderr[-2000:])
+    assert "rank 1 exited with 1" in r.stderr and took < 120, took
+    assert not [ln for ln in r.stdout.splitlines() if ln.strip()], "no JSON line from a failed job"
+
+
+def test_overall_wall_clock_limit_of_self_launched_ranks():
+    """Both ranks alive but stuck (rank 1 never joins: it fails only after a sleep is impossible to stage here, so the
+    limit itself is exercised with a job that cannot finish in time): exit code 124 and no orphan processes."""
+    r = subprocess.run([sys.executable, BENCH, "--gpus", "2", "--steps", "2000000", "--stub-step", "--gather-block", "1",
+                        "--drones-per-gpu", "100000", "--spawn-timeout-s", "6"], capture_output=True, text=True, timeout=300,
+                       env=_clean_env())
+    assert r.returncode == 124, (r.returncode, r.stderr[-2000:])
+    assert "still running after 6 s" in r.stderr
 
 
 def test_refuses_more_gpus_than_the_node_has():

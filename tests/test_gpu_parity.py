@@ -22,11 +22,10 @@ def _drone_batch(p, n, **kw):
     return DroneBatch(p, n, device=DEV, **kw)
 
 
-def _run_golden(p, g, dpl=1, per_step_calls=False):
+def _run_golden(p, g, per_step_calls=False):
     acts = g["actions"]
     T, n = acts.shape[:2]
     env = _drone_batch(p, n)
-    env.set_tuning(dpl)
     env.reset(position=g["init_position"], velocity=g["init_velocity"], ypr=g["init_ypr"])
     a = torch.from_numpy(acts).to(DEV)
     if per_step_calls:
@@ -103,16 +102,14 @@ def test_config1_first_1000_steps_and_10k_drift(params_1k):
     np.testing.assert_allclose(end[6:10], [1, 0, 0, 0], atol=1e-6)
 
 
-@pytest.mark.parametrize("n", [1, 63, 257, 1000, 4096 + 5])
-@pytest.mark.parametrize("dpl,block", [(1, 128), (2, 128), (4, 128), (1, 256), (4, 256)])
-def test_bitwise_equal_to_lane_model_ragged_sizes(params_1k, n, dpl, block):
-    """Empty tails, ragged sizes, every launch geometry: the gfx950 kernel must reproduce the
-    host build of the same arithmetic bit for bit (both -ffp-contract=off, explicit fmaf)."""
+@pytest.mark.parametrize("n", [1, 63, 64, 127, 129, 257, 1000, 4096 + 5])
+def test_bitwise_equal_to_lane_model_ragged_sizes(params_1k, n):
+    """Empty tails, ragged sizes around the wave (64) and workgroup (128) widths: the gfx950 kernel must reproduce
+    the host build of the same arithmetic bit for bit (both -ffp-contract=off, explicit fmaf)."""
     steps = 50
     acts = sticks.ema_noise(steps, range(n), seed=11)
     acts[:, :, 3] += np.float32(0.1)
     env = _drone_batch(params_1k, n, with_done_bits=True)
-    env.set_tuning(dpl, block)
     env.reset()
     env.rollout(torch.from_numpy(acts).to(DEV), wind=(1.0, -2.0, 0.5))
     torch.cuda.synchronize()
@@ -376,19 +373,18 @@ def test_racer_omega_dt_batch_vs_oracle(params_1k):
 def test_full_size_properties_1M(params_1k):
     """BASELINE config 3 size (2^20 drones): properties that need no full-size oracle run.
     N-invariance (a drone's trajectory does not depend on the batch it sits in or on its lane),
-    unit quaternions, done bit mask == byte mask, every launch geometry agrees bitwise."""
+    unit quaternions, done bit mask == byte mask, every host path (k-step kernel, k launches, hipGraph replay) agrees bitwise."""
     n, k = 1 << 20, 64
     p = params_1k
     acts = sticks.ema_noise_device(k, n, DEV, seed=1234)
     states = []
-    for dpl, block in ((1, 128), (2, 256), (4, 128)):
+    for j, how in enumerate((dict(fused=True), dict(fused=False), dict(graph=True))):
         env = _drone_batch(p, n, with_accel=False, with_done_bits=True)
-        env.set_tuning(dpl, block)
         env.reset()
-        env.rollout(acts)
+        env.rollout(acts, **how)
         torch.cuda.synchronize()
         states.append(env.state.clone())
-        if dpl != 4:
+        if j != 2:
             del env
     assert torch.equal(states[0], states[1]) and torch.equal(states[0], states[2])
     s = states[0]
@@ -424,9 +420,61 @@ def test_vec_env_surface(params_1k):
     a = torch.zeros((1024, 4), device=DEV)
     obs, reward, done, info = env.step(a)
     assert obs.shape == (1024, 13) and reward.shape == (1024,) and done.shape == (1024,)
+    # done[N] bool - the tensor the kernel itself writes (one byte of 0/1 per drone), not a converted copy
+    assert done.dtype == torch.bool and done.data_ptr() == env.batch.done_u8.data_ptr()
     assert "episode_return" in info and info["episode_length"].dtype == torch.int32
     torch.cuda.synchronize()
     np.testing.assert_allclose(reward.cpu().numpy(), -np.linalg.norm(obs[:, 0:3].cpu().numpy() - params_1k.goal, axis=1), rtol=1e-5, atol=1e-6)
+    # done really is written as a bool: drive every other drone through the ceiling
+    low = FpvVecEnv(params_1k.replace(ceiling=10.0005), num_envs=130, device=DEV, auto_reset=True)
+    low.reset()
+    a = torch.zeros((130, 4), device=DEV)
+    a[::2, 3] = 1.0                                    # full throttle: climbs past 10.0005 m within a few steps
+    a[1::2, 3] = -0.9                                  # 5 % throttle: sinks
+    hits = torch.zeros(130, dtype=torch.bool, device=DEV)
+    for _ in range(40):
+        _, _, done, _ = low.step(a)
+        assert done.dtype == torch.bool
+        hits |= done                                   # bool arithmetic on the kernel's own output
+    assert bool(hits[::2].all()) and not bool(hits[1::2].any())
+    raw = low.batch.done_u8.cpu().numpy()
+    assert set(np.unique(raw)) <= {0, 1}
+
+
+@pytest.mark.parametrize("name", ["g7_racer_main", "g8_racer_pid_thrust"])
+def test_vec_env_racer_mode_vs_reference_capture(params_1k, name):
+    """FpvVecEnv(mode="racer"): the gym surface over Racer.step (racer_drone_test.py:95-103) against the reference
+    captures G7 / G8, stepping through env.step() one call per step; obs = (p, v, q, omega) zero-copy, done is bool."""
+    from fpyv_amd.env import FpvVecEnv
+    g = load_golden(name)
+    p = params_1k.replace(mode=1, racer_pid=g["pid"])
+    env = FpvVecEnv(p, num_envs=3, device=DEV, mode="racer", auto_reset=False)
+    obs = env.reset()
+    assert obs.shape == (3, 13) and obs.data_ptr() == env.batch.state.data_ptr()
+    acts = torch.from_numpy(g["actions"]).to(DEV)            # [T, 1, 4]
+    snaps = {int(t): k for k, t in enumerate(np.asarray(g["snap_steps"]).reshape(-1))}
+    worst = dict(quat=0.0, pos=0.0)
+    for t in range(acts.shape[0]):
+        obs, reward, done, info = env.step(acts[t].expand(3, 4).contiguous())
+        if t + 1 in snaps:
+            k = snaps[t + 1]
+            o = obs.cpu().numpy().astype(np.float64)
+            x, y, z, w = g["quat_xyzw"][0, k]
+            qr = np.array([w, x, y, z])
+            q = o[0, 6:10] * np.sign(o[0, 6:10] @ qr)
+            pr = g["position"][0, k]
+            worst["quat"] = max(worst["quat"], np.abs(q - qr).max())
+            worst["pos"] = max(worst["pos"], np.abs(o[0, 0:3] - pr).max() / max(np.abs(pr).max(), 1e-3))
+            assert np.array_equal(o[0], o[1]) and np.array_equal(o[0], o[2])
+    assert done.dtype == torch.bool and not bool(done.any()) and reward.shape == (3,)
+    assert worst["quat"] < REL_TOL and worst["pos"] < REL_TOL, worst
+    # the same steps through RacerBatch.rollout (k-step kernel) land on the same bits
+    from fpyv_amd.env import RacerBatch
+    rb = RacerBatch(p, 3, device=DEV)
+    rb.reset()
+    rb.rollout(acts.expand(-1, 3, 4).contiguous())
+    torch.cuda.synchronize()
+    assert torch.equal(rb.state, env.batch.state)
 
 
 def test_argument_errors(params_1k):
@@ -454,8 +502,7 @@ def test_argument_errors(params_1k):
     h = C.c_void_p()
     assert L.fpv_create(C.byref(bad), 8, 0, C.byref(h)) == -5
     assert L.fpv_create(C.byref(_lib.pack_params(params_1k)), 8, 99, C.byref(h)) == -3
-    with pytest.raises(_lib.FpvError):
-        env.set_tuning(3)
+    assert not hasattr(L, "fpv_set_tuning"), "removed in ABI 4 (the rejected launch geometries are no longer built)"
 
 
 # ---- BASELINE config 4: fp16 state / fp32 integrator -------------------------------------------------
@@ -485,6 +532,43 @@ def test_fp16_state_bitwise_vs_lane_model_and_restated_tolerance(params_1k):
     np.testing.assert_allclose(env.velocity.cpu().numpy(), ref[:, 3:6], rtol=5e-2, atol=5e-2)
 
 
+@pytest.mark.parametrize("n", [1, 63, 333, 4099])
+@pytest.mark.parametrize("fused", [False, True], ids=["single-step", "k-step"])
+def test_fp16_state_ragged_sizes_vs_lane_model_and_oracle(params_1k, n, fused):
+    """the fp16 kernels' odd-n path (st_thrust_pair_h: the last even lane has no live neighbour and the DPP
+    quad-permute hands it a zero half) against an INDEPENDENT restatement - the host lane model, bit for bit, and the
+    float64 oracle within the restated tolerance - for n = 1 (one lane), 63 (odd, inside one wave), 333 (odd, last
+    workgroup partly filled) and 4099 (odd, 33 workgroups)."""
+    from test_lane_model import FP16_TOL
+    steps = 1000 if n <= 333 else 250
+    acts = sticks.ema_noise(steps, range(n), seed=31)
+    env = _drone_batch(params_1k, n, fp16_state=True, rounding_seed=17, with_accel=False)
+    env.reset()
+    a = torch.from_numpy(acts).to(DEV)
+    if fused:
+        for t0 in range(0, steps, 125):
+            env.rollout(a[t0:t0 + 125])                    # fpv_step_n: fpv_drone_rollout_h_kernel
+    else:
+        for t in range(steps):
+            env.step(a[t], return_imu=False)               # fpv_step: fpv_drone_step_h_kernel
+    torch.cuda.synchronize()
+    pos, sh = lane_model.split_half(lane_model.initial_state(params_1k, n))
+    done, rew = lane_model.run_h(params_1k, pos, sh, acts, seed0=17)
+    ld, lm = env.ld, pos.shape[1]
+    got_h = env.state_h.cpu().numpy().view(np.uint16)
+    assert np.array_equal(env.state.cpu().numpy()[:, :n].view(np.uint32), pos[:, :n].view(np.uint32))
+    assert np.array_equal(got_h[:10 * ld].reshape(5, ld, 2)[:, :n], sh[:10 * lm].reshape(5, lm, 2)[:, :n])      # pair rows
+    assert np.array_equal(got_h[10 * ld:10 * ld + n], sh[10 * lm:10 * lm + n]), "thrust halves (the exchanged row)"
+    assert np.array_equal(env.done_u8.cpu().numpy(), done) and np.array_equal(env.reward.cpu().numpy().view(np.uint32), rew.view(np.uint32))
+    # nothing beyond the batch's padded pair of the last drone is written: halves n+1.. of the thrust row stay zero
+    assert not got_h[10 * ld + n + (n & 1):11 * ld].any() and not got_h[:10 * ld].reshape(5, ld, 2)[:, n:].any()
+    ref = oracle.drone_initial_state(n, params_1k.init_position, params_1k.init_velocity, [0, 0, 0])
+    oracle.drone_run(params_1k, ref, acts.astype(np.float64), threads=0)
+    err = soa_vs_oracle(lane_model.join_half(env.state.cpu().numpy(), got_h), ref, n)
+    for k, tol in FP16_TOL.items():
+        assert err[k] <= tol, (k, err[k], n)
+
+
 def test_fp16_state_full_size_vs_fp32_run():
     """Config 4 at full size: same sticks through the fp32 and the fp16-storage kernels; the
     distribution of the difference after 500 steps must sit inside the restated tolerance."""
@@ -505,17 +589,16 @@ def test_fp16_state_full_size_vs_fp32_run():
     assert bool(torch.isfinite(e16.state_h.float()).all())
 
 
-@pytest.mark.parametrize("n,block", [(1, 128), (63, 128), (1000, 128), (4096 + 5, 256), (1 << 16, 128)])
-def test_obs_aos_rows_equal_soa_state(params_1k, n, block):
+@pytest.mark.parametrize("n", [1, 63, 1000, 4096 + 5, 1 << 16])
+def test_obs_aos_rows_equal_soa_state(params_1k, n):
     """The LDS-transposed [n, 16] observation must be exactly the SoA state + the accelerometer
-    triple of the same step (p3 v3 q4 rates3 R_new@acc 3), for ragged sizes and both block widths."""
+    triple of the same step (p3 v3 q4 rates3 R_new@acc 3), for ragged sizes."""
     steps = 20
     acts = torch.from_numpy(sticks.ema_noise(steps, range(min(n, 2048)), seed=2)).to(DEV)
     if n > 2048:
         acts = acts.repeat(1, (n + 2047) // 2048, 1)[:, :n].contiguous()
     env = _drone_batch(params_1k.replace(ceiling=10.4), n, with_obs_aos=True, auto_reset=True)
     plain = _drone_batch(params_1k.replace(ceiling=10.4), n, auto_reset=True)
-    env.set_tuning(1, block)
     env.reset(); plain.reset()
     env.obs_aos.fill_(float("nan"))
     for t in range(steps):
@@ -636,6 +719,34 @@ def test_config1_10k_steps_with_kahan_rows(params_1k):
     assert np.all(pc[:, 0] == 0) and np.any(pc[:, 1] != 0)
 
 
+def test_config0_default_fps60_10k_steps_with_kahan_rows(params_60):
+    """BASELINE configs[0] to the letter - params.yaml defaults (fps = 60), zero sticks, 10 000 steps - on the GPU with
+    the Kahan rows, against the reference capture G1 @ fps 60 at every 100th step (1e-5; measured < 1e-6) and the
+    host lane model bit for bit."""
+    g = load_golden("g1_zero_10k_fps60")
+    env = _drone_batch(params_60, 2, kahan_position=True)
+    env.reset()
+    a = torch.zeros((100, 2, 4), dtype=torch.float32, device=DEV)
+    worst = 0.0
+    for k, t in enumerate(np.asarray(g["snap_steps"]).reshape(-1)):
+        env.rollout(a)
+        ref = np.concatenate([g["state"][:, k], g["R"][:, k].reshape(1, 9), g["prev_rates"][:, k], g["prev_thrust"][:, k:k + 1]], axis=1)
+        err = soa_vs_oracle(env.state.cpu().numpy()[:, :1].copy(), ref, 1)
+        worst = max(worst, err["pos_rel"], err["pos_comp"], err["quat_abs"])
+        assert int(t) == 100 * (k + 1)
+    assert worst < REL_TOL, worst
+    assert worst < 1e-6, worst
+    assert not bool(env.done.any())
+    model = lane_model.initial_state(params_60, 2)
+    comp = np.zeros((6, model.shape[1]), dtype=np.float32)
+    lane_model.set_pos_comp(comp)
+    try:
+        lane_model.run(params_60, model, np.zeros((2, 4), np.float32), steps=10000)
+    finally:
+        lane_model.set_pos_comp(None)
+    assert np.array_equal(env.state.cpu().numpy()[:, :2].view(np.uint32), model[:, :2].view(np.uint32))
+
+
 def test_checkpoint_resume_is_bit_exact(params_1k, tmp_path):
     """state_dict()/load_state_dict(): tensors + step counter; a resumed run (in-kernel stick noise,
     auto-reset, episode bookkeeping) continues bit for bit, also through torch.save/torch.load."""
@@ -705,13 +816,11 @@ def test_feature_combinations_fuzz_bitwise(params_1k):
         world = ("none", "flag", "list")[case % 3]
         n = int(rng.integers(1, 700))
         steps = int(rng.integers(5, 60))
-        block = (128, 256)[(case // 3) % 2]
         p = base.replace(ground=(world == "flag"))
         acts = rng.uniform(-1, 1, (steps, n, 4)).astype(np.float32)
         acts[..., 3] = rng.uniform(-1, -0.3, (steps, n))            # mostly below hover: ground/objects get hit
         pos = np.concatenate([rng.uniform(-0.5, 0.5, (n, 2)), rng.uniform(0.3, 1.2, (n, 1))], axis=1).astype(np.float32)
         env = _drone_batch(p, n, auto_reset=auto, kahan_position=kahan, with_done_bits=True)
-        env.set_tuning(1, block)
         model = lane_model.initial_state(p, n, pos, [0.5, 0, 0], [0, 0, 0])
         env.state[:, :n] = torch.from_numpy(model[:, :n]).to(DEV)
         comp = np.zeros((6, model.shape[1]), dtype=np.float32)
@@ -726,7 +835,7 @@ def test_feature_combinations_fuzz_bitwise(params_1k):
             lane_model.set_pos_comp(None)
             lane_model.set_objects(())
         torch.cuda.synchronize()
-        tag = f"case {case}: auto={auto} kahan={kahan} world={world} n={n} steps={steps} block={block}"
+        tag = f"case {case}: auto={auto} kahan={kahan} world={world} n={n} steps={steps}"
         assert np.array_equal(env.state.cpu().numpy()[:, :n].view(np.uint32), model[:, :n].view(np.uint32)), tag
         assert np.array_equal(env.done_u8.cpu().numpy(), done), tag
         assert np.array_equal(env.reward.cpu().numpy().view(np.uint32), rew.view(np.uint32)), tag
@@ -735,8 +844,9 @@ def test_feature_combinations_fuzz_bitwise(params_1k):
 
 
 def test_big_angle_path_on_gpu(params_1k):
-    """max_rates so large that one step can turn more than 90 degrees: fpv_create selects the library
-    sincos instantiation (BIG); same physical trajectory as the small-angle kernel and the oracle."""
+    """max_rates so large that one step can turn more than 90 degrees: fpv_create selects angle mode 2 (range
+    reduction without a library call, fpv_sincos_reduced); same physical trajectory as the small-angle kernel and the
+    oracle, and - new in round 3 - the same bits as the host build."""
     g = load_golden("g3_ema_noise")
     n = g["actions"].shape[1]
     p_big = params_1k.replace(max_rates=2.0e5)
@@ -759,6 +869,16 @@ def test_big_angle_path_on_gpu(params_1k):
     oracle.drone_run(p_big, ref, acts2.astype(np.float64))
     err = soa_vs_oracle(env.state.cpu().numpy(), ref, n)
     assert err["quat_abs"] < 5e-5 and err["pos_rel"] < 5e-5, err
+    model = lane_model.initial_state(p_big, n)
+    lane_model.run(p_big, model, acts2)
+    assert np.array_equal(env.state.cpu().numpy()[:, :n].view(np.uint32), model[:, :n].view(np.uint32)), "big-angle kernel != lane model (bitwise)"
+    single = _drone_batch(p_big, n)
+    single.reset()
+    a2 = torch.from_numpy(acts2).to(DEV)
+    for t in range(acts2.shape[0]):
+        single.step(a2[t], return_imu=False)
+    torch.cuda.synchronize()
+    assert torch.equal(single.state, env.state), "single-step and k-step kernels must agree in angle mode 2 as well"
 
 
 def test_graph_rollout_equals_plain_rollout(params_1k):
@@ -1284,40 +1404,146 @@ def test_reference_scalar_attributes_of_drone(params_1k):
     assert abs(env.max_throttle_in_force - float(g["max_throttle_in_force"])) < 1e-10
     assert env.mass == float(g["mass"]) and env.gravity == float(g["gravity"]) and env.max_rates == float(g["max_rates"])
     assert env.prev_rates.shape == (7, 3) and env.prev_thrust.shape == (7,)
+    # after a rollout `throttle` reports the LAST step's sticks of that rollout, not the step() before it
+    acts = torch.rand((5, 7, 4), device=DEV) * 2 - 1
+    env.rollout(acts)
+    assert torch.equal(env.throttle, acts[-1, :, 3])
 
 
-def test_two_ranks_rehearsed_on_one_gpu(params_1k, tmp_path):
-    """The real N-rank path of bench.py at world size 2 - self-launched ranks, per-rank stick streams, the step kernels,
-    the bucketed asynchronous done-mask all-gather with its flush, MAX over ranks, one JSON line - with both ranks on
-    GPU 0 over gloo (RCCL refuses two ranks on one device; the driver's multi-GPU run uses RCCL).  Every rank's final
-    state and the gathered masks of the last bucket must equal a single-process run of the same shards, bit for bit."""
+def test_force_multiplier_pid_built_and_reset_like_the_reference(params_1k):
+    """Drone.force_multiplier_pid (components.py:143-145): PID(**params['drone']['force_multiplier_pid'], dt=dt) with
+    min_output / max_output REPLACED by the 5 %-throttle and full-throttle forces, reset by Drone.reset (:166).  One
+    controller per drone; its arithmetic is the a16 kernel (checked against the reference class in
+    test_components_pid_kernel_vs_reference_class), here: construction constants, per-drone targets, reset."""
+    from fpyv_amd.components import Drone
+    from fpyv_amd.params import DEFAULT_PARAMS_PATH
+    import yaml
+    cfg = yaml.safe_load(open(DEFAULT_PARAMS_PATH))
+    cfg["simulator"]["fps"] = 1000
+    before = yaml.safe_dump(cfg)
+    d = Drone(cfg, num_envs=5, device=DEV)
+    assert yaml.safe_dump(cfg) == before, "the caller's params dict must not be modified (the reference mutates it)"
+    pid = d.force_multiplier_pid
+    g = load_golden("params_golden")
+    assert (pid.kP, pid.kI, pid.kD) == (0.1, 2.0, 0.05) and pid.integral_clip == 100.0 and pid.derivative_transition_rate == 0.2
+    assert abs(pid.min_output - float(g["min_throttle_in_force"])) < 1e-10      # components.py:143
+    assert abs(pid.max_output - float(g["max_throttle_in_force"])) < 1e-10      # components.py:144
+    assert pid.dt == d.dt == 1e-3 and pid.n == 5
+    # the call of components.py:288: multiplier = pid(measured_dist2target, keep_distance); numpy arrays of targets work
+    dist = np.array([3.0, 7.0, 9.0, 12.0, 30.0], dtype=np.float32)
+    out1 = pid(dist, 6.0).clone()
+    out2 = pid(dist, np.full(5, 6.0)).clone()                 # per-drone targets as an ndarray (ADVICE r2)
+    out3 = pid(torch.from_numpy(dist).to(DEV), [6.0] * 5).clone()
+    torch.cuda.synchronize()
+    want, _ = lane_model.pid_run([0.1, 2.0, 0.05, 1e-3, 100.0, pid.min_output, pid.max_output, 0.2], np.repeat(dist[2:3], 3), np.full(3, 6.0))
+    assert np.array_equal(np.array([out1[2].item(), out2[2].item(), out3[2].item()], dtype=np.float32).view(np.uint32), want.view(np.uint32))
+    assert float(out1.min()) >= pid.min_output - 1e-6 and float(out3.max()) <= pid.max_output + 1e-6
+    assert float(pid.integral.abs().max()) > 0
+    d.reset(mask=np.array([1, 0, 1, 0, 1], dtype=np.uint8))                   # components.py:166, masked like the drones
+    torch.cuda.synchronize()
+    integ = pid.integral.cpu().numpy()
+    assert np.all(integ[[0, 2, 4]] == 0) and np.all(integ[[1, 3]] != 0)
+    d.reset()
+    torch.cuda.synchronize()
+    assert float(pid.integral.abs().max()) == 0.0 and bool((pid.state[3, :5] == 1).all())
+    with pytest.raises(ValueError):
+        pid(np.zeros(4), 1.0)
+
+
+def test_failed_step_does_not_leak_the_guidance_override(params_1k):
+    """a step that raises after rotation_matrix= was bound (bad object row, too many objects) must not
+    leave the matrix in place for the next plain step."""
+    n = 9
+    env, ref = _drone_batch(params_1k, n), _drone_batch(params_1k, n)
+    env.reset(); ref.reset()
+    a = torch.zeros((n, 4), device=DEV)
+    R = np.array([[0, 0, 1], [0, 1, 0], [-1, 0, 0]], dtype=np.float32)
+    with pytest.raises((TypeError, ValueError)):
+        env.step(a, object_list=[object()], rotation_matrix=R, thrust_force=5.0, return_imu=False)
+    with pytest.raises((TypeError, ValueError)):
+        env.step(a, object_list=[(0, 0, 0, 0, 0, 0)] * 9, rotation_matrix=R, thrust_force=5.0, return_imu=False)
+    assert not env._buf.rotation_override and not env._buf.thrust_override
+    env.step(a, return_imu=False); ref.step(a, return_imu=False)
+    env.rollout(a, steps=3); ref.rollout(a, steps=3)                          # "use fpv_step" if the override had leaked
+    torch.cuda.synchronize()
+    assert torch.equal(env.state, ref.state)
+
+
+def test_calls_restore_the_callers_current_device(params_1k):
+    """SURVEY 8b "one process with 8 handles": an fpv_* call binds the handle's device for its own launches and puts
+    the caller's current device back.  With one GPU the observable part is that the current device is never left
+    changed and that a handle created for device 0 works from any thread state; the guard itself (DeviceGuard,
+    fpv_hip.hip) is what a multi-GPU host relies on."""
+    import ctypes as C
+    L = _lib.lib()
+    before = torch.cuda.current_device()
+    env = _drone_batch(params_1k, 128)
+    env.reset()
+    env.step(torch.zeros((128, 4), device=DEV), return_imu=False)
+    env.rollout(torch.zeros((4, 128, 4), device=DEV))
+    from fpyv_amd.components import PID
+    PID(1, 0, 0, 1e-3, num_envs=4, device=DEV)(torch.zeros(4, device=DEV), 0.0)
+    torch.cuda.synchronize()
+    assert torch.cuda.current_device() == before
+    if torch.cuda.device_count() > 1:                 # the driver's 8-GPU box: a handle on GPU 1 driven while GPU 0 is current
+        other = _lib.pack_params(params_1k)
+        h = C.c_void_p()
+        assert L.fpv_create(C.byref(other), 64, 1, C.byref(h)) == 0
+        st = torch.zeros((14, 64 + 256), device="cuda:1")
+        b = _lib.FpvBuffers()
+        b.state, b.ld = st.data_ptr(), st.shape[1]
+        torch.cuda.set_device(0)
+        assert L.fpv_reset(h, C.byref(b), None, None, None, None, None) == 0
+        assert torch.cuda.current_device() == 0
+        torch.cuda.synchronize(1)
+        assert float(st[2, 0]) == 10.0
+        L.fpv_destroy(h)
+
+
+@pytest.mark.parametrize("api", ["step", "rollout"])
+def test_two_ranks_rehearsed_on_one_gpu(params_1k, tmp_path, api):
+    """The real N-rank path of bench.py at world size 2 - self-launched ranks, per-rank stick streams, the step kernels
+    (api=step) or the k-step kernel writing one mask row per step into the bucket (api=rollout: done_bits_stride), the
+    bucketed asynchronous done-mask all-gather with its FLUSH of a partly filled last bucket, MAX over ranks, one JSON
+    line - with both ranks on GPU 0 over gloo (RCCL refuses two ranks on one device; the driver's multi-GPU run uses
+    RCCL).  The ceiling sits 0.5 mm above the start height with auto-reset on, so done bits ARE set on most steps
+    (with a 100 m ceiling every mask was zero and a kernel that never wrote the rows would have passed), and
+    warm-up + steps = 45 is not a multiple of the 16-step bucket, so the last bucket travels through flush() with 13
+    rows.  Every rank's final state and the gathered masks must equal a single-process run of the same shards."""
     import json
     import os
     import subprocess
     import sys
     from conftest import REPO
-    n, steps, warm, ring = 4096, 40, 8, 8
+    n, steps, warm, ring, ceiling = 4096, 37, 8, 8, 10.0005
     env = {k: v for k, v in os.environ.items() if k not in ("RANK", "LOCAL_RANK", "WORLD_SIZE", "MASTER_ADDR", "MASTER_PORT", "LOCAL_WORLD_SIZE")}
     r = subprocess.run([sys.executable, os.path.join(REPO, "bench.py"), "--gpus", "2", "--rehearse-on-one-gpu", "--steps", str(steps),
                         "--warmup", str(warm), "--drones-per-gpu", str(n), "--ring", str(ring), "--preheat-s", "0", "--no-cpu-baseline",
-                        "--dump-gathered", str(tmp_path)], capture_output=True, text=True, timeout=600, env=env)
+                        "--ceiling", str(ceiling), "--api", api, "--dump-gathered", str(tmp_path)],
+                       capture_output=True, text=True, timeout=600, env=env)
     assert r.returncode == 0, r.stderr[-3000:]
     lines = [ln for ln in r.stdout.splitlines() if ln.strip()]
     assert len(lines) == 1, lines
     out = json.loads(lines[0])
     assert out["n_gpus"] == 2 and out["steps"] == steps and out["data"].startswith("rehearsal")
     assert out["config"]["global_drones"] == 2 * n and "allgather(done_bits x16 steps)" in out["config"]["parallelism"]
+    assert out["collective"]["world_seen"] == 2 and out["collective"]["backend"] == "gloo"
     gathered = np.load(tmp_path / "gathered_last_bucket.npy")              # [world, rows, words]
     total, block = warm + steps, 16
     first = (total - 1) // block * block
-    assert gathered.shape == (2, total - first, n // 64)
-    p = load_params(fps=1000, ceiling=100.0)
+    assert total % block != 0 and gathered.shape == (2, total - first, n // 64), "the last bucket is a flushed, partly filled one"
+    assert gathered.any(), "the scenario must set done bits"
+    p = load_params(fps=1000, ceiling=ceiling)
     for rank in range(2):
         acts = sticks.ema_noise_device(ring, n, DEV, seed=1234 + rank)
         ref = _drone_batch(p, n, auto_reset=True, with_accel=False, with_done_bits=True)
         ref.reset()
+        set_rows = 0
         for t in range(total):
             ref.step(acts[t % ring], return_imu=False)
             if t >= first:
-                assert np.array_equal(ref.done_bits.cpu().numpy(), gathered[rank, t - first]), f"rank {rank} step {t}"
+                bits = ref.done_bits.cpu().numpy()
+                set_rows += int(bits.any())
+                assert np.array_equal(bits, gathered[rank, t - first]), f"rank {rank} step {t}"
+        assert set_rows >= 3, "several of the flushed rows must carry set bits"
         assert np.array_equal(ref.state.cpu().numpy().view(np.uint32), np.load(tmp_path / f"state_rank{rank}.npy").view(np.uint32))

@@ -299,6 +299,32 @@ def test_config1_10k_steps_with_kahan_compensation(params_1k):
     assert err["pos_rel"] < 1e-6 and err["vel_rel"] < 1e-6 and err["quat_abs"] < 1e-6, err
 
 
+def test_config0_default_fps60_10k_steps_with_kahan_compensation(params_60):
+    """BASELINE configs[0] to the letter (fps = 60, zero sticks, 10 000 steps; capture G1 @ fps 60) in the kernel's fp32
+    arithmetic: 0.34 m increments into a coordinate that reaches 3.4 km.  Plain fp32 sums drift; the Kahan rows hold
+    the north-star bar against the reference capture at every 100th step."""
+    g = load_golden("g1_zero_10k_fps60")
+    plain = lane_model.initial_state(params_60, 1)
+    lane_model.run(params_60, plain, np.zeros((1, 4), np.float32), steps=10000)
+    ref = np.concatenate([g["state"][:, -1], g["R"][:, -1].reshape(1, 9), g["prev_rates"][:, -1], g["prev_thrust"][:, -1:]], axis=1)
+    assert 1e-6 < soa_vs_oracle(plain, ref, 1)["pos_rel"] < 1e-3, "plain fp32 accumulation: documented drift"
+    s = lane_model.initial_state(params_60, 1)
+    comp = np.zeros((6, s.shape[1]), dtype=np.float32)
+    lane_model.set_pos_comp(comp)
+    worst = 0.0
+    try:
+        prev = 0
+        for k, t in enumerate(np.asarray(g["snap_steps"]).reshape(-1)):
+            lane_model.run(params_60, s, np.zeros((1, 4), np.float32), steps=int(t) - prev)
+            prev = int(t)
+            ref = np.concatenate([g["state"][:, k], g["R"][:, k].reshape(1, 9), g["prev_rates"][:, k], g["prev_thrust"][:, k:k + 1]], axis=1)
+            err = soa_vs_oracle(s, ref, 1)
+            worst = max(worst, err["pos_rel"], err["pos_comp"], err["vel_rel"], err["quat_abs"])
+    finally:
+        lane_model.set_pos_comp(None)
+    assert worst < 1e-6, worst
+
+
 def test_guidance_override_fp32(params_1k):
     """The kernel's fp32 arithmetic for Drone.step(..., rotation_matrix=, thrust_force=) (matrix -> quaternion by
     Shepperd's method, then the usual step) against the reference capture G13, every step of every case."""

@@ -54,6 +54,17 @@ def test_default_fps60(params_60):
     _replay_drone(params_60, load_golden("g1b_fps60_sin"))
 
 
+def test_config0_to_the_letter_default_fps60_zero_sticks_10k(params_60):
+    """BASELINE configs[0] as worded: 1 drone, params.yaml defaults (fps = 60, /root/reference/config/params.yaml:2),
+    10 000 steps of zero stick input - 166.7 s of flight, the drone climbs to 3.4 km (capture G1 @ fps 60)."""
+    g = load_golden("g1_zero_10k_fps60")
+    s, done_all, _ = _replay_drone(params_60, g)
+    assert abs(float(g["dt"]) - 1 / 60) < 1e-15 and not done_all.any()
+    np.testing.assert_allclose(s[0, 0:3], [2.64701726, 0, 3424.66753], rtol=2e-9)
+    np.testing.assert_allclose(s[0, 5], 20.5456781, rtol=2e-9)          # terminal climb rate: thrust - weight = drag
+    np.testing.assert_allclose(s[0, 6:15].reshape(3, 3), np.eye(3), atol=1e-15)
+
+
 def test_ground_contact_done_sequence(params_1k):
     g = load_golden("g6_ground")
     _, done_all, _ = _replay_drone(params_1k, g)

@@ -66,6 +66,50 @@ def test_streams_depend_only_on_global_id_and_step():
     assert not np.array_equal(other, whole[:, :64])
 
 
+def test_step_index_is_64_bit_and_does_not_wrap():
+    """The Philox counter carries the step index in words 2 AND 3 (ABI 4): the stream continues across 2^32 steps
+    (5.5 h at the k-step kernel's rate) instead of repeating, and is unchanged below 2^32 (ABI <= 3 streams)."""
+    p = load_params(fps=1000)
+    n, seed, off = 96, 0xfeed_f00d_1234, 7
+    ids = off + np.arange(n, dtype=np.uint64)
+    edge = (1 << 32) - 3
+    # the integer generator itself: counter word 3 = high word of the step
+    for step in (edge + 2, 1 << 32, (1 << 32) + 5, (123 << 32) | 77):
+        want = philox.philox4x32_10(np.array([[off & 0xFFFFFFFF, off >> 32, step & 0xFFFFFFFF, step >> 32]], dtype=np.uint32),
+                                    np.array([[seed & 0xFFFFFFFF, seed >> 32]], dtype=np.uint32))[0]
+        assert lane_model.philox([off & 0xFFFFFFFF, off >> 32, step & 0xFFFFFFFF, step >> 32], [seed & 0xFFFFFFFF, seed >> 32]) == [int(x) for x in want]
+    # six steps across the boundary: host build of the kernel's generator vs the float64 restatement with a 64-bit step
+    across, ns = lane_model.stick_noise(p, n, 6, noise_seed=seed, drone_id_offset=off, step0=edge)
+    ref, ref_s = philox.ema_sticks(seed, ids, 6, step0=edge)
+    assert np.abs(across - ref).max() < 3e-6 and np.abs(ns[:, :n].T - ref_s).max() < 3e-6
+    # a 32-bit counter would have wrapped: after steps 2^32-3 .. 2^32-1 it replayed steps 0, 1, 2 of the stream
+    head, ns3 = lane_model.stick_noise(p, n, 3, noise_seed=seed, drone_id_offset=off, step0=edge)
+    wrapped, _ = lane_model.stick_noise(p, n, 3, noise_seed=seed, drone_id_offset=off, step0=0, ns=ns3.copy())
+    assert np.array_equal(head, across[:3]) and not np.array_equal(wrapped, across[3:])
+    # resuming in the middle of the crossing with the saved EMA state continues the same stream bit for bit
+    a, ns_a = lane_model.stick_noise(p, n, 2, noise_seed=seed, drone_id_offset=off, step0=edge)
+    b, _ = lane_model.stick_noise(p, n, 4, noise_seed=seed, drone_id_offset=off, step0=edge + 2, ns=ns_a)
+    assert np.array_equal(np.concatenate([a, b]), across)
+    # the stochastic-rounding seed: base + step below 2^32 (= ABI <= 3), high word folded in beyond
+    assert lane_model.round_seed(11, 5) == 16 and lane_model.round_seed(0xFFFFFFFF, 2) == 1
+    assert lane_model.round_seed(11, (1 << 32) + 5) == (16 + 0x9e3779b1) & 0xFFFFFFFF
+    assert lane_model.round_seed(11, (1 << 32) + 5) != lane_model.round_seed(11, 5)
+
+
+def test_reduced_sincos_without_libm():
+    """fpv_sincos_reduced (big-angle step, fp32 Racer, reset kernel): Cody-Waite by pi/2 + the short polynomials, the
+    same instructions on the host and on gfx950.  Against float64 over the half-angles a step can produce."""
+    rng = np.random.default_rng(3)
+    x = np.concatenate([rng.uniform(-4, 4, 20000), rng.uniform(-60, 60, 20000), rng.uniform(-1e3, 1e3, 5000),
+                        np.arange(-8, 9) * (np.pi / 4), np.arange(-8, 9) * (np.pi / 2), [0.0, 1e-8, -1e-8]]).astype(np.float32)
+    s, c = lane_model.sincos_reduced(x)
+    x64 = x.astype(np.float64)
+    # the input is exact fp32; the reduction adds <= ulp(r) ~ 6e-8 to the 3e-9 of the polynomials
+    assert np.abs(s - np.sin(x64)).max() < 1.5e-7, np.abs(s - np.sin(x64)).max()
+    assert np.abs(c - np.cos(x64)).max() < 1.5e-7, np.abs(c - np.cos(x64)).max()
+    assert np.all(np.abs(s * s + c * c - 1) < 4e-7)
+
+
 def test_noise_added_to_policy_action_and_clipped():
     p = load_params(fps=1000).replace(noise_gain=2.0)
     base = np.full((30, 16, 4), 0.9, dtype=np.float32)
@@ -118,3 +162,48 @@ def test_kernel_stick_noise_vs_references():
     env3.rollout(None, steps=5)
     with pytest.raises(ValueError):
         DroneBatch(p, 8, device="cuda:0").step(None)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("n", [64, 333])
+def test_kernel_step_index_crosses_2_to_the_32(n):
+    """set the handle's counter to 2^32 - 3, run 6 steps single-step and fused (the k-step kernel adds t to
+    a 64-bit base in SGPRs): both equal the host build of the generator bit for bit, and differ from what a wrapping
+    32-bit counter would have produced.  Also the checkpoint round trip of a counter beyond 2^32."""
+    import torch
+    if not torch.cuda.is_available():
+        pytest.skip("needs a GPU: the stepper has no CPU path")
+    from fpyv_amd.env import DroneBatch
+    p = load_params(fps=1000)
+    seed, off, edge = 0xabcdef12345, 1000, (1 << 32) - 3
+    host, host_ns = lane_model.stick_noise(p, n, 6, noise_seed=seed, drone_id_offset=off, step0=edge)
+    kw = dict(device="cuda:0", stick_noise=True, noise_seed=seed, drone_id_offset=off, with_action_out=True, with_accel=False)
+    single = DroneBatch(p, n, **kw)
+    single.reset(); single.set_step_counter(edge)
+    got = np.zeros((6, n, 4), dtype=np.float32)
+    for t in range(6):
+        single.step(None, return_imu=False)
+        got[t] = single.action_out.cpu().numpy()
+    assert np.array_equal(got, host)
+    assert single.step_counter() == edge + 6 == single.state_dict()["step_counter"] and single.step_counter() > (1 << 32)
+    fused = DroneBatch(p, n, **kw)
+    fused.reset(); fused.set_step_counter(edge)
+    fused.rollout(None, steps=6)
+    torch.cuda.synchronize()
+    assert torch.equal(fused.state, single.state) and torch.equal(fused.noise_state, single.noise_state)
+    assert np.array_equal(fused.action_out.cpu().numpy(), host[-1])
+    assert np.array_equal(fused.noise_state[:, :n].cpu().numpy(), host_ns[:, :n])
+    # what ABI <= 3 did: the counter wrapped, so steps 3..5 replayed steps 0..2 of the stream
+    wrapped = DroneBatch(p, n, **kw)
+    wrapped.reset(); wrapped.set_step_counter(0)
+    wrapped.noise_state.copy_(torch.from_numpy(lane_model.stick_noise(p, n, 3, noise_seed=seed, drone_id_offset=off, step0=edge)[1]).to("cuda:0"))
+    wrapped.rollout(None, steps=3)
+    assert not np.array_equal(wrapped.action_out.cpu().numpy(), host[-1])
+    # resume from a checkpoint taken beyond 2^32
+    ck = single.state_dict()
+    cont = DroneBatch(p, n, **kw)
+    cont.reset(); cont.load_state_dict(ck)
+    cont.rollout(None, steps=4); single.rollout(None, steps=4)
+    assert torch.equal(cont.state, single.state) and cont.step_counter() == edge + 10
+    with pytest.raises(ValueError):
+        cont.set_step_counter(1 << 64)

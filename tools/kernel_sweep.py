@@ -1,7 +1,7 @@
 #!/usr/bin/env python3
-"""Interleaved A/B timing of launch geometries (drones per lane) and host paths in ONE process
-(cdna_hip_programming.md 5.4 rule 24).  Prints median / min microseconds per launch and the
-algorithmic-bytes bandwidth it implies."""
+"""Interleaved A/B timing of the kernel variants and host paths in ONE process (cdna_hip_programming.md 5.4 rule 24).
+Prints median / min microseconds per step and the algorithmic-bytes bandwidth it implies.  (Rounds 1-2 also swept
+launch geometries here - 2 / 4 drones per lane, 256-thread workgroups; they lost everywhere and are no longer built.)"""
 import argparse
 import json
 import os
@@ -21,8 +21,6 @@ def main():
     ap.add_argument("--launches", type=int, default=200)
     ap.add_argument("--rounds", type=int, default=7)
     ap.add_argument("--ring", type=int, default=32)
-    ap.add_argument("--geom", type=str, nargs="*", default=["1x128", "1x256", "2x128", "4x128"],
-                    help="<drones per lane>x<threads per workgroup>")
     ap.add_argument("--fp16", action="store_true", help="also time the fp16-storage kernel (config 4, 89 B/env-step)")
     ap.add_argument("--aos", action="store_true", help="also time the step with the [n,16] AoS observation head")
     ap.add_argument("--noise", action="store_true", help="also time pure in-kernel noise sticks (no action read)")
@@ -40,34 +38,33 @@ def main():
     # ONE state buffer for every geometry: timings depend on buffer placement
     shared = DroneBatch(p, a.n, device=dev, with_accel=False)
     shared.reset()
-    for g in a.geom:
-        envs[g] = shared
+    a.geom = ["f32"]
+    envs["f32"] = shared
     if a.fp16:
         e16 = DroneBatch(p, a.n, device=dev, with_accel=False, fp16_state=True)
         e16.reset()
-        for g in ("h1x128", "h1x256"):                          # fp16 storage (half2 pair rows) x block
-            envs[g] = e16
-        a.geom = list(a.geom) + ["h1x128", "h1x256"]
+        envs["h"] = e16                                         # fp16 storage (half2 pair rows)
+        a.geom = list(a.geom) + ["h"]
     if a.aos:
         ea = DroneBatch(p, a.n, device=dev, with_accel=False, with_obs_aos=True)
         ea.reset()
-        envs["aos1x128"] = envs["aos1x256"] = ea
-        a.geom = list(a.geom) + ["aos1x128", "aos1x256"]
+        envs["aos"] = ea
+        a.geom = list(a.geom) + ["aos"]
     if a.noise:
         en = DroneBatch(p, a.n, device=dev, with_accel=False, stick_noise=True, noise_seed=1)
         en.reset()
-        envs["noise1x128"] = en
-        a.geom = list(a.geom) + ["noise1x128"]
+        envs["noise"] = en
+        a.geom = list(a.geom) + ["noise"]
     if a.extras:
         from fpyv_amd.objects import Cylinder, Ground, Target
         ek = DroneBatch(p, a.n, device=dev, with_accel=False, kahan_position=True)
         ek.reset()
-        envs["kahan1x128"] = ek
+        envs["kahan"] = ek
         eo = DroneBatch(p, a.n, device=dev, with_accel=False)
         eo.reset()
         world = [Target([0, -6, 3], 0.8), Cylinder([3, 0, 0], 1.0, 5.0), Cylinder([-2, 2.5, 0], 0.6, 1.5), Ground()]
-        envs["obj1x128"] = eo
-        a.geom = list(a.geom) + ["kahan1x128", "obj1x128"]
+        envs["obj"] = eo
+        a.geom = list(a.geom) + ["kahan", "obj"]
     if a.racer:
         import numpy as np
         pid = np.array([[0.004, 0.02, 1e-6], [0.003, 0.01, 2e-6], [0.002, 0.005, 0.0]])
@@ -77,9 +74,8 @@ def main():
             rp = p.replace(**dict(dict(mode=1, racer_pid=pid, ceiling=50.0), **kw))
             er = RacerBatch(rp, a.n, device=dev, auto_reset=True)
             er.reset()
-            for blk in ("1x128", "1x256"):
-                envs[tag + blk] = er
-                a.geom = list(a.geom) + [tag + blk]
+            envs[tag] = er
+            a.geom = list(a.geom) + [tag]
     if a.ovr:
         eg = DroneBatch(p, a.n, device=dev, with_accel=False)
         eg.reset()
@@ -88,21 +84,19 @@ def main():
         rot_over = torch.stack([ang.cos(), zero, ang.sin(), zero, one, zero, -ang.sin(), zero, ang.cos()], dim=1).contiguous()   # Ry
         thrust_over = torch.full((a.n,), 7.4, device=dev)
         eg._buf.rotation_override, eg._buf.thrust_override = rot_over.data_ptr(), thrust_over.data_ptr()
-        envs["ovr1x128"] = eg
-        a.geom = list(a.geom) + ["ovr1x128"]
+        envs["ovr"] = eg
+        a.geom = list(a.geom) + ["ovr"]
     variants = [(g, api) for g in a.geom for api in ("rollout", "step") if not (g.startswith("ovr") and api == "rollout")]
     if a.graph:
-        variants += [(g, "graph") for g in a.geom if g[0].isdigit()]
+        variants += [(g, "graph") for g in a.geom if g == "f32"]
     if a.fused:
-        variants += [(g, "fused") for g in a.geom if g.endswith("1x128") and not g.startswith("aos")]
+        variants += [(g, "fused") for g in a.geom if g not in ("aos", "ovr")]
     times = {v: [] for v in variants}
     ev0, ev1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
     for r in range(a.rounds + 1):
         for v in variants:
             d, api = v
             e = envs[d]
-            e.set_tuning(*[int(x) for x in d.replace("aos", "").replace("noise", "").replace("kahan", "").replace("obj", "")
-                           .replace("racerWC", "").replace("racerW", "").replace("racerD", "").replace("ovr", "").lstrip("h").split("x")])
             torch.cuda.synchronize()
             ev0.record()
             done = 0

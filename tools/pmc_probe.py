@@ -19,12 +19,9 @@ ap.add_argument("--n", type=int, default=1 << 20)
 ap.add_argument("--launches", type=int, default=64)
 ap.add_argument("--ring", type=int, default=32)
 ap.add_argument("--calib-floats", type=int, default=1 << 27)     # 512 MiB read + 512 MiB written
-ap.add_argument("--dpl", type=int, default=0)
 a = ap.parse_args()
 dev = torch.device("cuda:0")
 env = DroneBatch(load_params(fps=1000), a.n, device=dev, with_accel=False)
-if a.dpl:
-    env.set_tuning(a.dpl)
 env.reset()
 acts = sticks.ema_noise_device(a.ring, a.n, dev)
 done = 0
