@@ -288,27 +288,56 @@ __global__ __launch_bounds__(kStepBlock) FPV_EXP_STEP_ATTR void fpv_drone_step_k
     }
     const FpvStepOut o = fpv_drone_step_lane<OBJ>(K, s, a.x, a.y, a.z, a.w, B.wx, B.wy, B.wz, &B.objs,
                                                   KAHAN ? kc : nullptr, OVR ? ro : nullptr, to);
+    // OBJ: the store addresses are formed only now - the 14 row-address pairs the compiler would otherwise carry from
+    // the loads to the stores (28 VGPRs) come on top of the object pass's own registers (102 VGPRs, 4 waves per SIMD);
+    // the plain kernel is faster WITH the carried addresses (profiles/r02_exp_state_cache_policy.log) and keeps them
+    uint32_t j = i;
+    if (OBJ) FPV_KEEP_HERE(j);
     if (KAHAN) {
         const bool rst = (K.flags & FPV_FLAG_AUTO_RESET) && o.done;
 #pragma unroll
-        for (int k = 0; k < 6; ++k) row_at(ROW(B.pos_comp, k, B.ld), i) = rst ? 0.0f : kc[k];
+        for (int k = 0; k < 6; ++k) row_at(ROW(B.pos_comp, k, B.ld), j) = rst ? 0.0f : kc[k];
     }
     if (B.accel) {
-        row_at(ROW(B.accel, 0, B.ld), i) = o.ax; row_at(ROW(B.accel, 1, B.ld), i) = o.ay; row_at(ROW(B.accel, 2, B.ld), i) = o.az;
+        row_at(ROW(B.accel, 0, B.ld), j) = o.ax; row_at(ROW(B.accel, 1, B.ld), j) = o.ay; row_at(ROW(B.accel, 2, B.ld), j) = o.az;
     }
     if ((K.flags & FPV_FLAG_AUTO_RESET) && o.done) fpv_drone_reset_lane(K, s);
-    st_drone(B.state, B.ld, i, s);
-    emit_outputs(B, i, true, o.reward, o.done);
+    st_drone(B.state, B.ld, j, s);
+    emit_outputs(B, j, true, o.reward, o.done);
+}
+
+// ---- k-step kernels: ONE kernel parameter, so that offsets into the kernel-argument segment are offsetof() ----
+struct FpvRollArgs { FpvK K; FpvBufD B; int64_t n; FpvRoll R; };
+typedef const __attribute__((address_space(4))) FpvRollArgs* FpvArgsPtr;
+
+// A fresh, opaque view of the kernel arguments.  Every field of FpvRollArgs is a scalar load from the kernarg segment;
+// the compiler issues all of them at the top of the kernel and keeps the values in SGPRs for as long as anything below
+// uses them - the 14 row addresses of the final state stores, the reset pose, the goal, the episode buffers ... lived
+// in SGPRs ACROSS the k-step loop, the kernel sat at the 102-SGPR limit (7 waves per SIMD) and spilled 40-105 of them
+// into VGPR lanes (round 2; tools/kernel_resources.py had been hiding it).  Loads through the pointer returned here
+// cannot be merged with earlier loads of the same field, nor hoisted above this point: what is needed only after the
+// loop (or only in the rare reset branch) is loaded there.
+__device__ __forceinline__ const FpvRollArgs& fpv_args_again()
+{
+    FpvArgsPtr p = (FpvArgsPtr)__builtin_amdgcn_kernarg_segment_ptr();
+    asm volatile("" : "+s"(p));
+    return *(const FpvRollArgs*)p;
 }
 
 // k steps of Drone.step in ONE launch (fpv_step_n): the loop `for i in range(time_steps): drone.step(...)`
 // of src/core/simulator.py:83-156 for pre-computed or in-kernel-generated sticks.  The lane keeps its
 // drone (and the noise / Kahan rows) in registers for all k steps; step t+1's action is in flight while
 // step t computes; reward/done leave per step only when asked to.  Per env-step this moves
-// 16 (action) + 5 (reward, done; optional) + 112/k bytes instead of 133, so for k >~ 8 the kernel is
-// bound by the fp32 vector ALUs (~400 instructions per env-step), not by HBM.  The arithmetic per step
-// is the single-step kernel's lane function, called in the same order: results are bit-identical to k
-// fpv_step launches.
+// 16 (action) + (112 + 5)/k bytes instead of 133, so for k >~ 8 the kernel is bound by the fp32 vector ALUs
+// (~190 instructions per env-step), not by HBM.  The arithmetic per step is the single-step kernel's lane function,
+// called in the same order: results are bit-identical to k fpv_step launches.
+//
+// Three sections, each with its own view of the arguments (fpv_args_again):
+//   1. the QUIET steps - a launch whose outputs leave only after the last step (no per-step stride, no episode
+//      bookkeeping) runs its first k-1 steps in a loop with no output code and only the ~35 uniforms the physics
+//      needs; the reset pose is loaded inside the (rare) reset branch;
+//   2. the remaining steps - the last one, or all of them when reward/done leave per step or episodes are tracked;
+//   3. the stores.
 // SQ: launched only for the X frame without the ground-spring flag and without objects (choose_rollout_kernel):
 // the quiet steps use the two-height ground flag (fpv_drone_step_lane<.., SQ = true>).
 #ifdef FPV_EXP_ROLL_WAVES
@@ -316,78 +345,116 @@ __global__ __launch_bounds__(kStepBlock) FPV_EXP_STEP_ATTR void fpv_drone_step_k
 #else
 #define FPV_EXP_ROLL_ATTR
 #endif
+#ifndef FPV_EXP_QUIET_UNROLL
+#define FPV_EXP_QUIET_UNROLL 1
+#endif
 template <bool NOISE, bool OBJ, bool KAHAN, bool SQ = false>
-__global__ __launch_bounds__(kStepBlock) FPV_EXP_ROLL_ATTR void fpv_drone_rollout_kernel(const FpvK K, const FpvBufD B, const int64_t n, const FpvRoll R)
+__global__ __launch_bounds__(kStepBlock) FPV_EXP_ROLL_ATTR void fpv_drone_rollout_kernel(const FpvRollArgs A)
 {
     static_assert(!(SQ && OBJ), "the two-height ground flag does not feed the object pass");
     const uint32_t i = blockIdx.x * (uint32_t)kStepBlock + threadIdx.x;
-    if (i >= n) return;
+    if (i >= A.n) return;
     FpvDroneState s;
-    const bool has_action = !NOISE || B.action;
-    const float* ap = reinterpret_cast<const float*>(B.action);
-    float4 a_next = has_action ? ld_action(reinterpret_cast<const float4*>(ap), i) : make_float4(0.f, 0.f, 0.f, 0.f);   // rows only (fpv_step_n)
-    ld_drone(B.state, B.ld, i, s);
+    const int k = A.R.k;
+    const bool has_action = !NOISE || A.B.action;
+    float4 a_next = has_action ? ld_action(A.B.action, i) : make_float4(0.f, 0.f, 0.f, 0.f);     // rows only (fpv_step_n)
+    ld_drone(A.B.state, A.B.ld, i, s);
     float ns[4] = {0.f, 0.f, 0.f, 0.f}, kc[6] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
     if (NOISE) {
 #pragma unroll
-        for (int k = 0; k < 4; ++k) ns[k] = row_at(ROW(B.noise_state, k, B.ld), i);
+        for (int c = 0; c < 4; ++c) ns[c] = row_at(ROW(A.B.noise_state, c, A.B.ld), i);
     }
     if (KAHAN) {
 #pragma unroll
-        for (int k = 0; k < 6; ++k) kc[k] = row_at(ROW(B.pos_comp, k, B.ld), i);
+        for (int c = 0; c < 6; ++c) kc[c] = row_at(ROW(A.B.pos_comp, c, A.B.ld), i);
     }
-    RollOut out(B, R, i, true);
-    FpvStepOut o;
-    o.done = false; o.reward = 0.0f; o.ax = o.ay = o.az = 0.0f;
-    float av[4] = {0.f, 0.f, 0.f, 0.f};
     fpv_settle(s.px); fpv_settle(s.py); fpv_settle(s.pz); fpv_settle(s.vx); fpv_settle(s.vy); fpv_settle(s.vz);
     fpv_settle(s.q.w); fpv_settle(s.q.x); fpv_settle(s.q.y); fpv_settle(s.q.z);
     fpv_settle(s.rx); fpv_settle(s.ry); fpv_settle(s.rz); fpv_settle(s.thrust);
     if (NOISE) { fpv_settle(ns[0]); fpv_settle(ns[1]); fpv_settle(ns[2]); fpv_settle(ns[3]); }
-    if (KAHAN) { for (int k = 0; k < 6; ++k) fpv_settle(kc[k]); }
-    if (out.track) { fpv_settle(out.ep_r); fpv_settle(__int_as_float(out.ep_l)); }
-    // reward / R_new @ acc are computed only on the steps that store or accumulate them.  A launch whose outputs
-    // leave only after the last step (no per-step stride, no episode bookkeeping) runs its first k-1 steps in a
-    // loop of their own that knows this at compile time - no per-step test, no output code in the loop
-    auto one_step = [&](int t, auto quiet_c) {
+    if (KAHAN) { for (int c = 0; c < 6; ++c) fpv_settle(kc[c]); }
+    float av[4] = {0.f, 0.f, 0.f, 0.f};
+
+    // one step on the view V of the arguments.  QUIET steps take their next action unconditionally (there is always
+    // a step t + 1 behind a quiet one; a held action - stride 0 - is simply read again: 16 bytes from the cache)
+    auto one_step = [&](const FpvRollArgs& V, const float* ap_next, bool prefetch, int t, auto quiet_c) -> FpvStepOut {
         constexpr bool QUIET = decltype(quiet_c)::value;
         av[0] = a_next.x; av[1] = a_next.y; av[2] = a_next.z; av[3] = a_next.w;
-        if (has_action && R.action_stride && t + 1 < R.k) {
-            ap += R.action_stride;
-            a_next = ld_action(reinterpret_cast<const float4*>(ap), i);
+        if ((!NOISE || has_action) && (QUIET || prefetch)) a_next = ld_action(reinterpret_cast<const float4*>(ap_next), i);
+        if (NOISE) {
+            // the ten Philox round keys are uniform and loop-invariant: left alone the compiler keeps all twenty words
+            // in SGPRs for the whole loop; seen through an opaque copy of the seed they are ten scalar adds per step
+            FpvNoiseK N = V.K.noise;
+            asm volatile("" : "+s"(N.seed_lo), "+s"(N.seed_hi));
+            fpv_stick_noise(N, V.B.step + (uint64_t)t, (uint64_t)i, ns, av);
         }
-        if (NOISE) fpv_stick_noise(K.noise, B.step + (uint64_t)t, (uint64_t)i, ns, av);
-        o = fpv_drone_step_lane<OBJ, !QUIET, SQ && QUIET>(K, s, av[0], av[1], av[2], av[3], B.wx, B.wy, B.wz, &B.objs, KAHAN ? kc : nullptr);
-        const bool rst = (K.flags & FPV_FLAG_AUTO_RESET) && o.done;
-        if (KAHAN && rst) {
+        FpvStepOut o = fpv_drone_step_lane<OBJ, !QUIET, SQ && QUIET>(V.K, s, av[0], av[1], av[2], av[3], V.B.wx, V.B.wy, V.B.wz,
+                                                                       &V.B.objs, KAHAN ? kc : nullptr);
+        if ((V.K.flags & FPV_FLAG_AUTO_RESET) && o.done) {
+            // rare (once per episode and lane): the reset pose comes through its own view, inside the branch
+            const FpvRollArgs& Z = fpv_args_again();
+            fpv_drone_reset_lane(Z.K, s);
+            if (KAHAN) {
 #pragma unroll
-            for (int k = 0; k < 6; ++k) kc[k] = 0.0f;
+                for (int c = 0; c < 6; ++c) kc[c] = 0.0f;
+            }
         }
-        if (rst) fpv_drone_reset_lane(K, s);
-        out.template step<QUIET>(i, t, o.reward, o.done);
+        return o;
     };
+
     int t = 0;
-    if (!out.track && R.out_stride == 0) {
-        for (; t < R.k - 1; ++t) one_step(t, std::true_type{});
+    if (A.B.ep_return == nullptr && A.R.out_stride == 0 && k > 1) {
+        // ---- 1. quiet steps: only the optional per-step done_bits row leaves the lane
+        const float* ap = reinterpret_cast<const float*>(A.B.action);
+        const int64_t astride = A.R.action_stride;
+        unsigned long long* bp = A.R.bits_stride ? A.B.done_bits : nullptr;
+        const int64_t bstride = A.R.bits_stride;
+#pragma unroll FPV_EXP_QUIET_UNROLL
+        for (; t < k - 1; ++t) {
+            ap += astride;
+            const FpvStepOut o = one_step(A, ap, true, t, std::true_type{});
+            if (bp) {
+                const unsigned long long mask = __ballot(o.done);
+                if ((threadIdx.x & 63) == 0) bp[i >> 6] = mask;
+                bp += bstride;
+            }
+        }
     }
-    for (; t < R.k; ++t) one_step(t, std::false_type{});
-    // the store addresses are formed only now: computed before the loop they would sit in ~30 VGPRs for all k steps
+    // ---- 2. the remaining steps, with every output the caller asked for
+    FpvStepOut o;
+    o.done = false; o.reward = 0.0f; o.ax = o.ay = o.az = 0.0f;
+    {
+        const FpvRollArgs& G = fpv_args_again();
+        RollOut out(G.B, G.R, i, true);
+        if (out.bp) out.bp += (int64_t)t * G.R.bits_stride;
+        const float* ap = reinterpret_cast<const float*>(G.B.action) + (int64_t)t * G.R.action_stride;
+        const int kk = G.R.k;
+        if (out.track) { fpv_settle(out.ep_r); fpv_settle(__int_as_float(out.ep_l)); }
+        for (; t < kk; ++t) {
+            ap += G.R.action_stride;
+            o = one_step(G, ap, G.R.action_stride != 0 && t + 1 < kk, t, std::false_type{});
+            out.template step<false>(i, t, o.reward, o.done);
+        }
+        out.finish(i);
+    }
+    // ---- 3. the stores: row addresses are formed only now (computed before the loops they would sit in ~30 registers
+    //         for all k steps)
+    const FpvRollArgs& E = fpv_args_again();
     uint32_t j = i;
     asm volatile("" : "+v"(j));
-    if (B.accel) {
-        row_at(ROW(B.accel, 0, B.ld), j) = o.ax; row_at(ROW(B.accel, 1, B.ld), j) = o.ay; row_at(ROW(B.accel, 2, B.ld), j) = o.az;
+    if (E.B.accel) {
+        row_at(ROW(E.B.accel, 0, E.B.ld), j) = o.ax; row_at(ROW(E.B.accel, 1, E.B.ld), j) = o.ay; row_at(ROW(E.B.accel, 2, E.B.ld), j) = o.az;
     }
-    st_drone(B.state, B.ld, j, s);
+    st_drone(E.B.state, E.B.ld, j, s);
     if (NOISE) {
 #pragma unroll
-        for (int k = 0; k < 4; ++k) row_at(ROW(B.noise_state, k, B.ld), j) = ns[k];
-        if (B.action_out) B.action_out[j] = make_float4(av[0], av[1], av[2], av[3]);
+        for (int c = 0; c < 4; ++c) row_at(ROW(E.B.noise_state, c, E.B.ld), j) = ns[c];
+        if (E.B.action_out) E.B.action_out[j] = make_float4(av[0], av[1], av[2], av[3]);
     }
     if (KAHAN) {
 #pragma unroll
-        for (int k = 0; k < 6; ++k) row_at(ROW(B.pos_comp, k, B.ld), j) = kc[k];
+        for (int c = 0; c < 6; ++c) row_at(ROW(E.B.pos_comp, c, E.B.ld), j) = kc[c];
     }
-    out.finish(j);
 }
 
 // Same step + an array-of-structures observation row per drone, obs_aos[i][16] =
@@ -511,8 +578,9 @@ __global__ __launch_bounds__(kStepBlock) void fpv_drone_step_h_kernel(const FpvK
 
 // k steps of the fp16-storage kernel in one launch: the state is rounded to binary16 and widened again
 // after EVERY step, in registers, exactly as k single-step launches would do through HBM.
-__global__ __launch_bounds__(kStepBlock) void fpv_drone_rollout_h_kernel(const FpvK K, const FpvBufD B, const int64_t n, const FpvRoll R)
+__global__ __launch_bounds__(kStepBlock) void fpv_drone_rollout_h_kernel(const FpvRollArgs A)
 {
+    const FpvK& K = A.K; const FpvBufD& B = A.B; const int64_t n = A.n; const FpvRoll& R = A.R;
     const uint32_t i = blockIdx.x * (uint32_t)kStepBlock + threadIdx.x;
     const bool live = i < n;
     uint32_t th = 0;
@@ -615,43 +683,70 @@ __global__ __launch_bounds__(kStepBlock) void fpv_racer_step_kernel(const FpvK K
     emit_outputs(B, i, true, reward, done);
 }
 
+// k steps of Racer.step in one launch; the three sections and their argument views are those of fpv_drone_rollout_kernel
+// (the as-written variant alone carries 45 double-precision uniforms: through one view they could not all stay in SGPRs
+// across the loop together with the pointers of the outputs and the final stores - 75-87 spilled SGPRs in round 2).
 template <bool WIDE, bool PIDV>
-__global__ __launch_bounds__(kStepBlock) void fpv_racer_rollout_kernel(const FpvK K, const FpvBufD B, const int64_t n, const FpvRoll R)
+__global__ __launch_bounds__(kStepBlock) void fpv_racer_rollout_kernel(const FpvRollArgs A)
 {
     const uint32_t i = blockIdx.x * (uint32_t)kStepBlock + threadIdx.x;
-    if (i >= n) return;
+    if (i >= A.n) return;
     FpvRacerState s;
-    ld_racer<WIDE, PIDV>(B.state, B.ld, i, s);
-    RollOut out(B, R, i, true);
-    const float* ap = reinterpret_cast<const float*>(B.action);
-    float4 a_next = ld_action(reinterpret_cast<const float4*>(ap), i);
+    ld_racer<WIDE, PIDV>(A.B.state, A.B.ld, i, s);
+    float4 a_next = ld_action(A.B.action, i);
+    const int k = A.R.k;
     fpv_settle(s.px); fpv_settle(s.py); fpv_settle(s.pz); fpv_settle(s.vx); fpv_settle(s.vy); fpv_settle(s.vz);
     fpv_settle(s.q.w); fpv_settle(s.q.x); fpv_settle(s.q.y); fpv_settle(s.q.z); fpv_settle(s.first);
 #pragma unroll
-    for (int k = 0; k < 3; ++k) {
-        fpv_settle(s.w[k]); fpv_settle(s.ierr[k]); fpv_settle(s.lerr[k]);
-        if (WIDE) { fpv_settle(s.wlo[k]); fpv_settle(s.ilo[k]); }
-        if (PIDV) fpv_settle(s.dflt[k]);
+    for (int c = 0; c < 3; ++c) {
+        fpv_settle(s.w[c]); fpv_settle(s.ierr[c]); fpv_settle(s.lerr[c]);
+        if (WIDE) { fpv_settle(s.wlo[c]); fpv_settle(s.ilo[c]); }
+        if (PIDV) fpv_settle(s.dflt[c]);
     }
-    if (out.track) { fpv_settle(out.ep_r); fpv_settle(__int_as_float(out.ep_l)); }
-    auto one_step = [&](int t, auto quiet_c) {                           // see fpv_drone_rollout_kernel
+    float reward = 0.0f;
+    bool done = false;
+    auto one_step = [&](const FpvRollArgs& V, const float* ap_next, bool prefetch, auto quiet_c) {
         constexpr bool QUIET = decltype(quiet_c)::value;
         const float4 a = a_next;
-        if (R.action_stride && t + 1 < R.k) { ap += R.action_stride; a_next = ld_action(reinterpret_cast<const float4*>(ap), i); }
-        const float reward = fpv_racer_step_lane<WIDE, PIDV ? 1 : 0, !QUIET>(K, s, a.x, a.y, a.z, a.w);
-        const bool done = !(fabsf(s.pz) <= K.ceiling);
-        if ((K.flags & FPV_FLAG_AUTO_RESET) && done) fpv_racer_reset_lane(s);
-        out.template step<QUIET>(i, t, reward, done);
+        if (QUIET || prefetch) a_next = ld_action(reinterpret_cast<const float4*>(ap_next), i);
+        reward = fpv_racer_step_lane<WIDE, PIDV ? 1 : 0, !QUIET>(V.K, s, a.x, a.y, a.z, a.w);
+        done = !(fabsf(s.pz) <= V.K.ceiling);              // the Racer has no ground; build-defined ceiling only
+        if ((V.K.flags & FPV_FLAG_AUTO_RESET) && done) fpv_racer_reset_lane(s);
     };
     int t = 0;
-    if (!out.track && R.out_stride == 0) {
-        for (; t < R.k - 1; ++t) one_step(t, std::true_type{});
+    if (A.B.ep_return == nullptr && A.R.out_stride == 0 && k > 1) {
+        const float* ap = reinterpret_cast<const float*>(A.B.action);
+        const int64_t astride = A.R.action_stride;
+        unsigned long long* bp = A.R.bits_stride ? A.B.done_bits : nullptr;
+        const int64_t bstride = A.R.bits_stride;
+        for (; t < k - 1; ++t) {
+            ap += astride;
+            one_step(A, ap, true, std::true_type{});
+            if (bp) {
+                const unsigned long long mask = __ballot(done);
+                if ((threadIdx.x & 63) == 0) bp[i >> 6] = mask;
+                bp += bstride;
+            }
+        }
     }
-    for (; t < R.k; ++t) one_step(t, std::false_type{});
-    uint32_t j = i;                                  // form the store addresses after the loop (VGPR pressure)
+    {
+        const FpvRollArgs& G = fpv_args_again();
+        RollOut out(G.B, G.R, i, true);
+        if (out.bp) out.bp += (int64_t)t * G.R.bits_stride;
+        const float* ap = reinterpret_cast<const float*>(G.B.action) + (int64_t)t * G.R.action_stride;
+        const int kk = G.R.k;
+        if (out.track) { fpv_settle(out.ep_r); fpv_settle(__int_as_float(out.ep_l)); }
+        for (; t < kk; ++t) {
+            ap += G.R.action_stride;
+            one_step(G, ap, G.R.action_stride != 0 && t + 1 < kk, std::false_type{});
+            out.template step<false>(i, t, reward, done);
+        }
+        out.finish(i);
+    }
+    const FpvRollArgs& E = fpv_args_again();
+    uint32_t j = i;                                  // form the store addresses after the loops (VGPR pressure)
     asm volatile("" : "+v"(j));
-    st_racer<WIDE, PIDV>(B.state, B.ld, j, s);
-    out.finish(j);
+    st_racer<WIDE, PIDV>(E.B.state, E.B.ld, j, s);
 }
 
 // Drone.reset (components.py:150-169): p, v, R = E(deg2rad(ypr)) with the triple consumed as
@@ -922,8 +1017,8 @@ StepKernel racer_kernel(bool wide, bool pidv)
                 : (pidv ? fpv_racer_step_kernel<false, true> : fpv_racer_step_kernel<false, false>);
 }
 
-// ---- k-step kernels (fpv_step_n): signature (FpvK, FpvBufD, int64_t, FpvRoll) ----
-typedef void (*RollKernel)(const FpvK, const FpvBufD, const int64_t, const FpvRoll);
+// ---- k-step kernels (fpv_step_n): one FpvRollArgs parameter ----
+typedef void (*RollKernel)(const FpvRollArgs);
 
 RollKernel drone_rollout_kernel(bool noise, bool obj, bool kahan, bool sq)
 {
@@ -1189,7 +1284,10 @@ int fpv_step_n(fpv_handle_t h, const fpv_buffers_t* b, int k, int64_t action_str
     R.k = k; R.pad = 0; R.action_stride = action_stride; R.out_stride = out_stride; R.bits_stride = b->done_bits_stride;
     const RollKernel f = choose_rollout_kernel(h, d);
     const unsigned grid = (unsigned)((h->n + kStepBlock - 1) / kStepBlock);
-    hipLaunchKernelGGL(f, dim3(grid), dim3(kStepBlock), 0, (hipStream_t)stream, h->K, d, h->n, R);
+    FpvRollArgs args;
+    memset(&args, 0, sizeof(args));
+    args.K = h->K; args.B = d; args.n = h->n; args.R = R;
+    hipLaunchKernelGGL(f, dim3(grid), dim3(kStepBlock), 0, (hipStream_t)stream, args);
     const hipError_t e = hipGetLastError();
     if (e != hipSuccess) return hip_fail(e, "k-step kernel launch");
     return FPV_OK;

@@ -16,7 +16,7 @@
 //
 // Rounding discipline: every a*b+c that matters is an explicit fmaf and the translation units are
 // built with -ffp-contract=off, so the host lane model and the gfx950 kernel agree bit for bit
-// (sqrtf and '/' are correctly rounded on both).
+// (fpv_sqrt_flushed and '/' are correctly rounded on both).
 #pragma once
 
 #include <math.h>
@@ -80,6 +80,36 @@ struct FpvK {
 
 struct FpvQuat { float w, x, y, z; };
 
+// np.clip(x, lo, hi) for lo <= hi.  On gfx950 ONE v_med3_f32 instead of v_max + v_min; identical for every input,
+// NaN included (v_med3 with a NaN operand returns the minimum of the others = lo, and fmaxf(NaN, lo) = lo too).
+FPV_HD float fpv_clamp(float x, float lo, float hi)
+{
+#if defined(__HIP_DEVICE_COMPILE__) && !defined(FPV_EXP_NO_MED3)
+    return __builtin_amdgcn_fmed3f(x, lo, hi);
+#else
+    return fminf(fmaxf(x, lo), hi);
+#endif
+}
+
+// Correctly rounded sqrt of x >= 0 with everything below the smallest normal float flushed to 0 (the arguments are
+// sums of squares of speeds / distances: 1e-19 m/s is nothing).  The host build calls sqrtf; the kernel issues
+// v_sqrt_f32 (1 ulp) and the compiler's own two-sided correction step, but not the x 2^32 pre-scaling, the un-scaling
+// and the zero / infinity class test that `sqrtf` carries for denormal arguments: 11 instructions instead of 16,
+// the same bits for every normal x, +0 and +inf.
+FPV_HD float fpv_sqrt_flushed(float x)
+{
+#if defined(__HIP_DEVICE_COMPILE__) && !defined(FPV_EXP_LIB_SQRT)
+    const float r = __builtin_amdgcn_sqrtf(x);
+    const float r_dn = __uint_as_float(__float_as_uint(r) - 1u), r_up = __uint_as_float(__float_as_uint(r) + 1u);
+    const float e_dn = fmaf(-r_dn, r, x), e_up = fmaf(-r_up, r, x);
+    float y = e_dn <= 0.0f ? r_dn : r;
+    y = e_up > 0.0f ? r_up : y;
+    return x < 1.17549435e-38f ? 0.0f : y;
+#else
+    return x < 1.17549435e-38f ? 0.0f : sqrtf(x);
+#endif
+}
+
 // sin and cos for |x| <= pi/4 (half-angles of one step's rotation).  Truncation error
 // < 3e-9 relative; no range reduction, no slow path.
 FPV_HD void fpv_sincos_small(float x, float* s, float* c)
@@ -138,7 +168,15 @@ FPV_HD void fpv_sincos3(uint32_t mode, float x0, float x1, float x2, float s[3],
     } else if (mode == FPV_ANGLE_SMALL) {
         fpv_sincos_small(x0, &s[0], &c[0]); fpv_sincos_small(x1, &s[1], &c[1]); fpv_sincos_small(x2, &s[2], &c[2]);
     } else {
-        fpv_sincos_reduced(x0, &s[0], &c[0]); fpv_sincos_reduced(x1, &s[1], &c[1]); fpv_sincos_reduced(x2, &s[2], &c[2]);
+        fpv_sincos_reduced(x0, &s[0], &c[0]);
+#if defined(__HIP_DEVICE_COMPILE__) && defined(FPV_EXP_SERIAL_REDUCED)
+        asm volatile("" : "+v"(x1) : "v"(s[0]), "v"(c[0]));      // experiment: one axis after the other (register pressure of the rare path)
+#endif
+        fpv_sincos_reduced(x1, &s[1], &c[1]);
+#if defined(__HIP_DEVICE_COMPILE__) && defined(FPV_EXP_SERIAL_REDUCED)
+        asm volatile("" : "+v"(x2) : "v"(s[1]), "v"(c[1]));
+#endif
+        fpv_sincos_reduced(x2, &s[2], &c[2]);
     }
 }
 
@@ -191,7 +229,7 @@ FPV_HD FpvQuat fpv_quat_from_rot(const float m[9])
     } else {
         q.w = m[3] - m[1]; q.x = m[2] + m[6]; q.y = m[5] + m[7]; q.z = 1.0f + m[8] - m[0] - m[4];
     }
-    const float inv = 1.0f / sqrtf(fmaf(q.w, q.w, fmaf(q.x, q.x, fmaf(q.y, q.y, q.z * q.z))));
+    const float inv = 1.0f / fpv_sqrt_flushed(fmaf(q.w, q.w, fmaf(q.x, q.x, fmaf(q.y, q.y, q.z * q.z))));
     q.w *= inv; q.x *= inv; q.y *= inv; q.z *= inv;
     return q;
 }
@@ -398,7 +436,7 @@ FPV_HD void fpv_normal4(uint32_t seed_lo, uint32_t seed_hi, uint32_t drone_lo, u
     const float u1 = ((float)(r[1] >> 8) + 0.5f) * 5.9604644775390625e-08f;
     const float u2 = ((float)(r[2] >> 8) + 0.5f) * 5.9604644775390625e-08f;
     const float u3 = ((float)(r[3] >> 8) + 0.5f) * 5.9604644775390625e-08f;
-    const float ra = sqrtf(-2.0f * fpv_log_normal_arg(u0)), rb = sqrtf(-2.0f * fpv_log_normal_arg(u2));
+    const float ra = fpv_sqrt_flushed(-2.0f * fpv_log_normal_arg(u0)), rb = fpv_sqrt_flushed(-2.0f * fpv_log_normal_arg(u2));
     float s, c;
     fpv_sincos_2pi(u1, &s, &c);
     z[0] = ra * c; z[1] = ra * s;
@@ -415,7 +453,7 @@ FPV_HD void fpv_stick_noise(const FpvNoiseK& N, uint64_t step, uint64_t local_id
 #pragma unroll
     for (int k = 0; k < 4; ++k) {
         ns[k] = fmaf(z[k], N.tau, ns[k] * N.omtau);
-        a[k] = fminf(fmaxf(fmaf(N.gain, ns[k], a[k]), -1.0f), 1.0f);
+        a[k] = fpv_clamp(fmaf(N.gain, ns[k], a[k]), -1.0f, 1.0f);
     }
 }
 
@@ -445,9 +483,20 @@ struct FpvObjects { int32_t count; FpvObject o[FPV_MAX_OBJECTS]; };
 #define FPV_WAVE_ANY(x) (x)
 #endif
 
-FPV_HD bool fpv_collide_objects(const FpvK& K, const FpvObjects& T, const float mx[4], const float my[4],
-                                const float mz[4], float cx, float cy, float cz, float vx, float vy, float vz,
-                                float acc[3])
+// "this value is produced here": stops the compiler from hoisting what is computed from it out of a rarely taken
+// branch (loop-invariant code motion would otherwise keep those results in registers on the fast path too)
+#if defined(__HIP_DEVICE_COMPILE__)
+#define FPV_KEEP_HERE(x) asm volatile("" : "+v"(x))
+#else
+#define FPV_KEEP_HERE(x) ((void)0)
+#endif
+
+// R: the pre-update attitude.  The twelve world coordinates of the motors are formed per object INSIDE the branch
+// that a wave takes only when one of its drones is near that object (same expressions, same bits as forming them
+// up front): on the culled fast path the kernel keeps the register budget of the plain step kernel (round 2 formed
+// them before the object loop: 102 VGPRs, 4 waves per SIMD, even when every object was culled).
+FPV_HD bool fpv_collide_objects(const FpvK& K, const FpvObjects& T, const FpvRot& R, float cx, float cy, float cz,
+                                float vx, float vy, float vz, float acc[3])
 {
     bool crashed = false;
     acc[0] = acc[1] = acc[2] = 0.0f;
@@ -465,6 +514,17 @@ FPV_HD bool fpv_collide_objects(const FpvK& K, const FpvObjects& T, const float 
             else near = fmaf(dx, dx, fmaf(dy, dy, dz * dz)) < rr * rr;
         }
         if (!FPV_WAVE_ANY(near)) continue;
+        float mx[4], my[4], mz[4];
+        {
+            float px = cx, py = cy, pz = cz;
+            FPV_KEEP_HERE(px); FPV_KEEP_HERE(py); FPV_KEEP_HERE(pz);
+#pragma unroll
+            for (int m = 0; m < 4; ++m) {
+                mx[m] = px + fmaf(K.motor_x[m], R.r00, K.motor_y[m] * R.r01);
+                my[m] = py + fmaf(K.motor_x[m], R.r10, K.motor_y[m] * R.r11);
+                mz[m] = pz + fmaf(K.motor_x[m], R.r20, K.motor_y[m] * R.r21);
+            }
+        }
         // distances of all four motors first (the crash test needs them all, components.py:203-206); the radial
         // length rr is kept, the NORMAL (a correctly rounded division per motor) is formed only for a motor that is
         // actually in contact - the same arithmetic in the same order, evaluated lazily
@@ -475,17 +535,17 @@ FPV_HD bool fpv_collide_objects(const FpvK& K, const FpvObjects& T, const float 
             if (ob.type == 0) {
                 dist[m] = mz[m]; rrm[m] = 1.0f;
             } else if (ob.type == 1) {
-                const float rr = sqrtf(fmaf(rx, rx, ry * ry));
+                const float rr = fpv_sqrt_flushed(fmaf(rx, rx, ry * ry));
                 const float d2 = rr - ob.radius;
                 const float top = ob.z + ob.height;
                 if (ob.z < mz[m] && mz[m] < top) dist[m] = d2;
                 else {
                     const float dh = fminf(fabsf(mz[m] - ob.z), fabsf(mz[m] - top));
-                    dist[m] = sqrtf(fmaf(d2, d2, dh * dh));
+                    dist[m] = fpv_sqrt_flushed(fmaf(d2, d2, dh * dh));
                 }
                 rrm[m] = rr;
             } else {
-                const float rr = sqrtf(fmaf(rx, rx, fmaf(ry, ry, rz * rz)));
+                const float rr = fpv_sqrt_flushed(fmaf(rx, rx, fmaf(ry, ry, rz * rz)));
                 dist[m] = rr - ob.radius;
                 rrm[m] = rr;
             }
@@ -530,9 +590,9 @@ FPV_HD FpvStepOut fpv_drone_step_lane(const FpvK& K, FpvDroneState& s, float a0,
                                       float* kahan = nullptr, const float* rot_over = nullptr, float thrust_over = 0.0f)
 {
     // (1)-(2) stick -> rate command (deg/s), clipped, low-passed          components.py:185-189
-    const float c0 = fminf(fmaxf(-a0 * K.max_rates, -K.max_rates), K.max_rates);
-    const float c1 = fminf(fmaxf(-a1 * K.max_rates, -K.max_rates), K.max_rates);
-    const float c2 = fminf(fmaxf(-a2 * K.max_rates, -K.max_rates), K.max_rates);
+    const float c0 = fpv_clamp(-a0 * K.max_rates, -K.max_rates, K.max_rates);
+    const float c1 = fpv_clamp(-a1 * K.max_rates, -K.max_rates, K.max_rates);
+    const float c2 = fpv_clamp(-a2 * K.max_rates, -K.max_rates, K.max_rates);
     s.rx = fmaf(c0, K.kr, s.rx * K.omkr);
     s.ry = fmaf(c1, K.kr, s.ry * K.omkr);
     s.rz = fmaf(c2, K.kr, s.rz * K.omkr);
@@ -553,7 +613,7 @@ FPV_HD FpvStepOut fpv_drone_step_lane(const FpvK& K, FpvDroneState& s, float a0,
 
     // (5) drag: F_b = -k (R^T v_s) |v_s|, back to world; wind is ADDED      kinematics.py:33-38
     const float ux = s.vx + wx, uy = s.vy + wy, uz = s.vz + wz;
-    const float speed = sqrtf(fmaf(ux, ux, fmaf(uy, uy, uz * uz)));
+    const float speed = fpv_sqrt_flushed(fmaf(ux, ux, fmaf(uy, uy, uz * uz)));
     const float bx = fmaf(R.r00, ux, fmaf(R.r10, uy, R.r20 * uz));
     const float by = fmaf(R.r01, ux, fmaf(R.r11, uy, R.r21 * uz));
     const float bz = fmaf(R.r02, ux, fmaf(R.r12, uy, R.r22 * uz));
@@ -597,14 +657,8 @@ FPV_HD FpvStepOut fpv_drone_step_lane(const FpvK& K, FpvDroneState& s, float a0,
         }
     }
     if (OBJ) {                                               // general object_list replaces the ground-only pass
-        float mxw[4], myw[4], mzw[4], ca[3];
-#pragma unroll
-        for (int m = 0; m < 4; ++m) {
-            mxw[m] = s.px + fmaf(K.motor_x[m], R.r00, K.motor_y[m] * R.r01);
-            myw[m] = s.py + fmaf(K.motor_x[m], R.r10, K.motor_y[m] * R.r11);
-            mzw[m] = s.pz + fmaf(K.motor_x[m], R.r20, K.motor_y[m] * R.r21);
-        }
-        const bool crashed = fpv_collide_objects(K, *objs, mxw, myw, mzw, s.px, s.py, s.pz, s.vx, s.vy, s.vz, ca);
+        float ca[3];
+        const bool crashed = fpv_collide_objects(K, *objs, R, s.px, s.py, s.pz, s.vx, s.vy, s.vz, ca);
         accx += ca[0]; accy += ca[1]; accz += ca[2];
         done = done || crashed;
     }
@@ -661,7 +715,7 @@ FPV_HD FpvStepOut fpv_drone_step_lane(const FpvK& K, FpvDroneState& s, float a0,
         o.ay = fmaf(Rn.r10, accx, fmaf(Rn.r11, accy, Rn.r12 * accz));
         o.az = fmaf(Rn.r20, accx, fmaf(Rn.r21, accy, Rn.r22 * accz));
         const float gx = s.px - K.goal[0], gy = s.py - K.goal[1], gz = s.pz - K.goal[2];
-        o.reward = -sqrtf(fmaf(gx, gx, fmaf(gy, gy, gz * gz)));
+        o.reward = -fpv_sqrt_flushed(fmaf(gx, gx, fmaf(gy, gy, gz * gz)));
     }
     o.done = done || !(fabsf(s.pz) <= K.ceiling);
     return o;
@@ -728,7 +782,7 @@ struct FpvRacerState {
 
 FPV_HD float fpv_fma_t(float a, float b, float c) { return fmaf(a, b, c); }
 FPV_HD double fpv_fma_t(double a, double b, double c) { return fma(a, b, c); }
-FPV_HD float fpv_clip_t(float x, float lo, float hi) { return fminf(fmaxf(x, lo), hi); }     // np.clip
+FPV_HD float fpv_clip_t(float x, float lo, float hi) { return fpv_clamp(x, lo, hi); }                // np.clip
 FPV_HD double fpv_clip_t(double x, double lo, double hi) { return fmin(fmax(x, lo), hi); }
 
 // One axis of the rate loop in arithmetic type T (float, or double for the Racer as written).
@@ -817,7 +871,7 @@ FPV_HD float fpv_racer_step_lane(const FpvK& K, FpvRacerState& s, float a0, floa
         n.x = fmaf(s.q.w, dx, fmaf(s.q.x, dw, fmaf(s.q.y, dz, -s.q.z * dy)));
         n.y = fmaf(s.q.w, dy, fmaf(-s.q.x, dz, fmaf(s.q.y, dw, s.q.z * dx)));
         n.z = fmaf(s.q.w, dz, fmaf(s.q.x, dy, fmaf(-s.q.y, dx, s.q.z * dw)));
-        const float inv = 1.0f / sqrtf(fmaf(n.w, n.w, fmaf(n.x, n.x, fmaf(n.y, n.y, n.z * n.z))));
+        const float inv = 1.0f / fpv_sqrt_flushed(fmaf(n.w, n.w, fmaf(n.x, n.x, fmaf(n.y, n.y, n.z * n.z))));
         s.q.w = n.w * inv; s.q.x = n.x * inv; s.q.y = n.y * inv; s.q.z = n.z * inv;
     }
     s.first = 0.0f;
@@ -830,7 +884,7 @@ FPV_HD float fpv_racer_step_lane(const FpvK& K, FpvRacerState& s, float a0, floa
     s.px = fmaf(s.vx, K.r_dt, s.px); s.py = fmaf(s.vy, K.r_dt, s.py); s.pz = fmaf(s.vz, K.r_dt, s.pz);
     if (!OUT) return 0.0f;                           // a k-step launch's quiet steps store no reward
     const float gx = s.px - K.goal[0], gy = s.py - K.goal[1], gz = s.pz - K.goal[2];
-    return -sqrtf(fmaf(gx, gx, fmaf(gy, gy, gz * gz)));
+    return -fpv_sqrt_flushed(fmaf(gx, gx, fmaf(gy, gy, gz * gz)));
 }
 
 FPV_HD void fpv_racer_reset_lane(FpvRacerState& s)

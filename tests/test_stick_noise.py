@@ -196,7 +196,8 @@ def test_kernel_step_index_crosses_2_to_the_32(n):
     # what ABI <= 3 did: the counter wrapped, so steps 3..5 replayed steps 0..2 of the stream
     wrapped = DroneBatch(p, n, **kw)
     wrapped.reset(); wrapped.set_step_counter(0)
-    wrapped.noise_state.copy_(torch.from_numpy(lane_model.stick_noise(p, n, 3, noise_seed=seed, drone_id_offset=off, step0=edge)[1]).to("cuda:0"))
+    ns3 = lane_model.stick_noise(p, n, 3, noise_seed=seed, drone_id_offset=off, step0=edge)[1]      # EMA state after steps 2^32-3 .. 2^32-1
+    wrapped.noise_state[:, :n] = torch.from_numpy(ns3[:, :n]).to("cuda:0")
     wrapped.rollout(None, steps=3)
     assert not np.array_equal(wrapped.action_out.cpu().numpy(), host[-1])
     # resume from a checkpoint taken beyond 2^32

@@ -33,7 +33,7 @@ ap.add_argument("--lib", nargs="*", default=[], help="name=path/to/lib.so: a rea
 a = ap.parse_args()
 for e in a.extra:
     k, v = e.split("=", 1)
-    VARIANTS[k] = [f for f in v.split(",") if f]
+    VARIANTS[k] = [f for f in v.split(",") if f and f != "x"]        # "name=x": the library built earlier under that name
 READY = {}
 for e in a.lib:
     k, v = e.split("=", 1)
