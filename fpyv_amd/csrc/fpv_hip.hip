@@ -200,16 +200,18 @@ struct RollOut {
     // called by every live lane of the wave in the same iteration (the ballot spans the wave).  QUIET = a step of a
     // launch that neither stores reward/done per step nor tracks episodes, and is not the last one: only the
     // optional per-step done_bits row is left of it
+    // `live` = false: a lane that runs the step but owns no drone (fpv_drone_rollout_h_kernel's shadow lanes) - it
+    // stores nothing and does not vote; the per-step pointers stay wave-uniform because every lane advances them
     template <bool QUIET = false>
-    __device__ __forceinline__ void step(uint32_t i, int t, float reward, bool done)
+    __device__ __forceinline__ void step(uint32_t i, int t, float reward, bool done, bool live = true)
     {
         const bool last = !QUIET && t == last_t;
         if (bp && (bits_stride || last)) {
-            const unsigned long long mask = __ballot(done);
+            const unsigned long long mask = __ballot(live && done);
             if ((threadIdx.x & 63) == 0) bp[i >> 6] = mask;
         }
         if (!QUIET) {
-            if (out_stride || last) {
+            if ((out_stride || last) && live) {
                 if (rp) __builtin_nontemporal_store(reward, &row_at(rp, i));
                 if (dp) __builtin_nontemporal_store((uint8_t)(done ? 1 : 0), &row_at(dp, i));
             }
@@ -520,27 +522,29 @@ __device__ __forceinline__ void ld_drone_h(const FpvBufD& B, uint32_t i, FpvDron
 {
     s.px = row_at(ROW(B.state, 0, B.ld), i); s.py = row_at(ROW(B.state, 1, B.ld), i); s.pz = row_at(ROW(B.state, 2, B.ld), i);
     const uint32_t* __restrict__ sh = reinterpret_cast<const uint32_t*>(B.state_h);
-    uint32_t w[FPV_HALF_PAIR_ROWS];
-#pragma unroll
-    for (int k = 0; k < FPV_HALF_PAIR_ROWS; ++k) w[k] = row_at(ROW(sh, k, B.ld), i);
-    const uint32_t tw = row_at(thrust_row_h(B), i >> 1);          // shared with the neighbour lane
     FpvHalfState h;
-    fpv_split_pairs(w, h);
+#pragma unroll
+    for (int k = 0; k < FPV_HALF_PAIR_ROWS; ++k) h.w[k] = row_at(ROW(sh, k, B.ld), i);
+    const uint32_t tw = row_at(thrust_row_h(B), i >> 1);          // shared with the neighbour lane
     h.t = (uint16_t)((i & 1u) ? (tw >> 16) : tw);
     fpv_unpack_half(h, s);
 }
 
-// stores the position and pair rows and returns the new thrust half (the caller completes the pair)
-__device__ __forceinline__ uint32_t st_drone_h(const FpvBufD& B, uint32_t i, uint32_t seed, const FpvDroneState& s)
+// stores the position rows and the five pair words of an already packed state; the thrust half is the caller's
+__device__ __forceinline__ void st_packed_h(const FpvBufD& B, uint32_t i, const FpvDroneState& s, const FpvHalfState& h)
 {
     row_at(ROW(B.state, 0, B.ld), i) = s.px; row_at(ROW(B.state, 1, B.ld), i) = s.py; row_at(ROW(B.state, 2, B.ld), i) = s.pz;
-    FpvHalfState h;
-    fpv_pack_half(s, seed, (uint32_t)i, h);
-    uint32_t w[FPV_HALF_PAIR_ROWS];
-    fpv_join_pairs(h, w);
     uint32_t* __restrict__ sh = reinterpret_cast<uint32_t*>(B.state_h);
 #pragma unroll
-    for (int k = 0; k < FPV_HALF_PAIR_ROWS; ++k) row_at(ROW(sh, k, B.ld), i) = w[k];
+    for (int k = 0; k < FPV_HALF_PAIR_ROWS; ++k) row_at(ROW(sh, k, B.ld), i) = h.w[k];
+}
+
+// packs and stores the position and pair rows; returns the new thrust half (the caller completes the pair)
+__device__ __forceinline__ uint32_t st_drone_h(const FpvBufD& B, uint32_t i, uint32_t seed, const FpvDroneState& s)
+{
+    FpvHalfState h;
+    fpv_pack_half(s, seed, (uint32_t)i, h);
+    st_packed_h(B, i, s, h);
     return h.t;
 }
 
@@ -565,7 +569,7 @@ __global__ __launch_bounds__(kStepBlock) void fpv_drone_step_h_kernel(const FpvK
         const float4 a = ld_action(B.action, i);
         ld_drone_h(B, i, s);
         __builtin_amdgcn_sched_barrier(0);       // loads first, constants after (see fpv_drone_step_kernel)
-        o = fpv_drone_step_lane<false>(K, s, a.x, a.y, a.z, a.w, B.wx, B.wy, B.wz);
+        o = fpv_drone_step_lane<false, true, false, false>(K, s, a.x, a.y, a.z, a.w, B.wx, B.wy, B.wz);
         if (B.accel) {
             row_at(ROW(B.accel, 0, B.ld), i) = o.ax; row_at(ROW(B.accel, 1, B.ld), i) = o.ay; row_at(ROW(B.accel, 2, B.ld), i) = o.az;
         }
@@ -577,56 +581,78 @@ __global__ __launch_bounds__(kStepBlock) void fpv_drone_step_h_kernel(const FpvK
 }
 
 // k steps of the fp16-storage kernel in one launch: the state is rounded to binary16 and widened again
-// after EVERY step, in registers, exactly as k single-step launches would do through HBM.
+// after EVERY step, in registers, exactly as k single-step launches would do through HBM.  Sections and argument
+// views as in fpv_drone_rollout_kernel.  No lane leaves early (the thrust-pair exchange needs whole lane pairs): the
+// dead lanes of the last wave shadow the last drone - same loads, same arithmetic, uniform control flow - and store
+// nothing.
 __global__ __launch_bounds__(kStepBlock) void fpv_drone_rollout_h_kernel(const FpvRollArgs A)
 {
-    const FpvK& K = A.K; const FpvBufD& B = A.B; const int64_t n = A.n; const FpvRoll& R = A.R;
-    const uint32_t i = blockIdx.x * (uint32_t)kStepBlock + threadIdx.x;
-    const bool live = i < n;
-    uint32_t th = 0;
+    const uint32_t i0 = blockIdx.x * (uint32_t)kStepBlock + threadIdx.x;
+    const bool live = i0 < A.n;
+    const uint32_t i = live ? i0 : (uint32_t)(A.n - 1);
+    FpvDroneState s;
+    FpvHalfState h;
+    ld_drone_h(A.B, i, s);
+    float4 a_next = ld_action(A.B.action, i);
+    const int k = A.R.k;
+    fpv_settle(s.px); fpv_settle(s.py); fpv_settle(s.pz); fpv_settle(s.vx); fpv_settle(s.vy); fpv_settle(s.vz);
+    fpv_settle(s.q.w); fpv_settle(s.q.x); fpv_settle(s.q.y); fpv_settle(s.q.z);
+    fpv_settle(s.rx); fpv_settle(s.ry); fpv_settle(s.rz); fpv_settle(s.thrust);
+    auto one_step = [&](const FpvRollArgs& V, const float* ap_next, bool prefetch, bool widen, int t, auto quiet_c) -> FpvStepOut {
+        constexpr bool QUIET = decltype(quiet_c)::value;
+        const float4 a = a_next;
+        if (QUIET || prefetch) a_next = ld_action(reinterpret_cast<const float4*>(ap_next), i);
+        FpvStepOut o = fpv_drone_step_lane<false, !QUIET, false, false>(V.K, s, a.x, a.y, a.z, a.w, V.B.wx, V.B.wy, V.B.wz);
+        if ((V.K.flags & FPV_FLAG_AUTO_RESET) && o.done) {
+            const FpvRollArgs& Z = fpv_args_again();
+            fpv_drone_reset_lane(Z.K, s);
+        }
+        fpv_pack_half(s, fpv_round_seed(V.B.seed, V.B.step + (uint64_t)t), (uint32_t)i, h);   // the HBM round trip of a single step, in registers
+        if (QUIET || widen) fpv_unpack_half(h, s);
+        return o;
+    };
+    int t = 0;
+    if (A.B.ep_return == nullptr && A.R.out_stride == 0 && k > 1) {
+        const float* ap = reinterpret_cast<const float*>(A.B.action);
+        const int64_t astride = A.R.action_stride;
+        unsigned long long* bp = A.R.bits_stride ? A.B.done_bits : nullptr;
+        const int64_t bstride = A.R.bits_stride;
+        for (; t < k - 1; ++t) {
+            ap += astride;
+            const FpvStepOut o = one_step(A, ap, true, true, t, std::true_type{});
+            if (bp) {
+                const unsigned long long mask = __ballot(live && o.done);
+                if ((threadIdx.x & 63) == 0) bp[i0 >> 6] = mask;          // lane 0 of a launched wave is always live
+                bp += bstride;
+            }
+        }
+    }
     FpvStepOut o;
     o.done = false; o.reward = 0.0f; o.ax = o.ay = o.az = 0.0f;
-    RollOut out(B, R, i, live);
-    if (live) {
-        FpvDroneState s;
-        ld_drone_h(B, i, s);
-        const float* ap = reinterpret_cast<const float*>(B.action);
-        float4 a_next = ld_action(reinterpret_cast<const float4*>(ap), i);
-        FpvHalfState h;
-        fpv_settle(s.px); fpv_settle(s.py); fpv_settle(s.pz); fpv_settle(s.vx); fpv_settle(s.vy); fpv_settle(s.vz);
-        fpv_settle(s.q.w); fpv_settle(s.q.x); fpv_settle(s.q.y); fpv_settle(s.q.z);
-        fpv_settle(s.rx); fpv_settle(s.ry); fpv_settle(s.rz); fpv_settle(s.thrust);
+    {
+        const FpvRollArgs& G = fpv_args_again();
+        RollOut out(G.B, G.R, i, true);
+        if (out.bp) out.bp += (int64_t)t * G.R.bits_stride;
+        const float* ap = reinterpret_cast<const float*>(G.B.action) + (int64_t)t * G.R.action_stride;
+        const int kk = G.R.k;
         if (out.track) { fpv_settle(out.ep_r); fpv_settle(__int_as_float(out.ep_l)); }
-        auto one_step = [&](int t, auto quiet_c) {                       // see fpv_drone_rollout_kernel
-            constexpr bool QUIET = decltype(quiet_c)::value;
-            const float4 a = a_next;
-            if (R.action_stride && t + 1 < R.k) { ap += R.action_stride; a_next = ld_action(reinterpret_cast<const float4*>(ap), i); }
-            o = fpv_drone_step_lane<false, !QUIET>(K, s, a.x, a.y, a.z, a.w, B.wx, B.wy, B.wz);
-            if ((K.flags & FPV_FLAG_AUTO_RESET) && o.done) fpv_drone_reset_lane(K, s);
-            fpv_pack_half(s, fpv_round_seed(B.seed, B.step + (uint64_t)t), (uint32_t)i, h);       // the HBM round trip of a single step, in registers
-            if (QUIET || t + 1 < R.k) fpv_unpack_half(h, s);
-            out.template step<QUIET>(i, t, o.reward, o.done);
-        };
-        int t = 0;
-        if (!out.track && R.out_stride == 0) {
-            for (; t < R.k - 1; ++t) one_step(t, std::true_type{});
+        for (; t < kk; ++t) {
+            ap += G.R.action_stride;
+            o = one_step(G, ap, G.R.action_stride != 0 && t + 1 < kk, t + 1 < kk, t, std::false_type{});
+            out.template step<false>(i0, t, o.reward, o.done, live);
         }
-        for (; t < R.k; ++t) one_step(t, std::false_type{});
-        uint32_t j = i;                              // form the store addresses after the loop (VGPR pressure)
-        asm volatile("" : "+v"(j));
-        if (B.accel) {
-            row_at(ROW(B.accel, 0, B.ld), j) = o.ax; row_at(ROW(B.accel, 1, B.ld), j) = o.ay; row_at(ROW(B.accel, 2, B.ld), j) = o.az;
-        }
-        row_at(ROW(B.state, 0, B.ld), j) = s.px; row_at(ROW(B.state, 1, B.ld), j) = s.py; row_at(ROW(B.state, 2, B.ld), j) = s.pz;
-        uint32_t w[FPV_HALF_PAIR_ROWS];
-        fpv_join_pairs(h, w);
-        uint32_t* __restrict__ sh = reinterpret_cast<uint32_t*>(B.state_h);
-#pragma unroll
-        for (int k = 0; k < FPV_HALF_PAIR_ROWS; ++k) row_at(ROW(sh, k, B.ld), j) = w[k];
-        th = h.t;
-        out.finish(j);
+        if (live) out.finish(i0);
     }
-    st_thrust_pair_h(B, i, live, th);
+    const FpvRollArgs& E = fpv_args_again();
+    uint32_t j = i0;                             // form the store addresses after the loops (VGPR pressure)
+    asm volatile("" : "+v"(j));
+    if (live) {
+        if (E.B.accel) {
+            row_at(ROW(E.B.accel, 0, E.B.ld), j) = o.ax; row_at(ROW(E.B.accel, 1, E.B.ld), j) = o.ay; row_at(ROW(E.B.accel, 2, E.B.ld), j) = o.az;
+        }
+        st_packed_h(E.B, j, s, h);
+    }
+    st_thrust_pair_h(E.B, i0, live, h.t);
 }
 
 template <bool WIDE, bool PIDV>

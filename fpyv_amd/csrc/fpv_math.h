@@ -198,6 +198,9 @@ FPV_HD FpvRot fpv_rot(FpvQuat q)
 // q <- normalise(q + q (x) d) for a small-ish quaternion increment d = (dw, dx, dy, dz) (i.e. the
 // full factor is 1 + d).  First-order renormalisation: |q|^2 - 1 stays at rounding level because
 // it is corrected every step.
+// NORM = false leaves the renormalisation out: the fp16-storage kernels renormalise when they widen the stored
+// quaternion (every step), and q (x) (1 + d) is unit for unit q anyway - only rounding drift is at stake.
+template <bool NORM = true>
 FPV_HD FpvQuat fpv_quat_advance(FpvQuat q, float dw, float dx, float dy, float dz)
 {
     FpvQuat n;
@@ -205,6 +208,7 @@ FPV_HD FpvQuat fpv_quat_advance(FpvQuat q, float dw, float dx, float dy, float d
     n.x = q.x + fmaf(q.w, dx, fmaf(q.x, dw, fmaf(q.y, dz, -q.z * dy)));
     n.y = q.y + fmaf(q.w, dy, fmaf(-q.x, dz, fmaf(q.y, dw, q.z * dx)));
     n.z = q.z + fmaf(q.w, dz, fmaf(q.x, dy, fmaf(-q.y, dx, q.z * dw)));
+    if (!NORM) return n;
     const float e = fmaf(n.w, n.w, fmaf(n.x, n.x, fmaf(n.y, n.y, fmaf(n.z, n.z, -1.0f))));
     const float k = fmaf(0.375f * e, e, -0.5f * e);      // 1/sqrt(1+e) - 1
     n.w = fmaf(k, n.w, n.w); n.x = fmaf(k, n.x, n.x); n.y = fmaf(k, n.y, n.y); n.z = fmaf(k, n.z, n.z);
@@ -244,13 +248,16 @@ struct FpvDroneState {
 // ------------------------------------------------------------------------------------------------
 // fp16 storage (BASELINE config 4: "fp16 state / fp32 integrator"): v, q, prev_rates, prev_thrust
 // live in HBM as IEEE binary16, position stays fp32, all arithmetic stays fp32.  The kernel converts
-// with the hardware instructions, the host lane model with integer bit manipulation; both are
-// exact IEEE round-to-nearest-even, so they agree bit for bit.
-//   * low-pass states (rates, thrust) are rounded to nearest-even: their error does not accumulate;
+// with the hardware instructions, the host lane model with integer bit manipulation; they agree bit for bit.
+//   * low-pass states (rates, thrust) are rounded to nearest-even (v_cvt_f16_f32): their error does not accumulate;
 //   * integrator states (v, q) are rounded STOCHASTICALLY: at dt = 1 ms one step's increment is
 //     often below half an fp16 ulp (0.03 m/s against ulp 0.016 at 20 m/s; 3e-4 of quaternion against
 //     ulp 5e-4), and round-to-nearest would simply stall them.  Unbiased rounding keeps the
 //     expected trajectory and turns the stall into a random walk of ~ulp*sqrt(steps).
+//     Stochastic rounding = add 13 uniform random bits below the kept mantissa, then round TOWARD ZERO: one integer
+//     add per value and ONE v_cvt_pkrtz_f16_f32 per PAIR of values, which also packs the half2 word of the pair row
+//     (round 2: a range test, an add, a mask and a select per value, then a round-to-nearest conversion and a
+//     separate packing step - 368 VALU instructions per wave against 251 of the fp32 kernel).
 // ------------------------------------------------------------------------------------------------
 FPV_HD uint32_t fpv_f32_bits(float x) { uint32_t u; memcpy(&u, &x, 4); return u; }
 FPV_HD float fpv_bits_f32(uint32_t u) { float x; memcpy(&x, &u, 4); return x; }
@@ -298,18 +305,43 @@ FPV_HD uint16_t fpv_f32_to_f16_rn(float x)
 #endif
 }
 
-// Stochastic rounding: in the normal binary16 range add 13 uniform random bits below the kept
-// mantissa and truncate (unbiased: E[result] = x); the result is exactly representable, so the
-// final conversion is exact.  Below 2^-14 (irrelevant for the dynamics) plain nearest-even.
-FPV_HD uint16_t fpv_f32_to_f16_sr(float x, uint32_t rnd13)
+// fp32 -> binary16 with round TOWARD ZERO (host side of v_cvt_pkrtz_f16_f32): truncation of the mantissa, subnormal
+// halves by truncating |x| / 2^-24, finite overflow saturates at the largest finite half (round-toward-zero never
+// produces an infinity), inf stays inf.
+FPV_HD uint16_t fpv_f32_to_f16_rtz_host(float x)
 {
-    uint32_t b = fpv_f32_bits(x);
+    const uint32_t b = fpv_f32_bits(x), sign = (b >> 16) & 0x8000u;
     const uint32_t a = b & 0x7fffffffu;
-    if (a >= 0x38800000u && a < 0x7f800000u) b = (b + rnd13) & 0xffffe000u;
-    return fpv_f32_to_f16_rn(fpv_bits_f32(b));
+    if (a > 0x7f800000u) return (uint16_t)(sign | 0x7e00u);                                // nan
+    if (a == 0x7f800000u) return (uint16_t)(sign | 0x7c00u);                               // inf
+    if (a >= 0x47800000u) return (uint16_t)(sign | 0x7bffu);                               // >= 65536: largest finite
+    if (a < 0x38800000u) return (uint16_t)(sign | (uint32_t)(fpv_bits_f32(a) * 16777216.0f));   // exact scaling, then truncation
+    return (uint16_t)(sign | ((a - 0x38000000u) >> 13));
 }
 
-// three 32-bit hashes of (seed, drone) give the 7 x 13 random bits one step needs
+// half2 word (low half first) of two fp32 values, both rounded toward zero: ONE instruction on gfx950
+FPV_HD uint32_t fpv_pack_pair_rtz(float lo, float hi)
+{
+#if defined(__HIP_DEVICE_COMPILE__)
+    typedef __fp16 fpv_h2 __attribute__((ext_vector_type(2)));
+    const fpv_h2 p = __builtin_amdgcn_cvt_pkrtz(lo, hi);
+    uint32_t w;
+    memcpy(&w, &p, 4);
+    return w;
+#else
+    return (uint32_t)fpv_f32_to_f16_rtz_host(lo) | ((uint32_t)fpv_f32_to_f16_rtz_host(hi) << 16);
+#endif
+}
+
+// the value whose round-toward-zero conversion is the stochastic rounding of x: 13 uniform random bits added below the
+// kept mantissa (unbiased for every normal half: E[result] = x; an exactly representable x is never perturbed because
+// its low 13 bits are zero and rnd13 < 2^13).  Below 2^-14 - subnormal halves, spacing 6e-8 - the added bits are a
+// relative perturbation of at most 2^-10 and the truncation a bias of at most one spacing: irrelevant for the dynamics.
+FPV_HD float fpv_sr_arg(float x, uint32_t rnd13) { return fpv_bits_f32(fpv_f32_bits(x) + rnd13); }
+
+FPV_HD uint16_t fpv_f32_to_f16_sr(float x, uint32_t rnd13) { return (uint16_t)fpv_pack_pair_rtz(fpv_sr_arg(x, rnd13), 0.0f); }
+
+// the hash behind the 7 x 13 random bits one step needs
 FPV_HD uint32_t fpv_mix32(uint32_t x)
 {
     x ^= x >> 16; x *= 0x7feb352du; x ^= x >> 15; x *= 0x846ca68bu; x ^= x >> 16;
@@ -323,51 +355,39 @@ FPV_HD uint32_t fpv_round_seed(uint32_t base, uint64_t step)
     return base + (uint32_t)step + (uint32_t)(step >> 32) * 0x9e3779b1u;
 }
 
-struct FpvHalfState { uint16_t v[3], q[4], r[3], t; };   // the 11 binary16 values of one drone
-
-// storage order: FIVE half2 rows (low half first): (vx,vy) (vz,qw) (qx,qy) (qz,rx) (ry,rz), then ONE row of
-// single halves for prev_thrust (89 state+io bytes per env-step); h.t is moved separately
-FPV_HD void fpv_split_pairs(const uint32_t w[5], FpvHalfState& h)
-{
-    h.v[0] = (uint16_t)w[0]; h.v[1] = (uint16_t)(w[0] >> 16);
-    h.v[2] = (uint16_t)w[1]; h.q[0] = (uint16_t)(w[1] >> 16);
-    h.q[1] = (uint16_t)w[2]; h.q[2] = (uint16_t)(w[2] >> 16);
-    h.q[3] = (uint16_t)w[3]; h.r[0] = (uint16_t)(w[3] >> 16);
-    h.r[1] = (uint16_t)w[4]; h.r[2] = (uint16_t)(w[4] >> 16);
-}
-FPV_HD void fpv_join_pairs(const FpvHalfState& h, uint32_t w[5])
-{
-    w[0] = (uint32_t)h.v[0] | ((uint32_t)h.v[1] << 16);
-    w[1] = (uint32_t)h.v[2] | ((uint32_t)h.q[0] << 16);
-    w[2] = (uint32_t)h.q[1] | ((uint32_t)h.q[2] << 16);
-    w[3] = (uint32_t)h.q[3] | ((uint32_t)h.r[0] << 16);
-    w[4] = (uint32_t)h.r[1] | ((uint32_t)h.r[2] << 16);
-}
+// The 11 binary16 values of one drone in storage order: FIVE half2 words (low half first) - (vx,vy) (vz,qw) (qx,qy)
+// (qz,rx) (ry,rz) - and the prev_thrust half, which lives in a row of single halves (89 state+io bytes per env-step,
+// SURVEY 8d) and is moved separately.
+struct FpvHalfState { uint32_t w[5]; uint16_t t; };
 
 FPV_HD void fpv_unpack_half(const FpvHalfState& h, FpvDroneState& s)
 {
-    s.vx = fpv_f16_to_f32(h.v[0]); s.vy = fpv_f16_to_f32(h.v[1]); s.vz = fpv_f16_to_f32(h.v[2]);
-    s.q.w = fpv_f16_to_f32(h.q[0]); s.q.x = fpv_f16_to_f32(h.q[1]); s.q.y = fpv_f16_to_f32(h.q[2]); s.q.z = fpv_f16_to_f32(h.q[3]);
-    s.rx = fpv_f16_to_f32(h.r[0]); s.ry = fpv_f16_to_f32(h.r[1]); s.rz = fpv_f16_to_f32(h.r[2]);
+    s.vx = fpv_f16_to_f32((uint16_t)h.w[0]); s.vy = fpv_f16_to_f32((uint16_t)(h.w[0] >> 16));
+    s.vz = fpv_f16_to_f32((uint16_t)h.w[1]); s.q.w = fpv_f16_to_f32((uint16_t)(h.w[1] >> 16));
+    s.q.x = fpv_f16_to_f32((uint16_t)h.w[2]); s.q.y = fpv_f16_to_f32((uint16_t)(h.w[2] >> 16));
+    s.q.z = fpv_f16_to_f32((uint16_t)h.w[3]); s.rx = fpv_f16_to_f32((uint16_t)(h.w[3] >> 16));
+    s.ry = fpv_f16_to_f32((uint16_t)h.w[4]); s.rz = fpv_f16_to_f32((uint16_t)(h.w[4] >> 16));
     s.thrust = fpv_f16_to_f32(h.t);
     // a stored quaternion is unit only to ~1e-3; the fp32 integrator wants |q| = 1.
-    // 1/sqrt(1+e) = 1 - e/2 + 3e^2/8 - 5e^3/16 (+4e-12 at |e| = 2e-3): FMAs only, no sqrt/divide
+    // 1/sqrt(1+e) = 1 - e/2 + 3e^2/8 (the next term, 5e^3/16, is 2.5e-9 at |e| = 2e-3: below fp32 rounding)
     const float e = fmaf(s.q.w, s.q.w, fmaf(s.q.x, s.q.x, fmaf(s.q.y, s.q.y, fmaf(s.q.z, s.q.z, -1.0f))));
-    const float k = fmaf(fmaf(fmaf(-0.3125f, e, 0.375f), e, -0.5f), e, 0.0f);
+    const float k = fmaf(0.375f, e, -0.5f) * e;
     s.q.w = fmaf(k, s.q.w, s.q.w); s.q.x = fmaf(k, s.q.x, s.q.x); s.q.y = fmaf(k, s.q.y, s.q.y); s.q.z = fmaf(k, s.q.z, s.q.z);
 }
 
 FPV_HD void fpv_pack_half(const FpvDroneState& s, uint32_t seed, uint32_t drone, FpvHalfState& h)
 {
-    const uint32_t r0 = fpv_mix32(seed * 0x9e3779b9u + drone), r1 = fpv_mix32(r0 + 0x85ebca6bu), r2 = fpv_mix32(r1 + 0xc2b2ae35u);
-    h.v[0] = fpv_f32_to_f16_sr(s.vx, r0 & 0x1fffu);
-    h.v[1] = fpv_f32_to_f16_sr(s.vy, (r0 >> 13) & 0x1fffu);
-    h.v[2] = fpv_f32_to_f16_sr(s.vz, r1 & 0x1fffu);
-    h.q[0] = fpv_f32_to_f16_sr(s.q.w, (r1 >> 13) & 0x1fffu);
-    h.q[1] = fpv_f32_to_f16_sr(s.q.x, r2 & 0x1fffu);
-    h.q[2] = fpv_f32_to_f16_sr(s.q.y, (r2 >> 13) & 0x1fffu);
-    h.q[3] = fpv_f32_to_f16_sr(s.q.z, ((r0 >> 26) | ((r1 >> 26) << 6) | ((r2 >> 26) << 12)) & 0x1fffu);
-    h.r[0] = fpv_f32_to_f16_rn(s.rx); h.r[1] = fpv_f32_to_f16_rn(s.ry); h.r[2] = fpv_f32_to_f16_rn(s.rz);
+    // one full-avalanche hash of (seed, drone); the second and third word by one multiply-xorshift each (bijections of
+    // a uniform word: uniform again) - round 2 ran the full hash three times: six quarter-rate multiplies per lane
+    const uint32_t r0 = fpv_mix32(seed * 0x9e3779b9u + drone);
+    uint32_t r1 = r0 * 0x9e3779b1u; r1 ^= r1 >> 15;
+    uint32_t r2 = r1 * 0x85ebca77u; r2 ^= r2 >> 13;
+    const uint32_t f6 = (((r0 >> 26) | ((r1 >> 20) & 0xfc0u)) << 1) | 1u;         // 12 bits, centred on the 13-bit grid
+    h.w[0] = fpv_pack_pair_rtz(fpv_sr_arg(s.vx, r0 & 0x1fffu), fpv_sr_arg(s.vy, (r0 >> 13) & 0x1fffu));
+    h.w[1] = fpv_pack_pair_rtz(fpv_sr_arg(s.vz, r1 & 0x1fffu), fpv_sr_arg(s.q.w, (r1 >> 13) & 0x1fffu));
+    h.w[2] = fpv_pack_pair_rtz(fpv_sr_arg(s.q.x, r2 & 0x1fffu), fpv_sr_arg(s.q.y, (r2 >> 13) & 0x1fffu));
+    h.w[3] = fpv_pack_pair_rtz(fpv_sr_arg(s.q.z, f6), 0.0f) | ((uint32_t)fpv_f32_to_f16_rn(s.rx) << 16);
+    h.w[4] = (uint32_t)fpv_f32_to_f16_rn(s.ry) | ((uint32_t)fpv_f32_to_f16_rn(s.rz) << 16);
     h.t = fpv_f32_to_f16_rn(s.thrust);
 }
 
@@ -584,7 +604,8 @@ FPV_HD bool fpv_collide_objects(const FpvK& K, const FpvObjects& T, const FpvRot
 // test that once per launch); the ground flag then comes from two motor heights instead of four, bit for bit the
 // same flag.  The single-step kernels are HBM-bound and keep the four-height form (SQ = false): there the extra
 // uniform test costs more than the 14 instructions it saves.
-template <bool OBJ = false, bool OUT = true, bool SQ = false>
+// NORM = false: no renormalisation of the advanced quaternion (fp16-storage kernels only, see fpv_quat_advance).
+template <bool OBJ = false, bool OUT = true, bool SQ = false, bool NORM = true>
 FPV_HD FpvStepOut fpv_drone_step_lane(const FpvK& K, FpvDroneState& s, float a0, float a1, float a2, float a3,
                                       float wx, float wy, float wz, const FpvObjects* objs = nullptr,
                                       float* kahan = nullptr, const float* rot_over = nullptr, float thrust_over = 0.0f)
@@ -705,7 +726,7 @@ FPV_HD FpvStepOut fpv_drone_step_lane(const FpvK& K, FpvDroneState& s, float a0,
     // conj(q_E)^2 - 1 = (-2|e_v|^2, -2 e_w e_v)
     const float vv = fmaf(ex, ex, fmaf(ey, ey, ez * ez));
     const float m2w = -2.0f * ew;
-    s.q = fpv_quat_advance(s.q, -2.0f * vv, m2w * ex, m2w * ey, m2w * ez);
+    s.q = fpv_quat_advance<NORM>(s.q, -2.0f * vv, m2w * ex, m2w * ey, m2w * ez);
 
     FpvStepOut o;
     o.ax = o.ay = o.az = 0.0f; o.reward = 0.0f;

@@ -145,18 +145,15 @@ extern "C" int fpvl_run_h(const fpv_params_t* P, int64_t n, int steps, float* po
             FpvDroneState s;
             FpvHalfState h;
             s.px = pos[0 * ld + i]; s.py = pos[1 * ld + i]; s.pz = pos[2 * ld + i];
-            uint32_t w[FPV_HALF_PAIR_ROWS];
-            for (int k = 0; k < FPV_HALF_PAIR_ROWS; ++k) w[k] = sh[k * ld + i];
-            fpv_split_pairs(w, h);
+            for (int k = 0; k < FPV_HALF_PAIR_ROWS; ++k) h.w[k] = sh[k * ld + i];
             h.t = thrust[i];
             fpv_unpack_half(h, s);
             const float* a = actions + ((per_step ? (int64_t)t * n : 0) + i) * 4;
-            o = fpv_drone_step_lane<false>(K, s, a[0], a[1], a[2], a[3], wind[0], wind[1], wind[2]);
+            o = fpv_drone_step_lane<false, true, false, false>(K, s, a[0], a[1], a[2], a[3], wind[0], wind[1], wind[2]);
             if ((K.flags & FPV_FLAG_AUTO_RESET) && o.done) fpv_drone_reset_lane(K, s);
             fpv_pack_half(s, fpv_round_seed(seed0, step0 + (uint64_t)t), (uint32_t)i, h);
             pos[0 * ld + i] = s.px; pos[1 * ld + i] = s.py; pos[2 * ld + i] = s.pz;
-            fpv_join_pairs(h, w);
-            for (int k = 0; k < FPV_HALF_PAIR_ROWS; ++k) sh[k * ld + i] = w[k];
+            for (int k = 0; k < FPV_HALF_PAIR_ROWS; ++k) sh[k * ld + i] = h.w[k];
             thrust[i] = h.t;
         }
         if (done) done[i] = o.done ? 1 : 0;
@@ -168,6 +165,18 @@ extern "C" int fpvl_run_h(const fpv_params_t* P, int64_t n, int steps, float* po
 // conversion helpers exposed for the unit tests
 extern "C" uint16_t fpvl_f32_to_f16(float x, uint32_t rnd13, int stochastic) { return stochastic ? fpv_f32_to_f16_sr(x, rnd13) : fpv_f32_to_f16_rn(x); }
 extern "C" float fpvl_f16_to_f32(uint16_t h) { return fpv_f16_to_f32(h); }
+extern "C" uint16_t fpvl_f32_to_f16_rtz(float x) { return (uint16_t)fpv_pack_pair_rtz(x, 0.0f); }
+// the storage words of ONE drone state (14 fp32 values in row order) as the fp16 kernels pack it: out[0..4] pair words, out[5] thrust half
+extern "C" void fpvl_pack_state(const float st[14], uint32_t seed, uint32_t drone, uint32_t out[6])
+{
+    FpvDroneState s;
+    s.px = st[0]; s.py = st[1]; s.pz = st[2]; s.vx = st[3]; s.vy = st[4]; s.vz = st[5];
+    s.q.w = st[6]; s.q.x = st[7]; s.q.y = st[8]; s.q.z = st[9]; s.rx = st[10]; s.ry = st[11]; s.rz = st[12]; s.thrust = st[13];
+    FpvHalfState h;
+    fpv_pack_half(s, seed, drone, h);
+    for (int k = 0; k < 5; ++k) out[k] = h.w[k];
+    out[5] = h.t;
+}
 
 // stick-noise generator on the host: ns [4][ld] EMA state advanced `steps` times from step index
 // step0; applied [steps][n][4] receives clip(base + gain * x_s) (base = 0 when base_actions is NULL)

@@ -156,6 +156,27 @@ def run_h(p, pos: np.ndarray, sh: np.ndarray, actions: np.ndarray, steps: Option
     return done, reward
 
 
+def f32_to_f16_rtz(x: np.ndarray) -> np.ndarray:
+    """binary16 bit patterns of fp32 values rounded TOWARD ZERO (host side of v_cvt_pkrtz_f16_f32)."""
+    L = lib()
+    L.fpvl_f32_to_f16_rtz.argtypes = [C.c_float]
+    L.fpvl_f32_to_f16_rtz.restype = C.c_uint16
+    x = np.asarray(x, dtype=np.float32)
+    return np.array([L.fpvl_f32_to_f16_rtz(float(v)) for v in x.reshape(-1)], dtype=np.uint16).reshape(x.shape)
+
+
+def pack_state(state14, seed: int, drone: int) -> np.ndarray:
+    """[6] uint32: the five half2 pair words and the thrust half the fp16 kernels store for one drone state
+    (14 fp32 values in row order), rounding seed `seed` (= fpv_round_seed(rounding_seed, step)) and lane `drone`."""
+    L = lib()
+    L.fpvl_pack_state.argtypes = [C.POINTER(C.c_float), C.c_uint32, C.c_uint32, C.POINTER(C.c_uint32)]
+    st = np.ascontiguousarray(state14, dtype=np.float32)
+    out = np.zeros(6, dtype=np.uint32)
+    L.fpvl_pack_state(st.ctypes.data_as(C.POINTER(C.c_float)), int(seed) & 0xFFFFFFFF, int(drone) & 0xFFFFFFFF,
+                      out.ctypes.data_as(C.POINTER(C.c_uint32)))
+    return out
+
+
 def split_half(state: np.ndarray):
     """[14, ld] fp32 SoA -> (pos [3, ld] fp32, sh [11 * ld] uint16) with round-to-nearest halves (a freshly
     reset state is exactly representable, so the rounding mode does not matter)."""

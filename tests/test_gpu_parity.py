@@ -569,6 +569,32 @@ def test_fp16_state_ragged_sizes_vs_lane_model_and_oracle(params_1k, n, fused):
         assert err[k] <= tol, (k, err[k], n)
 
 
+def test_fp16_device_conversions_equal_the_host_emulation_on_special_values(params_1k):
+    """v_cvt_pkrtz_f16_f32 (round toward zero, two values per instruction) and the 13-bit stochastic rounding on the
+    device against the host emulation the lane model uses, on the values a trajectory never visits: every exponent
+    from fp32 subnormals to overflow, subnormal halves, the saturation boundary, +-0 (a non-finite state is garbage on
+    either side and is not compared).  The values reach the
+    kernel's packer as per-drone reset velocities (fpv_reset_kernel packs with the buffer's rounding seed)."""
+    rng = np.random.default_rng(11)
+    special = np.array([0.0, -0.0, 65504, 65519.9, 65520, 65535.9, 65536, 7e4, -7e4, 3e38, -3e38, 6e-8, 5.97e-8, 5.9e-8, 3e-8, 1e-41,
+                        6.1e-5, 6.09e-5, 6.103515625e-5, 1.0, -1.0, 1.0009765625, 1.00097, 2.0 ** -14, 2.0 ** -24, 2.0 ** -25], dtype=np.float32)
+    rnd = (rng.standard_normal(3 * 2000 - len(special)) * 10.0 ** rng.integers(-12, 7, 3 * 2000 - len(special))).astype(np.float32)
+    vel = np.concatenate([special, rnd]).reshape(-1, 3)
+    n = vel.shape[0]
+    env = _drone_batch(params_1k, n, fp16_state=True, rounding_seed=4242, with_accel=False)
+    env.reset(velocity=vel)
+    torch.cuda.synchronize()
+    ld = env.ld
+    got = env.state_h.cpu().numpy().view(np.uint16)[:10 * ld].reshape(5, ld, 2)[:, :n]        # [pair row, drone, half]
+    for i in range(n):
+        st = np.zeros(14, dtype=np.float32)
+        st[0:3] = [0, 0, 10]; st[3:6] = vel[i]; st[6] = 1.0
+        w = lane_model.pack_state(st, 4242, i)
+        want = [(int(w[0]) & 0xffff, int(w[0]) >> 16), (int(w[1]) & 0xffff, int(w[1]) >> 16)]
+        assert (int(got[0, i, 0]), int(got[0, i, 1])) == want[0], (i, vel[i], got[0, i], [hex(x) for x in want[0]])
+        assert (int(got[1, i, 0]), int(got[1, i, 1])) == want[1], (i, vel[i], got[1, i], [hex(x) for x in want[1]])
+
+
 def test_fp16_state_full_size_vs_fp32_run():
     """Config 4 at full size: same sticks through the fp32 and the fp16-storage kernels; the
     distribution of the difference after 500 steps must sit inside the restated tolerance."""

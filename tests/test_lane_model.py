@@ -216,6 +216,39 @@ def test_fp16_conversions_match_ieee_and_stochastic_rounding_is_unbiased():
         assert all(L.fpvl_f16_to_f32(L.fpvl_f32_to_f16(x, r, 1)) == x for r in (0, 1, 4095, 8191))
 
 
+def test_fp16_round_toward_zero_conversion_and_pair_packing():
+    """Host side of v_cvt_pkrtz_f16_f32 (the stochastic rounding = 13 random bits added below the kept mantissa, then
+    this conversion): truncation for normals, subnormal halves, saturation instead of overflow, against an
+    independent construction from numpy.float16 (the largest half whose magnitude does not exceed |x|)."""
+    rng = np.random.default_rng(1)
+    xs = rng.standard_normal(6000).astype(np.float32) * np.float32(10.0) ** rng.integers(-10, 6, 6000).astype(np.float32)
+    xs = np.concatenate([xs, np.array([0, -0.0, 65504, 65519.9, 65520, 65535.9, 65536, 7e4, -7e4, 3e38, 6e-8, 5.97e-8, 5.9e-8, 3e-8,
+                                       6.1e-5, 6.09e-5, 6.103515625e-5, 1.0, -1.0, 1.0009765625, 1.00097, np.inf, -np.inf], dtype=np.float32)])
+    got = lane_model.f32_to_f16_rtz(xs)
+    with np.errstate(over="ignore"):
+        rn = xs.astype(np.float16)
+    # round-to-nearest result, stepped one half towards zero wherever it overshot |x|; finite overflow -> 65504
+    bits = rn.view(np.uint16).copy()
+    mag = bits & 0x7fff
+    over = (np.abs(rn.astype(np.float64)) > np.abs(xs.astype(np.float64))) & np.isfinite(xs)
+    mag = np.where(over, mag - 1, mag)
+    want = ((bits & 0x8000) | mag).astype(np.uint16)
+    assert np.array_equal(got, want), [(float(x), hex(g), hex(w)) for x, g, w in zip(xs, got, want) if g != w][:5]
+    # one drone state through the packer: integrator values land on a neighbour half, low-pass values on the nearest
+    st = np.array([1, 2, 3, 0.3337, -12.3456, 20.5457, 0.70712, -0.00123, 0.70709, 1e-6, -159.99, 3.3333, 0.01, 31.5085], dtype=np.float32)
+    lo, hi = set(), set()
+    for seed in range(200):
+        w = lane_model.pack_state(st, seed, 5)
+        halves = np.array([w[0] & 0xffff, w[0] >> 16, w[1] & 0xffff, w[1] >> 16, w[2] & 0xffff, w[2] >> 16, w[3] & 0xffff,
+                           w[3] >> 16, w[4] & 0xffff, w[4] >> 16, w[5]], dtype=np.uint16).view(np.float16).astype(np.float64)
+        assert np.array_equal(halves[7:], st[10:].astype(np.float16).astype(np.float64)), "rates / thrust: round to nearest even"
+        f16 = st[3:10].astype(np.float16).astype(np.float64)
+        ulp = np.maximum(np.abs(np.spacing(st[3:10].astype(np.float16)).astype(np.float64)), 6e-8)
+        assert np.all(np.abs(halves[:7] - st[3:10]) <= ulp * 1.0001) and np.all(np.abs(halves[:7] - f16) <= ulp * 1.0001)
+        lo.add(halves[1]); hi.add(halves[4])
+    assert len(lo) == 2 and len(hi) == 2, "over 200 seeds a value between two halves must visit both neighbours"
+
+
 def load_params_1k():
     from fpyv_amd import load_params
     return load_params(fps=1000)
