@@ -102,6 +102,18 @@ def cpu_baseline(params, seconds_budget=12.0):
         oracle.drone_run(params, st1, a1, threads=1, native=True)
     one_core = n1 * a1.shape[0] * reps / (time.perf_counter() - t0)
     del L
+    # the "idiomatic Python" baseline - the same step written with NumPy over a drone axis
+    # (oracle/numpy_port.py, checked against the C oracle in tests/test_numpy_port.py); ~3 s of it
+    from oracle import numpy_port
+    nn = 1 << 16
+    Sn = numpy_port.initial_state(nn, params.init_position, params.init_velocity, params.init_orientation_deg)
+    an = np.ascontiguousarray(acts[:, :nn])
+    numpy_port.step(params, Sn, an[0])
+    t0, np_steps = time.perf_counter(), 0
+    while time.perf_counter() - t0 < 3.0:
+        numpy_port.step(params, Sn, an[np_steps % an.shape[0]])
+        np_steps += 1
+    numpy_rate = nn * np_steps / (time.perf_counter() - t0)
     return {"value": all_cores, "unit": "env-steps/s", "cores": threads, "kind": "port",
             "sample": f"{n} drones x {steps_done} steps of EMA-noise sticks, float64 C restatement of Drone.step "
                       f"(oracle/fpv_oracle.c, gcc -O3 -march=native -fno-tree-vectorize), OpenMP: {threads} threads each walking a contiguous "
@@ -109,6 +121,9 @@ def cpu_baseline(params, seconds_budget=12.0):
                       f"{usable} usable of {os.cpu_count()} logical CPUs: nproc / cgroup quota); reference's own Python Drone.step, timed in the build container only "
                       f"(it cannot travel): 2.7e3-4.0e3 env-steps/s on one core (profiles/r01_reference_python_timing.json)",
             "one_thread_value": one_core, "host_cpus": os.cpu_count(), "usable_cpus": usable, "threads_used": threads,
+            "numpy_vectorised": {"value": numpy_rate, "unit": "env-steps/s", "kind": "port",
+                                 "sample": f"{nn} drones x {np_steps} steps, oracle/numpy_port.py (float64 NumPy over a drone axis: the idiomatic-Python "
+                                           f"batching of Drone.step, SURVEY 8d iii), NumPy {np.__version__} as it threads itself on this host"},
             "scaling_limiter": "the job's CPU share (cgroup quota / affinity), not the code: each thread owns a contiguous drone "
                                "tile whose state stays in its L1/L2, and there is no shared write"}
 
@@ -601,7 +616,9 @@ def main(argv=None):
                 ent = vj.get("kernels", {}).get(fam)
                 if vj.get("kernel_source_sha256_16") != kernel_source_hash():
                     why = "stale: profiles/pmc_valu.json was measured on different kernel sources (re-run tools/pmc_valu.py)"
-                elif ent is None or gather is not None or abs(steps_per_launch - ent["steps_per_launch"]) > 1e-9 or n != vj.get("drones"):
+                elif ent is None or gather is not None or abs(steps_per_launch - ent["steps_per_launch"]) > 0.5 or n != vj.get("drones"):
+                    # (a timed region that starts in the middle of the action ring has one or two shorter launches: the
+                    # average steps per launch may sit a fraction below the ring span the count was taken at)
                     why = "profiles/pmc_valu.json holds no count for this configuration (kernel family / steps per launch / per-step mask rows)"
                 else:
                     inst = ent["valu_per_wave"] / ent["steps_per_launch"]

@@ -350,6 +350,9 @@ __device__ __forceinline__ const FpvRollArgs& fpv_args_again()
 #ifndef FPV_EXP_QUIET_UNROLL
 #define FPV_EXP_QUIET_UNROLL 1
 #endif
+#ifndef FPV_EXP_VCONST
+#define FPV_EXP_VCONST 0
+#endif
 template <bool NOISE, bool OBJ, bool KAHAN, bool SQ = false>
 __global__ __launch_bounds__(kStepBlock) FPV_EXP_ROLL_ATTR void fpv_drone_rollout_kernel(const FpvRollArgs A)
 {
@@ -379,7 +382,7 @@ __global__ __launch_bounds__(kStepBlock) FPV_EXP_ROLL_ATTR void fpv_drone_rollou
 
     // one step on the view V of the arguments.  QUIET steps take their next action unconditionally (there is always
     // a step t + 1 behind a quiet one; a held action - stride 0 - is simply read again: 16 bytes from the cache)
-    auto one_step = [&](const FpvRollArgs& V, const float* ap_next, bool prefetch, int t, auto quiet_c) -> FpvStepOut {
+    auto one_step = [&](const FpvRollArgs& V, const FpvObjects* objs, const float* ap_next, bool prefetch, int t, auto quiet_c) -> FpvStepOut {
         constexpr bool QUIET = decltype(quiet_c)::value;
         av[0] = a_next.x; av[1] = a_next.y; av[2] = a_next.z; av[3] = a_next.w;
         if ((!NOISE || has_action) && (QUIET || prefetch)) a_next = ld_action(reinterpret_cast<const float4*>(ap_next), i);
@@ -391,7 +394,7 @@ __global__ __launch_bounds__(kStepBlock) FPV_EXP_ROLL_ATTR void fpv_drone_rollou
             fpv_stick_noise(N, V.B.step + (uint64_t)t, (uint64_t)i, ns, av);
         }
         FpvStepOut o = fpv_drone_step_lane<OBJ, !QUIET, SQ && QUIET>(V.K, s, av[0], av[1], av[2], av[3], V.B.wx, V.B.wy, V.B.wz,
-                                                                       &V.B.objs, KAHAN ? kc : nullptr);
+                                                                       objs, KAHAN ? kc : nullptr);
         if ((V.K.flags & FPV_FLAG_AUTO_RESET) && o.done) {
             // rare (once per episode and lane): the reset pose comes through its own view, inside the branch
             const FpvRollArgs& Z = fpv_args_again();
@@ -411,10 +414,29 @@ __global__ __launch_bounds__(kStepBlock) FPV_EXP_ROLL_ATTR void fpv_drone_rollou
         const int64_t astride = A.R.action_stride;
         unsigned long long* bp = A.R.bits_stride ? A.B.done_bits : nullptr;
         const int64_t bstride = A.R.bits_stride;
+#if FPV_EXP_VCONST
+        // The physics constants of the loop as VECTOR registers.  On gfx950 a VALU instruction with an SGPR source
+        // issues in ~4.2 cycles per SIMD against ~2.4 for the same instruction on two VGPRs (tools/exp/issue/
+        // issue_probe.hip, profiles/r03_exp_issue_probe.log), and about a quarter of this loop's instructions read
+        // one of these uniforms.  A copy of the arguments whose hot fields went through a "+v" constraint keeps them in
+        // VGPRs for the k steps (one v_mov each, before the loop).
+        FpvRollArgs Q;
+        Q.K = A.K; Q.B.wx = A.B.wx; Q.B.wy = A.B.wy; Q.B.wz = A.B.wz; Q.B.step = A.B.step;
+#define FPV_VREG(x) do { if (!OBJ && !NOISE) asm volatile("" : "+v"(x)); } while (0)
+        FPV_VREG(Q.K.max_rates); FPV_VREG(Q.K.kr); FPV_VREG(Q.K.omkr); FPV_VREG(Q.K.kt); FPV_VREG(Q.K.omkt);
+        FPV_VREG(Q.K.d3); FPV_VREG(Q.K.d2); FPV_VREG(Q.K.d1); FPV_VREG(Q.K.d0);
+        FPV_VREG(Q.K.inv_mass); FPV_VREG(Q.K.g); FPV_VREG(Q.K.kdrag_m[0]); FPV_VREG(Q.K.kdrag_m[1]); FPV_VREG(Q.K.kdrag_m[2]);
+        FPV_VREG(Q.K.half_k); FPV_VREG(Q.K.dt);
+        if (SQ) FPV_VREG(Q.K.motor_c);
+#undef FPV_VREG
+        const FpvRollArgs& QA = Q;
+#else
+        const FpvRollArgs& QA = A;
+#endif
 #pragma unroll FPV_EXP_QUIET_UNROLL
         for (; t < k - 1; ++t) {
             ap += astride;
-            const FpvStepOut o = one_step(A, ap, true, t, std::true_type{});
+            const FpvStepOut o = one_step(QA, &A.B.objs, ap, true, t, std::true_type{});
             if (bp) {
                 const unsigned long long mask = __ballot(o.done);
                 if ((threadIdx.x & 63) == 0) bp[i >> 6] = mask;
@@ -434,7 +456,7 @@ __global__ __launch_bounds__(kStepBlock) FPV_EXP_ROLL_ATTR void fpv_drone_rollou
         if (out.track) { fpv_settle(out.ep_r); fpv_settle(__int_as_float(out.ep_l)); }
         for (; t < kk; ++t) {
             ap += G.R.action_stride;
-            o = one_step(G, ap, G.R.action_stride != 0 && t + 1 < kk, t, std::false_type{});
+            o = one_step(G, &G.B.objs, ap, G.R.action_stride != 0 && t + 1 < kk, t, std::false_type{});
             out.template step<false>(i, t, o.reward, o.done);
         }
         out.finish(i);

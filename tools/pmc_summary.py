@@ -36,7 +36,7 @@ def counters(d):
 
 def main():
     ap = argparse.ArgumentParser()
-    ap.add_argument("--round", default="r02")
+    ap.add_argument("--round", default="r03")
     ap.add_argument("--kt", required=True)
     ap.add_argument("--fetch", required=True)
     ap.add_argument("--write", required=True)
@@ -66,7 +66,7 @@ def main():
     res = {
         "source": f"profiles/{a.round}_pmc_summary.md (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE, separate passes, "
                   f"calibrated on fpv_diag_stream_copy)",
-        "kernel": "fpv_drone_step_kernel<128,1,false>", "drones": a.n,
+        "kernel": "fpv_drone_step_kernel<false, false, false, false> (NOISE, OBJ, KAHAN, OVR off; 128 threads, 1 drone per lane)", "drones": a.n,
         # bench.py reports this traffic only while the kernel sources still hash to this value
         "kernel_source_sha256_16": __import__("bench").kernel_source_hash(),
         "fetch_raw_kib": mean(fe[("step", "FETCH_SIZE")]), "write_raw_kib": mean(wr[("step", "WRITE_SIZE")]),
