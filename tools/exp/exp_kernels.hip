@@ -266,8 +266,8 @@ __global__ __launch_bounds__(128) void k_stagger(const FpvK K, const Buf B, cons
 extern "C" int exp_step(const fpv_params_t* P, float* state, int64_t ld, const float* action, float* reward,
                         uint8_t* done, int64_t n, int variant, int grid_blocks, void* stream)
 {
-    FpvK K; bool big; const char* why;
-    if (fpv_derive_constants(P, &K, &big, &why) != 0) return -1;
+    FpvK K; const char* why;
+    if (fpv_derive_constants(P, &K, &why) != 0) return -1;
     Buf B{state, ld, reinterpret_cast<const float4*>(action), reward, done, 0.f, 0.f, 0.f};
     hipStream_t s = (hipStream_t)stream;
     auto G = [&](int bs) { return dim3((unsigned)((n + bs - 1) / bs)); };
@@ -310,8 +310,8 @@ static bool g_init = false;
 extern "C" int exp_rollout_pipelined(const fpv_params_t* P, float* state, int64_t ld, const float* actions, int64_t action_stride,
                                      float* reward, uint8_t* done, int64_t n, int k, int S, void* stream)
 {
-    FpvK K; bool big; const char* why;
-    if (fpv_derive_constants(P, &K, &big, &why) != 0) return -1;
+    FpvK K; const char* why;
+    if (fpv_derive_constants(P, &K, &why) != 0) return -1;
     if (S < 1 || S > 8) return -2;
     if (!g_init) { for (int i = 0; i < 8; ++i) { hipStreamCreateWithFlags(&g_streams[i], hipStreamNonBlocking); hipEventCreateWithFlags(&g_evs[i], hipEventDisableTiming); }
                    hipEventCreateWithFlags(&g_ev0, hipEventDisableTiming); g_init = true; }
