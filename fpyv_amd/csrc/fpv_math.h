@@ -21,6 +21,7 @@
 
 #include <math.h>
 #include <stdint.h>
+#include <string.h>
 
 #if defined(__HIPCC__)
 #define FPV_HD __host__ __device__ __forceinline__
