@@ -35,11 +35,36 @@ VALU_PEAK_GINST = 256 * 4 * 32 * 2.4   # lane-instructions/ns: 256 CUs x 4 SIMD-
 KERNEL_SOURCES = [os.path.join(REPO, "fpyv_amd", "csrc", f) for f in ("fpv_hip.hip", "fpv_math.h", "fpv_addr.h", "fpv_derive.h")]
 
 
+def _strip_comments(src):
+    """C/C++ source without comments and with runs of white space collapsed (string and character literals are kept
+    verbatim), so that editing a comment does not make a measurement look stale - any change to code does."""
+    out, i, n = [], 0, len(src)
+    while i < n:
+        c = src[i]
+        if c in "\"'":                                       # literal: copy to the closing quote, honouring escapes
+            j = i + 1
+            while j < n and src[j] != c:
+                j += 2 if src[j] == "\\" else 1
+            out.append(src[i:j + 1]); i = j + 1
+        elif src.startswith("//", i):
+            j = src.find("\n", i)
+            i = n if j < 0 else j
+        elif src.startswith("/*", i):
+            j = src.find("*/", i + 2)
+            i = n if j < 0 else j + 2
+            out.append(" ")
+        else:
+            out.append(c); i += 1
+    return " ".join("".join(out).split())
+
+
 def kernel_source_hash():
+    """sha256 (16 hex digits) over the CODE of the kernel sources: comments and white space do not count."""
     h = hashlib.sha256()
     for p in KERNEL_SOURCES:
-        with open(p, "rb") as f:
-            h.update(f.read())
+        with open(p, "r", encoding="utf-8") as f:
+            h.update(_strip_comments(f.read()).encode("utf-8"))
+        h.update(b"\0")
     return h.hexdigest()[:16]
 
 

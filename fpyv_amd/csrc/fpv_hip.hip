@@ -1,16 +1,15 @@
 // fpv_hip.hip - gfx950 kernels + the C ABI of include/fpv_abi.h.
 //
-// One lane = one drone (or DPL drones, strided by the block width so every wave instruction still
-// touches 256 contiguous bytes of each SoA row).  Measured on MI355X at 2^20 drones (tools/exp,
-// profiles/r01_exp_*.log): 128-thread workgroups beat 64/256/512/1024, one drone per lane beats
-// 2/4 (scalar or float2/float4 rows), persistent/grid-stride/prefetch loops lose to plain
-// oversubscription, non-temporal hints on the once-touched operands (action in, reward/done out)
-// are worth ~0.5 %, and a row stride that is NOT a multiple of 8 KiB is worth 6-9 %
-// (fpv_recommended_ld).  A step is: 14 row loads + one 16-byte action
-// load per drone -> ~250 flop in registers (fpv_math.h) -> 14 row stores + reward + done.  There is
-// no reuse, no cross-lane data flow and no dense contraction, so the kernel is bound by HBM / the
-// Infinity Cache; the only wave-level primitive on the data path is the ballot that bit-packs the
-// done mask.  Uniform constants ride in the kernel argument (SGPRs).
+// One lane = one drone: every wave instruction touches 256 contiguous bytes of one SoA row.  Measured on MI355X
+// (tools/exp, profiles/r01_exp_*.log, r03_exp_wide_rows_beyond_mall.log): 128-thread workgroups beat 64/256/512/1024,
+// one drone per lane beats 2/4 with float2/float4 rows at 2^20 AND at 2^23 drones, persistent/grid-stride/prefetch
+// loops lose to plain oversubscription, non-temporal hints on the once-touched operands (action in, reward/done out)
+// are worth ~0.5 %, and a row stride that is NOT a multiple of 8 KiB is worth 6-9 % (fpv_recommended_ld).  A step is:
+// 14 row loads + one 16-byte action load per drone -> ~230 VALU instructions in registers (fpv_math.h) -> 14 row stores
+// + reward + done.  There is no reuse, no cross-lane data flow and no dense contraction, so the single-step kernels are
+// bound by HBM / the Infinity Cache; the k-step kernels (fpv_step_n) keep the drone in registers and are bound by
+// vector-instruction issue.  Wave-level primitives on the data path: the ballot that bit-packs the done mask, the
+// fp16 kernels' DPP pair exchange, the object pass's wave-level cull.  Uniform constants ride in the kernel argument.
 //
 // Replaces, per drone: Drone.step /root/reference/src/utils/components.py:220-248,
 // Drone.reset :150-169, Racer.step /root/reference/tests/racer_drone_test.py:95-103.

@@ -1259,6 +1259,26 @@ def test_c_abi_allgather_done_over_rccl(params_1k):
         assert torch.equal(returns, env.last_return)
         assert L.fpv_allgather_done(comm, None, gathered.data_ptr(), words, stream) == -1
         assert L.fpv_allgather_done(None, bucket.data_ptr(), gathered.data_ptr(), words, stream) == -1
+        # what a benchmark line certifies itself with: world size and rank of the communicator, the RCCL actually loaded
+        ws, rk, ver = C.c_int(-1), C.c_int(-1), C.c_int(-1)
+        _lib.check(L.fpv_comm_info(comm, C.byref(ws), C.byref(rk), C.byref(ver)))
+        assert (ws.value, rk.value) == (1, 0) and ver.value >= 20000, (ws.value, rk.value, ver.value)
+        assert L.fpv_comm_info(None, None, None, None) == -1
+        # the handle's 64-bit step counter through the C ABI
+        cnt = C.c_uint64(0)
+        _lib.check(L.fpv_get_step_counter(env._handle, C.byref(cnt)))
+        assert cnt.value == k
+        _lib.check(L.fpv_set_step_counter(env._handle, (1 << 40) + 7))
+        _lib.check(L.fpv_get_step_counter(env._handle, C.byref(cnt)))
+        assert cnt.value == (1 << 40) + 7
+        # fpv_step_n reads action rows only (ABI 4): SoA sticks are refused with a message, fpv_step takes them
+        b = _lib.FpvBuffers()
+        C.memmove(C.byref(b), C.byref(env._buf), C.sizeof(b))
+        soa = torch.zeros((4, env.ld), device=DEV)
+        b.action, b.action_ld = soa.data_ptr(), env.ld
+        assert L.fpv_step_n(env._handle, C.byref(b), 2, 0, 0, stream) == -1 and b"action rows" in L.fpv_last_error()
+        assert L.fpv_step(env._handle, C.byref(b), stream) == 0
+        torch.cuda.synchronize()
     finally:
         L.fpv_comm_destroy(comm)
     bad = C.c_void_p()
