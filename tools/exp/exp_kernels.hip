@@ -261,6 +261,33 @@ __global__ __launch_bounds__(128) void k_stagger(const FpvK K, const Buf B, cons
     __builtin_nontemporal_store(o.reward, &B.reward[i]); __builtin_nontemporal_store((uint8_t)(o.done ? 1 : 0), &B.done[i]);
     if (LDSB > 0 && B.wx == 54321.f) B.reward[i] = pad[0];
 }
+// V6: "grouped" SoA: the 14 state floats of a drone in FOUR group rows - three float4 rows (px py pz vx) (vy vz qw qx)
+// (qy qz rx ry) and one float2 row (rz thrust) - so that a lane moves its drone with 4 loads + 4 stores of 16 / 8
+// bytes (each wave instruction 1 KiB / 512 B contiguous) instead of 14 + 14 dword accesses: the same bytes in 7
+// memory streams instead of 17.  Group g starts at state + 4 g ld floats.
+typedef float v2f __attribute__((ext_vector_type(2)));
+template <int BS>
+__global__ __launch_bounds__(BS) void k_grp(const FpvK K, const Buf B, const int64_t n)
+{
+    const int64_t i = (int64_t)blockIdx.x * BS + threadIdx.x;
+    if (i >= n) return;
+    v4f* g0 = reinterpret_cast<v4f*>(B.state) + i;
+    v4f* g1 = reinterpret_cast<v4f*>(B.state + 4 * B.ld) + i;
+    v4f* g2 = reinterpret_cast<v4f*>(B.state + 8 * B.ld) + i;
+    v2f* g3 = reinterpret_cast<v2f*>(B.state + 12 * B.ld) + i;
+    const float4 a = nt_load4(&B.action[i]);
+    const v4f r0 = *g0, r1 = *g1, r2 = *g2;
+    const v2f r3 = *g3;
+    __builtin_amdgcn_sched_barrier(0);
+    FpvDroneState s;
+    s.px = r0.x; s.py = r0.y; s.pz = r0.z; s.vx = r0.w; s.vy = r1.x; s.vz = r1.y; s.q.w = r1.z; s.q.x = r1.w;
+    s.q.y = r2.x; s.q.z = r2.y; s.rx = r2.z; s.ry = r2.w; s.rz = r3.x; s.thrust = r3.y;
+    const FpvStepOut o = fpv_drone_step_lane<false>(K, s, a.x, a.y, a.z, a.w, B.wx, B.wy, B.wz);
+    *g0 = v4f{s.px, s.py, s.pz, s.vx}; *g1 = v4f{s.vy, s.vz, s.q.w, s.q.x}; *g2 = v4f{s.q.y, s.q.z, s.rx, s.ry}; *g3 = v2f{s.rz, s.thrust};
+    __builtin_nontemporal_store(o.reward, &B.reward[i]);
+    __builtin_nontemporal_store((uint8_t)(o.done ? 1 : 0), &B.done[i]);
+}
+
 #define STG(id, SL, LB) case id: hipLaunchKernelGGL((k_stagger<SL, LB>), G(128), dim3(128), 0, s, K, B, n); break;
 
 extern "C" int exp_step(const fpv_params_t* P, float* state, int64_t ld, const float* action, float* reward,
@@ -295,6 +322,9 @@ extern "C" int exp_step(const fpv_params_t* P, float* state, int64_t ld, const f
         case 301: hipLaunchKernelGGL((k_aos_lds<128, true>), G(128), dim3(128), 0, s, K, state, B.action, n, 0.f, 0.f, 0.f); break;
         case 302: hipLaunchKernelGGL((k_aos_lds<256, false>), G(256), dim3(256), 0, s, K, state, B.action, n, 0.f, 0.f, 0.f); break;
         case 303: hipLaunchKernelGGL((k_aos_lds<64, false>), G(64), dim3(64), 0, s, K, state, B.action, n, 0.f, 0.f, 0.f); break;
+        case 500: hipLaunchKernelGGL((k_grp<128>), G(128), dim3(128), 0, s, K, B, n); break;
+        case 501: hipLaunchKernelGGL((k_grp<256>), G(256), dim3(256), 0, s, K, B, n); break;
+        case 502: hipLaunchKernelGGL((k_grp<64>), G(64), dim3(64), 0, s, K, B, n); break;
         STG(400, 0, 0) STG(401, 20, 0) STG(402, 50, 0) STG(403, 100, 0) STG(404, 200, 0) STG(405, 400, 0)
         STG(410, 0, 20480) STG(411, 0, 40960) STG(412, 0, 10240) STG(413, 50, 20480)
         default: return -2;

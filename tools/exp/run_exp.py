@@ -53,6 +53,12 @@ def main():
     def reset_aos():
         v = backing[a.offset:a.offset + 16 * n].view(n, 16)
         v.zero_(); v[:, 2] = 10; v[:, 3] = 1; v[:, 6] = 1
+    def reset_grp(pad):                       # variants 500+: four group rows (see k_grp): pz = 10, vx = 1, qw = 1
+        ld = n + pad
+        flat = backing[a.offset:a.offset + 14 * ld]
+        flat.zero_()
+        g0 = flat[:4 * ld].view(ld, 4); g1 = flat[4 * ld:8 * ld].view(ld, 4)
+        g0[:, 2] = 10; g0[:, 3] = 1; g1[:, 2] = 1
     cases = [(v, pad) for pad in pads for v in variants]
     times = {c: [] for c in cases}
     e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
@@ -62,7 +68,8 @@ def main():
             v, pad = c
             st, ld = view(pad)
             reset(st)
-            if v[0] >= 300: reset_aos()
+            if 300 <= v[0] < 400: reset_aos()
+            if v[0] >= 500: reset_grp(pad)
             torch.cuda.synchronize(); e0.record()
             for t in range(a.launches):
                 rc = L.exp_step(C.byref(cp), st.data_ptr(), ld, acts[t % a.ring].data_ptr(), reward.data_ptr(), done.data_ptr(), n, v[0], v[1], None)
@@ -70,7 +77,13 @@ def main():
             e1.record(); torch.cuda.synchronize()
             if r: times[c].append(e0.elapsed_time(e1) * 1e3 / a.launches)
             if a.check and r == a.rounds:
-                finals[c] = (backing[a.offset:a.offset + 16 * n].view(n, 16)[:, :14].t().clone() if v[0] >= 300 else st[:, :n].clone())
+                if v[0] >= 500:
+                    ld_ = n + pad
+                    flat = backing[a.offset:a.offset + 14 * ld_]
+                    finals[c] = torch.cat([flat[:4 * ld_].view(ld_, 4)[:n], flat[4 * ld_:8 * ld_].view(ld_, 4)[:n], flat[8 * ld_:12 * ld_].view(ld_, 4)[:n],
+                                           flat[12 * ld_:14 * ld_].view(ld_, 2)[:n]], dim=1).t().clone()
+                else:
+                    finals[c] = (backing[a.offset:a.offset + 16 * n].view(n, 16)[:, :14].t().clone() if v[0] >= 300 else st[:, :n].clone())
     res = []
     for c in cases:
         v, pad = c
