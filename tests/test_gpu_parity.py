@@ -123,6 +123,39 @@ def test_bitwise_equal_to_lane_model_ragged_sizes(params_1k, n):
     assert np.all(got[:, n:] == 0), "padding columns beyond n must stay untouched"
 
 
+def test_edge_inputs_bitwise_equal_to_lane_model(params_1k):
+    """The two places where the kernel does NOT execute the host's instructions - the clip (one v_med3_f32 against
+    fminf(fmaxf())) and the square root (v_sqrt_f32 + correction, arguments below the smallest normal flushed to zero,
+    against sqrtf) - on the inputs a flight never produces: NaN and infinite sticks, sticks far outside [-1, 1],
+    velocities whose square is subnormal, sits on the flush boundary, or is near the top of the fp32 range."""
+    vels = np.array([[0, 0, 0], [1e-30, 0, 0], [1e-20, -1e-20, 1e-21], [1.05e-19, 0, 0], [1.1e-19, 0, 0], [7.7e-20, 7.7e-20, 0],
+                     [1e-15, 0, 0], [3e18, -2e18, 1e18], [1e19, 0, 0], [-0.0, 0.0, -0.0]], dtype=np.float32)
+    sticks_ = np.array([[np.nan, 0, 0, 0], [0, np.nan, np.nan, -0.5], [np.inf, -np.inf, 1e30, 0.2], [5, -7, 1.0000001, -1.5],
+                        [-1, 1, -1, 1], [0, 0, 0, 0]], dtype=np.float32)
+    n = len(vels) * len(sticks_)
+    vel = np.repeat(vels, len(sticks_), axis=0)
+    act = np.tile(sticks_, (len(vels), 1))[None].repeat(3, axis=0).copy()          # three steps of the same sticks
+    for fused in (False, True):
+        env = _drone_batch(params_1k, n)
+        env.reset(velocity=vel)
+        a = torch.from_numpy(act).to(DEV)
+        if fused:
+            env.rollout(a)
+        else:
+            for t in range(3):
+                env.step(a[t], wind_velocity_vector=(0.0, 0.0, 0.0), return_imu=False)
+        torch.cuda.synchronize()
+        model = lane_model.initial_state(params_1k, n, velocity=vel)
+        _, acc, done, rew = lane_model.run(params_1k, model, act)
+        got = env.state.cpu().numpy()[:, :n]
+        both_nan = np.isnan(got) & np.isnan(model[:, :n])                          # a NaN's payload is not part of the contract
+        same = (got.view(np.uint32) == model[:, :n].view(np.uint32)) | both_nan
+        assert same.all(), (fused, np.argwhere(~same)[:5], got[~same][:5], model[:, :n][~same][:5])
+        # NaN rate sticks come out of the clip as -max_rates on both sides (fminf(fmaxf(NaN, lo), hi) = lo = v_med3's answer)
+        np.testing.assert_allclose(got[10, 0::len(sticks_)], -0.7 * params_1k.max_rates * (1 + 0.3 + 0.09), rtol=1e-6)
+        assert np.array_equal(env.done_u8.cpu().numpy(), done)
+
+
 def test_config2_4096_drones_vs_oracle(params_1k):
     """BASELINE config 2: 4096 drones, constant throttle + sinusoidal roll/pitch, 1000 steps."""
     n, T = 4096, 1000
