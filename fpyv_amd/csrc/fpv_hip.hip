@@ -991,7 +991,8 @@ int check_buffers(const fpv_env* h, const fpv_buffers_t* b, bool need_action)  /
     return FPV_OK;
 }
 
-FpvBufD to_device_view(const fpv_buffers_t* b)
+// `reach` = the handle's K.contact_reach: the bounds of the object list are grown by it (fpv_objects_bounds)
+FpvBufD to_device_view(const fpv_buffers_t* b, float reach)
 {
     FpvBufD d;
     memset(&d, 0, sizeof(d));          // padding bytes are part of the graph-cache key
@@ -1013,6 +1014,7 @@ FpvBufD to_device_view(const fpv_buffers_t* b)
             d.objs.o[k].type = o.type; d.objs.o[k].x = o.x; d.objs.o[k].y = o.y; d.objs.o[k].z = o.z;
             d.objs.o[k].radius = o.radius; d.objs.o[k].height = o.height;
         }
+        fpv_objects_bounds(d.objs, reach);
     }
     return d;
 }
@@ -1249,7 +1251,7 @@ int fpv_reset(fpv_handle_t h, const fpv_buffers_t* b, const uint8_t* mask, const
     const DeviceGuard dev(h->device);
     if (dev.rc != FPV_OK) return dev.rc;
     const dim3 grid((unsigned)((h->n + kBlock - 1) / kBlock));
-    hipLaunchKernelGGL(fpv_reset_kernel, grid, dim3(kBlock), 0, (hipStream_t)stream, h->K, to_device_view(b),
+    hipLaunchKernelGGL(fpv_reset_kernel, grid, dim3(kBlock), 0, (hipStream_t)stream, h->K, to_device_view(b, h->K.contact_reach),
                        h->mode, mask, position, velocity, ypr_deg, h->n);
     const hipError_t e = hipGetLastError();
     if (e != hipSuccess) return hip_fail(e, "reset kernel launch");
@@ -1262,7 +1264,7 @@ int fpv_step(fpv_handle_t h, const fpv_buffers_t* b, void* stream)
     if (rc != FPV_OK) return rc;
     const DeviceGuard dev(h->device);
     if (dev.rc != FPV_OK) return dev.rc;
-    return launch_step(h, to_device_view(b), (hipStream_t)stream);
+    return launch_step(h, to_device_view(b, h->K.contact_reach), (hipStream_t)stream);
 }
 
 int fpv_rollout(fpv_handle_t h, const fpv_buffers_t* b, int k, int64_t action_stride, int64_t out_stride,
@@ -1275,7 +1277,7 @@ int fpv_rollout(fpv_handle_t h, const fpv_buffers_t* b, int k, int64_t action_st
     if (b->rotation_override) return fail(FPV_EINVAL, "the guidance override is a per-step input: use fpv_step");
     const DeviceGuard dev(h->device);
     if (dev.rc != FPV_OK) return dev.rc;
-    FpvBufD d = to_device_view(b);
+    FpvBufD d = to_device_view(b, h->K.contact_reach);
     const float* a0 = b->action;
     for (int t = 0; t < k; ++t) {
         d.action = a0 ? reinterpret_cast<const float4*>(a0 + (int64_t)t * action_stride) : nullptr;
@@ -1324,7 +1326,7 @@ int fpv_step_n(fpv_handle_t h, const fpv_buffers_t* b, int k, int64_t action_str
     if (b->rotation_override) return fail(FPV_EINVAL, "the guidance override is a per-step input: use fpv_step");
     const DeviceGuard dev(h->device);
     if (dev.rc != FPV_OK) return dev.rc;
-    FpvBufD d = to_device_view(b);
+    FpvBufD d = to_device_view(b, h->K.contact_reach);
     d.step = h->launches;
     h->launches += (uint64_t)k;
     FpvRoll R;
@@ -1379,7 +1381,7 @@ int fpv_rollout_graph(fpv_handle_t h, const fpv_buffers_t* b, int k, int64_t act
     if (h->K.flags & (FPV_FLAG_STICK_NOISE | FPV_FLAG_FP16_STATE)) return fpv_step_n(h, b, k, action_stride, out_stride, stream);
     const DeviceGuard dev(h->device);
     if (dev.rc != FPV_OK) return dev.rc;
-    const FpvBufD d0 = to_device_view(b);
+    const FpvBufD d0 = to_device_view(b, h->K.contact_reach);
     // SHAPE of the graph: everything that selects kernels, grids and non-pointer arguments
     const KernelChoice c0 = choose_kernel(h, d0);
     std::string shape(reinterpret_cast<const char*>(&h->K), sizeof(h->K));

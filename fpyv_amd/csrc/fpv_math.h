@@ -495,7 +495,31 @@ struct FpvStepOut {
 #define FPV_MAX_OBJECTS 8
 #endif
 struct FpvObject { int32_t type; float x, y, z, radius, height; };      // type: 0 Ground, 1 Cylinder, 2 Target
-struct FpvObjects { int32_t count; FpvObject o[FPV_MAX_OBJECTS]; };
+// `has_ground`, `lo`, `hi`: a conservative summary of the whole list for ONE wave-level test before the per-object
+// pass - a drone whose centre is neither within contact reach of the ground plane (if the list has one) nor inside the
+// axis-aligned box around every cylinder and sphere (grown by the contact reach) cannot touch anything: filled by
+// fpv_objects_bounds() on the host, for the kernel and for the lane model alike.
+struct FpvObjects { int32_t count; int32_t has_ground; float lo[3], hi[3]; FpvObject o[FPV_MAX_OBJECTS]; };
+
+// `reach` = K.contact_reach (arm + motor_radius + 1 mm).  The box is grown by a little more than the reach so that
+// fp32 rounding of the bounds can only make the test MORE conservative; an empty box (no cylinder / sphere) is lo > hi.
+static inline void fpv_objects_bounds(FpvObjects& T, float reach)
+{
+    T.has_ground = 0;
+    for (int c = 0; c < 3; ++c) { T.lo[c] = 3.0e38f; T.hi[c] = -3.0e38f; }
+    for (int k = 0; k < T.count; ++k) {
+        const FpvObject& ob = T.o[k];
+        if (ob.type == 0) { T.has_ground = 1; continue; }
+        const float r = fabsf(ob.radius) + reach, m = 1.0e-3f;
+        const float cl[3] = {ob.x - r, ob.y - r, ob.type == 1 ? ob.z - reach : ob.z - r};
+        const float ch[3] = {ob.x + r, ob.y + r, ob.type == 1 ? ob.z + fabsf(ob.height) + reach : ob.z + r};
+        for (int c = 0; c < 3; ++c) {
+            const float l = cl[c] - m - 1.0e-6f * fabsf(cl[c]), h = ch[c] + m + 1.0e-6f * fabsf(ch[c]);
+            if (l < T.lo[c]) T.lo[c] = l;
+            if (h > T.hi[c]) T.hi[c] = h;
+        }
+    }
+}
 
 // wave-level "does any lane need this": on the device one ballot, on the host the lane's own flag
 #if defined(__HIP_DEVICE_COMPILE__)
@@ -522,6 +546,13 @@ FPV_HD bool fpv_collide_objects(const FpvK& K, const FpvObjects& T, const FpvRot
     bool crashed = false;
     acc[0] = acc[1] = acc[2] = 0.0f;
     const float reach = K.contact_reach;       // arm + motor_radius + 1 mm: no motor can touch beyond this
+    // one test for the whole list first (see FpvObjects): the common wave - nobody near anything - leaves here with a
+    // dozen instructions and ONE ballot instead of a cull and a ballot per object (1.7 us of a 24 us kernel in round 2)
+    {
+        const bool maybe = (T.has_ground != 0 && cz < reach)
+                           || (cx > T.lo[0] && cx < T.hi[0] && cy > T.lo[1] && cy < T.hi[1] && cz > T.lo[2] && cz < T.hi[2]);
+        if (!FPV_WAVE_ANY(maybe)) return false;
+    }
     for (int o = 0; o < T.count && !crashed; ++o) {
         const FpvObject& ob = T.o[o];
         // cheap conservative cull on the drone centre; a whole wave with nobody near skips the

@@ -17,7 +17,7 @@ extern "C" {
 
 // state: [rows][ld] SoA like the product.  actions: [steps][n][4] (per_step) or [n][4] held.
 // accel: [3][ld] or NULL; done/reward: [n] or NULL (last step's values).  Returns 0 or FPV_E*.
-static FpvObjects g_objs = {0, {}};
+static FpvObjects g_objs = {0, 0, {0, 0, 0}, {0, 0, 0}, {}};
 static float* g_pos_comp = nullptr;      // [6][ld] Kahan compensation rows (p, v) used by subsequent fpvl_run calls, or null
 void fpvl_set_pos_comp(float* c) { g_pos_comp = c; }
 // guidance override ([n][9] rotation matrices, [n] thrust forces) applied on every step of subsequent fpvl_run calls, or null
@@ -49,6 +49,7 @@ int fpvl_run(const fpv_params_t* P, int64_t n, int steps, float* st, int64_t ld,
     // the two-height ground flag of the k-step kernels' X-frame loop (fpv_drone_step_lane<.., SQ = true>) is used
     // here whenever its precondition holds, unless a test asks for the four-height form
     const bool sq = K.motor_square && !(K.flags & FPV_FLAG_GROUND) && g_objs.count == 0 && !g_general_motors;
+    fpv_objects_bounds(g_objs, K.contact_reach);          // the list-level test of the collision pass, as the kernel's host side fills it
     for (int64_t i = 0; i < n; ++i) {
         if (P->mode == FPV_MODE_DRONE) {
             FpvDroneState s;
