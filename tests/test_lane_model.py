@@ -358,6 +358,59 @@ def test_config0_default_fps60_10k_steps_with_kahan_compensation(params_60):
     assert worst < 1e-6, worst
 
 
+def test_object_culls_never_skip_a_contact(params_1k):
+    """The collision pass skips work three times over - a list-level test (ground reach + the box around all cylinders and
+    spheres), a per-object test on the drone's centre, and lazily formed contact normals.  Every one of them must be
+    CONSERVATIVE: a culled drone gets exactly zero object force and no crash flag, so a cull that is too tight shows up
+    as a missing force against the float64 oracle, which culls nothing.  20 000 drones placed within +-0.6 m of every
+    surface and every cull boundary of a five-object world, random attitudes, one step."""
+    rng = np.random.default_rng(77)
+    objs = ((2, 1.5, -2.0, 3.0, 0.8, 0.0), (1, 3.0, 0.5, 0.0, 1.0, 5.0), (1, -2.0, 2.5, 1.0, 0.6, 1.5), (2, -4.0, -4.0, 0.3, 0.5, 0.0), (0, 0, 0, 0, 0, 0))
+    reach = float(np.linalg.norm(params_1k.motor_xy, axis=1).max() + params_1k.motor_radius + 1e-3)
+    pts = []
+    for (t, x, y, z, r, h) in objs[:-1]:
+        m = 4000
+        d = rng.normal(size=(m, 3)); d /= np.linalg.norm(d, axis=1, keepdims=True)
+        if t == 2:
+            rad = r + rng.choice([0.0, reach], m) + rng.uniform(-0.6, 0.6, m)
+            pts.append(np.array([x, y, z]) + d * rad[:, None])
+        else:
+            ang = rng.uniform(0, 2 * np.pi, m)
+            rad = r + rng.choice([0.0, reach], m) + rng.uniform(-0.6, 0.6, m)
+            zz = np.where(rng.random(m) < 0.5, rng.uniform(z - reach - 0.6, z + h + reach + 0.6, m),
+                          rng.choice([z, z + h], m) + rng.choice([0.0, -reach, reach], m) + rng.uniform(-0.3, 0.3, m))
+            rad = np.where(rng.random(m) < 0.3, rng.uniform(0, r + reach + 0.6, m), rad)        # also above / below the caps
+            pts.append(np.stack([x + rad * np.cos(ang), y + rad * np.sin(ang), zz], axis=1))
+    g = np.stack([rng.uniform(-6, 6, 4000), rng.uniform(-6, 6, 4000), rng.choice([0.0, reach], 4000) + rng.uniform(-0.3, 0.3, 4000)], axis=1)
+    pos = np.concatenate(pts + [g]).astype(np.float32)
+    n = len(pos)
+    ypr = rng.uniform([-180, -80, -180], [180, 80, 180], (n, 3))
+    vel = rng.normal(size=(n, 3)) * 3
+    p = params_1k.replace(objects=objs)
+    act = np.zeros((1, n, 4), dtype=np.float32)
+    ref = oracle.drone_initial_state(n, pos.astype(np.float64), vel, ypr)
+    s = lane_model.initial_state(params_1k, n, pos, vel, ypr)
+    v0 = ref[:, 3:6].copy()
+    _, _, ref_done = oracle.drone_run(p, ref, act.astype(np.float64))
+    try:
+        lane_model.set_objects(objs)
+        _, _, done, _ = lane_model.run(params_1k, s, act)
+    finally:
+        lane_model.set_objects(())
+    # a flag may legitimately differ only where a float64 distance is within fp32 rounding of zero
+    differ = np.flatnonzero(done != ref_done)
+    assert len(differ) <= 5, len(differ)
+    # the velocity change of one step IS the acceleration (incl. the spring forces): a skipped contact is off by ~k d / m dt
+    dv, dv_ref = s[3:6, :n].T - v0.astype(np.float32), ref[:, 3:6] - v0
+    keep = np.setdiff1d(np.arange(n), differ)
+    assert np.abs(dv[keep] - dv_ref[keep]).max() < 2e-5, np.abs(dv[keep] - dv_ref[keep]).max()
+    # the scenario is what it claims: many drones feel a spring, many crash, many do neither
+    free = oracle.drone_initial_state(n, pos.astype(np.float64), vel, ypr)
+    oracle.drone_run(params_1k, free, act.astype(np.float64))
+    springs = np.linalg.norm(ref[:, 3:6] - free[:, 3:6], axis=1) > 1e-6
+    assert springs.sum() > 500 and ref_done.sum() > 500 and (~ref_done.astype(bool) & ~springs).sum() > 500, (springs.sum(), ref_done.sum())
+
+
 def test_guidance_override_fp32(params_1k):
     """The kernel's fp32 arithmetic for Drone.step(..., rotation_matrix=, thrust_force=) (matrix -> quaternion by
     Shepperd's method, then the usual step) against the reference capture G13, every step of every case."""
