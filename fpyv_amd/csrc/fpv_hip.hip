@@ -560,11 +560,13 @@ __device__ __forceinline__ void st_packed_h(const FpvBufD& B, uint32_t i, const 
     for (int k = 0; k < FPV_HALF_PAIR_ROWS; ++k) row_at(ROW(sh, k, B.ld), i) = h.w[k];
 }
 
-// packs and stores the position and pair rows; returns the new thrust half (the caller completes the pair)
-__device__ __forceinline__ uint32_t st_drone_h(const FpvBufD& B, uint32_t i, uint32_t seed, const FpvDroneState& s)
+// packs and stores the position and pair rows; returns the new thrust half (the caller completes the pair).
+// `id0` = low word of the global id of this shard's drone 0: the rounding stream of a drone is keyed by its GLOBAL id
+// (like its stick-noise stream), so a drone's fp16 trajectory does not depend on the shard or lane it lands in.
+__device__ __forceinline__ uint32_t st_drone_h(const FpvBufD& B, uint32_t i, uint32_t id0, uint32_t seed, const FpvDroneState& s)
 {
     FpvHalfState h;
-    fpv_pack_half(s, seed, (uint32_t)i, h);
+    fpv_pack_half(s, seed, id0 + (uint32_t)i, h);
     st_packed_h(B, i, s, h);
     return h.t;
 }
@@ -595,7 +597,7 @@ __global__ __launch_bounds__(kStepBlock) void fpv_drone_step_h_kernel(const FpvK
             row_at(ROW(B.accel, 0, B.ld), i) = o.ax; row_at(ROW(B.accel, 1, B.ld), i) = o.ay; row_at(ROW(B.accel, 2, B.ld), i) = o.az;
         }
         if ((K.flags & FPV_FLAG_AUTO_RESET) && o.done) fpv_drone_reset_lane(K, s);
-        th = st_drone_h(B, i, fpv_round_seed(B.seed, B.step), s);
+        th = st_drone_h(B, i, K.noise.id_lo, fpv_round_seed(B.seed, B.step), s);
     }
     st_thrust_pair_h(B, i, live, th);
     emit_outputs(B, i, live, o.reward, o.done);
@@ -628,7 +630,7 @@ __global__ __launch_bounds__(kStepBlock) void fpv_drone_rollout_h_kernel(const F
             const FpvRollArgs& Z = fpv_args_again();
             fpv_drone_reset_lane(Z.K, s);
         }
-        fpv_pack_half(s, fpv_round_seed(V.B.seed, V.B.step + (uint64_t)t), (uint32_t)i, h);   // the HBM round trip of a single step, in registers
+        fpv_pack_half(s, fpv_round_seed(V.B.seed, V.B.step + (uint64_t)t), V.K.noise.id_lo + (uint32_t)i, h);   // the HBM round trip of a single step, in registers
         if (QUIET || widen) fpv_unpack_half(h, s);
         return o;
     };
@@ -825,7 +827,7 @@ __global__ __launch_bounds__(kBlock) void fpv_reset_kernel(const FpvK K, const F
         }
         if (K.flags & FPV_FLAG_FP16_STATE) {
             // masked lanes are independent here, so the thrust half goes out as a 2-byte store (not a hot path)
-            const uint32_t th = st_drone_h(B, (uint32_t)i, B.seed, s);
+            const uint32_t th = st_drone_h(B, (uint32_t)i, K.noise.id_lo, B.seed, s);
             reinterpret_cast<uint16_t*>(const_cast<uint32_t*>(thrust_row_h(B)))[i] = (uint16_t)th;
         } else {
             st_drone(B.state, B.ld, i, s);

@@ -152,7 +152,7 @@ extern "C" int fpvl_run_h(const fpv_params_t* P, int64_t n, int steps, float* po
             const float* a = actions + ((per_step ? (int64_t)t * n : 0) + i) * 4;
             o = fpv_drone_step_lane<false, true, false, false>(K, s, a[0], a[1], a[2], a[3], wind[0], wind[1], wind[2]);
             if ((K.flags & FPV_FLAG_AUTO_RESET) && o.done) fpv_drone_reset_lane(K, s);
-            fpv_pack_half(s, fpv_round_seed(seed0, step0 + (uint64_t)t), (uint32_t)i, h);
+            fpv_pack_half(s, fpv_round_seed(seed0, step0 + (uint64_t)t), K.noise.id_lo + (uint32_t)i, h);     // keyed by the GLOBAL drone id
             pos[0 * ld + i] = s.px; pos[1 * ld + i] = s.py; pos[2 * ld + i] = s.pz;
             for (int k = 0; k < FPV_HALF_PAIR_ROWS; ++k) sh[k * ld + i] = h.w[k];
             thrust[i] = h.t;

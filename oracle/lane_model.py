@@ -119,7 +119,8 @@ def run(p, state: np.ndarray, actions: np.ndarray, steps: Optional[int] = None, 
 
 
 def run_h(p, pos: np.ndarray, sh: np.ndarray, actions: np.ndarray, steps: Optional[int] = None,
-          wind=(0.0, 0.0, 0.0), seed0: int = 0, n: Optional[int] = None, auto_reset: bool = False, step0: int = 0):
+          wind=(0.0, 0.0, 0.0), seed0: int = 0, n: Optional[int] = None, auto_reset: bool = False, step0: int = 0,
+          drone_id_offset: int = 0):
     """fp16-storage variant: pos [3, ld] float32 and sh [11 * ld] uint16 (binary16 bits in the layout of
     fpv_abi.h: five half2 pair rows, then one row of thrust halves), advanced in place exactly like
     fpv_drone_step_h_kernel; step t rounds with fpv_round_seed(seed0, step0 + t) (seed0 = the buffer's rounding_seed,
@@ -146,7 +147,7 @@ def run_h(p, pos: np.ndarray, sh: np.ndarray, actions: np.ndarray, steps: Option
     done = np.zeros(n, dtype=np.uint8)
     reward = np.zeros(n, dtype=np.float32)
     w = np.asarray(wind, dtype=np.float32)
-    cp = abi.pack_params(p, auto_reset=auto_reset, fp16_state=True)
+    cp = abi.pack_params(p, auto_reset=auto_reset, fp16_state=True, drone_id_offset=drone_id_offset)
     fp = lambda a: a.ctypes.data_as(C.POINTER(C.c_float))  # noqa: E731
     rc = L.fpvl_run_h(C.byref(cp), n, steps, fp(pos), sh.ctypes.data, ld, fp(actions),
                       int(per_step), fp(w), int(seed0) & 0xFFFFFFFF, done.ctypes.data_as(C.POINTER(C.c_uint8)), fp(reward),

@@ -628,6 +628,40 @@ def test_fp16_device_conversions_equal_the_host_emulation_on_special_values(para
         assert (int(got[1, i, 0]), int(got[1, i, 1])) == want[1], (i, vel[i], got[1, i], [hex(x) for x in want[1]])
 
 
+@pytest.mark.parametrize("fused", [False, True], ids=["single-step", "k-step"])
+def test_fp16_state_is_shard_invariant(params_1k, fused):
+    """The stochastic rounding of a drone is keyed by its GLOBAL id (drone_id_offset + lane), like its stick-noise stream:
+    the fp16 trajectory of a drone must not depend on the shard it lands in or on its lane (round 2 keyed it by the
+    local lane index).  One batch of 3000 drones against the same drones as shards of 1000 / 77 / 1923."""
+    n, steps = 3000, 120
+    acts = sticks.ema_noise(steps, range(n), seed=5)
+    a = torch.from_numpy(acts).to(DEV)
+
+    def run(lo, hi):
+        env = _drone_batch(params_1k, hi - lo, fp16_state=True, rounding_seed=3, with_accel=False, drone_id_offset=lo)
+        env.reset()
+        sub = a[:, lo:hi].contiguous()
+        if fused:
+            env.rollout(sub)
+        else:
+            for t in range(steps):
+                env.step(sub[t], return_imu=False)
+        torch.cuda.synchronize()
+        m = hi - lo
+        half = env.state_h.cpu().numpy().view(np.uint16)
+        ld = env.ld
+        return env.state.cpu().numpy()[:, :m], half[:10 * ld].reshape(5, ld, 2)[:, :m], half[10 * ld:10 * ld + m]
+
+    whole = run(0, n)
+    for lo, hi in ((0, 1000), (1000, 1077), (1077, 3000)):
+        part = run(lo, hi)
+        assert np.array_equal(part[0].view(np.uint32), whole[0][:, lo:hi].view(np.uint32)), (lo, hi)
+        assert np.array_equal(part[1], whole[1][:, lo:hi]) and np.array_equal(part[2], whole[2][lo:hi]), (lo, hi)
+    pos, sh = lane_model.split_half(lane_model.initial_state(params_1k, 77))
+    lane_model.run_h(params_1k, pos, sh, acts[:, 1000:1077], seed0=3, drone_id_offset=1000)
+    assert np.array_equal(whole[0][:, 1000:1077].view(np.uint32), pos[:, :77].view(np.uint32)), "and the host build agrees on the keyed stream"
+
+
 def test_fp16_state_full_size_vs_fp32_run():
     """Config 4 at full size: same sticks through the fp32 and the fp16-storage kernels; the
     distribution of the difference after 500 steps must sit inside the restated tolerance."""
