@@ -1122,11 +1122,12 @@ KernelChoice choose_kernel(const fpv_env* h, const FpvBufD& d)
 int launch_step(fpv_env* h, const FpvBufD& d_in, hipStream_t s)
 {
     FpvBufD d = d_in;
-    d.step = h->launches++;
+    d.step = h->launches;
     const KernelChoice c = choose_kernel(h, d);
     hipLaunchKernelGGL(c.func, dim3(c.grid), dim3(c.block), 0, s, h->K, d, h->n);
     const hipError_t e = hipGetLastError();
     if (e != hipSuccess) return hip_fail(e, "step kernel launch");
+    ++h->launches;                     // a refused launch leaves the step index where it was
     return FPV_OK;
 }
 
@@ -1330,7 +1331,6 @@ int fpv_step_n(fpv_handle_t h, const fpv_buffers_t* b, int k, int64_t action_str
     if (dev.rc != FPV_OK) return dev.rc;
     FpvBufD d = to_device_view(b, h->K.contact_reach);
     d.step = h->launches;
-    h->launches += (uint64_t)k;
     FpvRoll R;
     R.k = k; R.pad = 0; R.action_stride = action_stride; R.out_stride = out_stride; R.bits_stride = b->done_bits_stride;
     const RollKernel f = choose_rollout_kernel(h, d);
@@ -1341,6 +1341,7 @@ int fpv_step_n(fpv_handle_t h, const fpv_buffers_t* b, int k, int64_t action_str
     hipLaunchKernelGGL(f, dim3(grid), dim3(kStepBlock), 0, (hipStream_t)stream, args);
     const hipError_t e = hipGetLastError();
     if (e != hipSuccess) return hip_fail(e, "k-step kernel launch");
+    h->launches += (uint64_t)k;
     return FPV_OK;
 }
 
