@@ -200,12 +200,13 @@ def lib() -> C.CDLL:
     L.fpv_error_name.argtypes = [C.c_int]
     L.fpv_error_name.restype = C.c_char_p
     L.fpv_sizeof.argtypes = [C.c_int]
+    if L.fpv_abi_version() != FPV_ABI_VERSION:
+        raise ImportError(f"libfpv_hip.so ABI {L.fpv_abi_version()} != binding {FPV_ABI_VERSION} - rebuild the library "
+                          "(`python -c 'import __graft_entry__ as g; g.build()'`)")
     for which, struct in ((0, FpvParams), (1, FpvBuffers), (2, FpvObjects), (3, FpvPidParams)):
         if L.fpv_sizeof(which) != C.sizeof(struct):
             raise ImportError(f"{struct.__name__}: ctypes declares {C.sizeof(struct)} bytes, libfpv_hip.so has "
                               f"{L.fpv_sizeof(which)} - _lib.py and include/fpv_abi.h are out of step")
-    if L.fpv_abi_version() != FPV_ABI_VERSION:
-        raise ImportError(f"libfpv_hip.so ABI {L.fpv_abi_version()} != binding {FPV_ABI_VERSION}")
     _lib = L
     return L
 

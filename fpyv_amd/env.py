@@ -253,6 +253,13 @@ class _Batch:
                                      self._stream()))
         self._keepalive_reset = (pos, vel, ang, m)
 
+    def set_objects(self, object_list) -> None:
+        """The collision world of the following `rollout` calls: the same `object_list` a `step` takes, bound until it
+        is replaced.  (`step` binds its own argument on every call, like the reference's Drone.step does - an empty
+        default there clears what was bound here.)  The table is read on the host when a launch is enqueued: objects
+        that move (Target) are re-bound by the caller after each update, exactly as the reference re-passes the list."""
+        self._set_objects(object_list)
+
     def _set_objects(self, object_list) -> None:
         """Bind the step's object_list (host-side table, read by fpv_step during the call)."""
         if object_list is None or not len(object_list):
@@ -305,16 +312,20 @@ class _Batch:
 
     def rollout(self, actions: Optional[torch.Tensor], wind: Optional[Sequence[float]] = None,
                 rewards: Optional[torch.Tensor] = None, dones: Optional[torch.Tensor] = None,
-                steps: Optional[int] = None, graph: Optional[bool] = None, fused: Optional[bool] = None) -> None:
+                steps: Optional[int] = None, graph: Optional[bool] = None, fused: Optional[bool] = None,
+                object_list: Any = None) -> None:
         """k steps without returning to Python: actions [k, num_envs, 4] (one batch per step) or
         [num_envs, 4] with `rewards`/`dones` of shape [k, num_envs] (or `steps`) giving k; actions=None
-        with stick_noise=True runs `steps` steps of pure in-kernel noise sticks.
+        with stick_noise=True runs `steps` steps of pure in-kernel noise sticks.  `object_list` (what `step`
+        takes) is the collision world of all k steps; None keeps whatever `set_objects` / the last `step` bound.
 
         fused (default): ONE launch of the k-step kernel (fpv_step_n) - the drone stays in registers for
         the k steps; results are bit-identical to k single steps.  fused=False issues k single-step
         launches from one C call (fpv_rollout); graph=True replays those launches from a hipGraph cached
         in the handle (fpv_rollout_graph)."""
         b = self._buf
+        if object_list is not None:
+            self._set_objects(object_list)
         if actions is None:
             if not self.stick_noise or steps is None:
                 raise ValueError("actions=None needs stick_noise=True and steps=k")
@@ -567,6 +578,8 @@ class FpvVecEnv:
         """`batch_options` go to DroneBatch / RacerBatch (stick_noise=, noise_seed=, drone_id_offset=,
         fp16_state=, with_obs_aos=, kahan_position=, with_done_bits=, ...); `object_list` is the
         collision world of every step (fpyv_amd.objects)."""
+        if mode not in ("drone", "racer"):
+            raise ValueError(f'mode must be "drone" or "racer", got {mode!r}')
         params = params if params is not None else load_params(fps=1000)
         cls = DroneBatch if mode == "drone" else RacerBatch
         kw: Dict[str, Any] = dict(auto_reset=auto_reset, track_episodes=track_episodes)
@@ -585,7 +598,7 @@ class FpvVecEnv:
         return self.batch.rows_f32(0, 13)
 
     def reset(self, mask=None) -> torch.Tensor:
-        self.batch._reset_raw(mask=mask)
+        self.batch.reset(mask=mask)
         return self.obs
 
     def step(self, action) -> Tuple[torch.Tensor, torch.Tensor, torch.Tensor, Dict[str, Any]]:

@@ -27,7 +27,7 @@ class PID:
         if self.device.type != "cuda":
             raise ValueError("fpyv_amd runs on the GPU only (device must be cuda:N); there is no CPU path")
         self._L = _lib.lib()
-        self._dev = self.device.index if self.device.index is not None else 0
+        self._dev = self.device.index if self.device.index is not None else torch.cuda.current_device()
         self.ld = (self.n + 63) // 64 * 64
         self.state = torch.zeros((_lib.FPV_PID_ROWS, self.ld), dtype=torch.float32, device=self.device)
         self.output = torch.zeros(self.n, dtype=torch.float32, device=self.device)

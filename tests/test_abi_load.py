@@ -120,3 +120,11 @@ def test_components_module_mirrors_reference_names_and_constructor_signatures():
     rows = to_rows([t, gate, cyl, trail, g])
     assert [r[0] for r in rows] == [2, 1, 0]
     assert c.PID is not None
+
+
+def test_vec_env_refuses_an_unknown_mode():
+    """Checked before anything touches the GPU or the library (the reference raises ValueError on its mode strings too,
+    components.py:278,301)."""
+    from fpyv_amd.env import FpvVecEnv
+    with pytest.raises(ValueError, match="mode must be"):
+        FpvVecEnv(num_envs=4, mode="plane")

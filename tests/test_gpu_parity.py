@@ -1094,15 +1094,15 @@ def test_step_n_fuzz_bitwise_equal_to_single_steps(params_1k):
         da, db = (torch.zeros((k, n), dtype=torch.uint8, device=DEV) for _ in range(2))
         ba, bb = (torch.zeros((k, words), dtype=torch.int64, device=DEV) for _ in range(2))
         wind = (0.3, -0.2, 0.1)
-        a._set_objects(objs if world == "list" else ())
-        b._set_objects(objs if world == "list" else ())
+        a.set_objects(objs if world == "list" else ())       # bound for the following rollouts ...
+        b.set_objects(() if world == "list" else [(0, 0, 0, 0, 0, 0)])  # ... and replaced by rollout(object_list=...) below
         a.set_done_bits_target(ba, stride_words=words)
         b.set_done_bits_target(bb, stride_words=words)
         arg = None if no_action else (act_t[0].contiguous() if held else act_t)
         out = dict(rewards=ra, dones=da) if per_step_out else {}
         out_b = dict(rewards=rb, dones=db) if per_step_out else {}
         a.rollout(arg, wind=wind, steps=k, fused=False, **out)
-        b.rollout(arg, wind=wind, steps=k, fused=True, **out_b)
+        b.rollout(arg, wind=wind, steps=k, fused=True, object_list=objs if world == "list" else (), **out_b)
         torch.cuda.synchronize()
         tag = f"case {case}: auto={auto} kahan={kahan} noise={noise} track={track} world={world} held={held} n={n} k={k}"
         for name in ("state", "reward", "done_u8", "accel", "noise_state", "pos_comp", "action_out", "ep_return",

@@ -121,10 +121,10 @@ def main():
                 elif d.startswith("obj"):
                     w = far if d == "objfar" else world
                     if api in ("rollout", "fused"):
-                        e._set_objects(w)
+                        e.set_objects(w)
                         e.rollout(acts[:span], fused=(api == "fused"))
                     else:
-                        e._set_objects(w)                      # bound once per span: the per-step Python conversion of the
+                        e.set_objects(w)                      # bound once per span: the per-step Python conversion of the
                         for t in range(span):                  # list (30 us) would hide a 24 us kernel
                             e._step_raw(acts[t])
                 elif d.startswith("ovr"):
