@@ -248,7 +248,9 @@ int fpv_step_n(fpv_handle_t h, const fpv_buffers_t* b, int k, int64_t action_str
 /* The 64-bit step index that keys the stick-noise stream (Philox4x32-10 counter = global drone id, step index; key =
  * noise_seed) and the stochastic rounding counts the steps a handle has launched, from 0: set it to resume / replay a
  * run, read it to checkpoint one.  2^64 steps do not wrap in practice (2^32 took 5.5 h at the k-step kernel's rate,
- * which is why the 32-bit counter of ABI <= 3 was widened); streams below 2^32 steps are those of ABI <= 3 bit for bit. */
+ * which is why the 32-bit counter of ABI <= 3 was widened); streams below 2^32 steps are those of ABI <= 3 bit for bit.
+ * A call that is refused (bad argument, failed launch) leaves the counter where it was; fpv_rollout advances it by the
+ * launches that were accepted before the failing one. */
 int fpv_set_step_counter(fpv_handle_t h, uint64_t step);
 int fpv_get_step_counter(fpv_handle_t h, uint64_t* step);
 
