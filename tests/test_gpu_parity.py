@@ -781,6 +781,52 @@ def test_config5_shard_invariance_8M(params_1k):
     assert any_reset, "the scenario must trigger in-kernel resets"
 
 
+def test_maximum_handle_size_2_to_the_28(params_1k):
+    """The largest population one handle takes (fpv_create: n <= 2^28, the bound that keeps 16 * i - the byte offset
+    of a lane's action row - inside 32 bits): 268 435 456 drones, 15 GB of state + 4.3 GB of sticks on one GPU, three
+    single steps and a 2-step k-step launch.  The first, the middle and the LAST 4096 drones (lane offsets up to
+    0xFFFFFFF0) must equal the same drones stepped as small batches bit for bit; n + 1 is refused."""
+    from fpyv_amd import _lib as L
+    from fpyv_amd.env import DroneBatch
+    n = 1 << 28
+    free, _ = torch.cuda.mem_get_info()
+    if free < 30 << 30:
+        pytest.skip("needs 30 GB of free device memory")
+    with pytest.raises(L.FpvError, match="2\\^28"):
+        DroneBatch(params_1k, n + 1, device=DEV)
+
+    def sticks_of(ids):                         # a per-drone stick pattern any slice can re-create from its ids alone
+        x = ids.to(torch.float32) * 1e-3
+        return torch.stack([torch.sin(x) * 0.6, torch.cos(x * 0.7) * 0.6, torch.sin(x * 1.3) * 0.3,
+                            torch.cos(x * 0.31) * 0.5 - 0.2], dim=1).contiguous()
+
+    big = DroneBatch(params_1k, n, device=DEV, with_accel=False)
+    big.reset()
+    a = torch.empty((n, 4), dtype=torch.float32, device=DEV)
+    chunk = 1 << 24
+    for lo in range(0, n, chunk):               # built in pieces: the temporaries stay small
+        a[lo:lo + chunk] = sticks_of(torch.arange(lo, lo + chunk, device=DEV))
+    for _ in range(3):
+        big.step(a, return_imu=False)
+    big.rollout(a, steps=2)
+    torch.cuda.synchronize()
+    for lo in (0, (n >> 1) - 2048, n - 4096):
+        ids = torch.arange(lo, lo + 4096, device=DEV)
+        small = DroneBatch(params_1k, 4096, device=DEV, with_accel=False)
+        small.reset()
+        sa = sticks_of(ids)
+        assert torch.equal(sa, a[lo:lo + 4096])
+        for _ in range(3):
+            small.step(sa, return_imu=False)
+        small.rollout(sa, steps=2)
+        torch.cuda.synchronize()
+        assert torch.equal(small.state[:, :4096], big.state[:, lo:lo + 4096]), f"drones {lo}.. differ"
+        assert torch.equal(small.reward, big.reward[lo:lo + 4096]) and torch.equal(small.done, big.done[lo:lo + 4096])
+    assert bool(torch.isfinite(big.state[:, :n]).all())
+    del big, a
+    torch.cuda.empty_cache()
+
+
 def test_config1_10k_steps_with_kahan_rows(params_1k):
     """BASELINE config 1 end to end on the GPU at the 1e-5 bar: 10 000 zero-stick steps with the Kahan
     compensation rows; also bit-identical to the host lane model, and the rows reset with the lane."""
