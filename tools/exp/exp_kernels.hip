@@ -288,6 +288,29 @@ __global__ __launch_bounds__(BS) void k_grp(const FpvK K, const Buf B, const int
     __builtin_nontemporal_store((uint8_t)(o.done ? 1 : 0), &B.done[i]);
 }
 
+// V7: first-generation ramp.  The dispatcher starts every resident wave of the first generation at once: their loads
+// queue up together (a read-only phase, nothing to write yet) and complete together.  Here block b of the first G
+// blocks sleeps b * T / G sleep units (64 clocks each) before its loads - waves that would otherwise wait in the
+// memory queue wait in s_sleep instead - so completions, and with them the first stores and the second generation's
+// loads, spread over the ramp.  Blocks >= G (later generations) are untouched.
+template <int G, int T>
+__global__ __launch_bounds__(128) void k_ramp(const FpvK K, const Buf B, const int64_t n)
+{
+    if (blockIdx.x < (unsigned)G) {
+        const int units = (int)(blockIdx.x * (unsigned)T / (unsigned)G);
+        for (int k = 0; k < units; ++k) __builtin_amdgcn_s_sleep(1);
+    }
+    const uint32_t i = blockIdx.x * 128u + threadIdx.x;
+    if (i >= n) return;
+    FpvDroneState s;
+    float4 a = nt_load4(&B.action[i]);
+    ld_drone(B.state, B.ld, i, s);
+    FpvStepOut o = fpv_drone_step_lane<false>(K, s, a.x, a.y, a.z, a.w, B.wx, B.wy, B.wz);
+    st_drone(B.state, B.ld, i, s);
+    __builtin_nontemporal_store(o.reward, &B.reward[i]); __builtin_nontemporal_store((uint8_t)(o.done ? 1 : 0), &B.done[i]);
+}
+#define RMP(id, G, T) case id: hipLaunchKernelGGL((k_ramp<G, T>), dim3((unsigned)((n + 127) / 128)), dim3(128), 0, s, K, B, n); break;
+
 #define STG(id, SL, LB) case id: hipLaunchKernelGGL((k_stagger<SL, LB>), G(128), dim3(128), 0, s, K, B, n); break;
 
 extern "C" int exp_step(const fpv_params_t* P, float* state, int64_t ld, const float* action, float* reward,
@@ -327,6 +350,8 @@ extern "C" int exp_step(const fpv_params_t* P, float* state, int64_t ld, const f
         case 502: hipLaunchKernelGGL((k_grp<64>), G(64), dim3(64), 0, s, K, B, n); break;
         STG(400, 0, 0) STG(401, 20, 0) STG(402, 50, 0) STG(403, 100, 0) STG(404, 200, 0) STG(405, 400, 0)
         STG(410, 0, 20480) STG(411, 0, 40960) STG(412, 0, 10240) STG(413, 50, 20480)
+        RMP(600, 3072, 0) RMP(601, 3072, 16) RMP(602, 3072, 32) RMP(603, 3072, 48) RMP(604, 3072, 64) RMP(605, 3072, 96) RMP(606, 3072, 128)
+        RMP(610, 4096, 32) RMP(611, 4096, 64) RMP(612, 4096, 96) RMP(613, 2048, 32) RMP(614, 2048, 64) RMP(615, 8192, 64) RMP(616, 8192, 128)
         default: return -2;
     }
     return hipGetLastError() == hipSuccess ? 0 : -3;
