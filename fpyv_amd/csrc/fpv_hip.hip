@@ -814,17 +814,7 @@ __global__ __launch_bounds__(kBlock) void fpv_reset_kernel(const FpvK K, const F
         fpv_drone_reset_lane(K, s);
         if (pos) { s.px = pos[3 * i]; s.py = pos[3 * i + 1]; s.pz = pos[3 * i + 2]; }
         if (vel) { s.vx = vel[3 * i]; s.vy = vel[3 * i + 1]; s.vz = vel[3 * i + 2]; }
-        if (ypr) {
-            const float d2r_half = 0.5f * 0.017453292519943295f;
-            float sr, cr, sp, cp, sy, cy;
-            fpv_sincos_reduced(ypr[3 * i] * d2r_half, &sr, &cr);
-            fpv_sincos_reduced(ypr[3 * i + 1] * d2r_half, &sp, &cp);
-            fpv_sincos_reduced(ypr[3 * i + 2] * d2r_half, &sy, &cy);
-            s.q.w = fmaf(cy * cp, cr, sy * sp * sr);
-            s.q.x = fmaf(cy * cp, sr, -(sy * sp * cr));
-            s.q.y = fmaf(cy * sp, cr, sy * cp * sr);
-            s.q.z = fmaf(sy * cp, cr, -(cy * sp * sr));
-        }
+        if (ypr) s.q = fpv_quat_from_rpy_deg(ypr[3 * i], ypr[3 * i + 1], ypr[3 * i + 2]);
         if (K.flags & FPV_FLAG_FP16_STATE) {
             // masked lanes are independent here, so the thrust half goes out as a 2-byte store (not a hot path)
             const uint32_t th = st_drone_h(B, (uint32_t)i, K.noise.id_lo, B.seed, s);

@@ -774,6 +774,24 @@ FPV_HD FpvStepOut fpv_drone_step_lane(const FpvK& K, FpvDroneState& s, float a0,
     return o;
 }
 
+// Drone.reset's attitude for a per-drone `ypr` argument (components.py:150-154): the triple is consumed as (roll,
+// pitch, yaw) in DEGREES and R = Rz(yaw) Ry(pitch) Rx(roll), i.e. q = qz (x) qy (x) qx of the half angles.  The
+// reset kernel and the host build run these instructions (range-reduced sin/cos, no library call).
+FPV_HD FpvQuat fpv_quat_from_rpy_deg(float roll_deg, float pitch_deg, float yaw_deg)
+{
+    const float d2r_half = 0.5f * 0.017453292519943295f;
+    float sr, cr, sp, cp, sy, cy;
+    fpv_sincos_reduced(roll_deg * d2r_half, &sr, &cr);
+    fpv_sincos_reduced(pitch_deg * d2r_half, &sp, &cp);
+    fpv_sincos_reduced(yaw_deg * d2r_half, &sy, &cy);
+    FpvQuat q;
+    q.w = fmaf(cy * cp, cr, sy * sp * sr);
+    q.x = fmaf(cy * cp, sr, -(sy * sp * cr));
+    q.y = fmaf(cy * sp, cr, sy * cp * sr);
+    q.z = fmaf(sy * cp, cr, -(cy * sp * sr));
+    return q;
+}
+
 FPV_HD void fpv_drone_reset_lane(const FpvK& K, FpvDroneState& s)
 {
     s.px = K.p0[0]; s.py = K.p0[1]; s.pz = K.p0[2];

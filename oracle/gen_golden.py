@@ -424,6 +424,45 @@ def main():
     save("g13_guidance_override", dt=1e-3, actions=a13, init_position=ip, init_velocity=iv, init_ypr=io_, wind=np.zeros(3),
          rotation_override=rot13, thrust_force=tf13, ground_case=np.array([0, 0, 1]), **stack(cs))
 
+    # ---- G14: OTHER DRONE TYPES - every quantity Drone.__init__ reads from params (components.py:86-142) moved away
+    # from params.yaml: mass, drag coefficients, frame dimensions, max_rates, both transition rates, the motor block
+    # of the bench report (another thrust cubic), fps and gravity; EMA-noise sticks, wind, tilted start.  Pins the
+    # oracle's (and the build's) handling of the parameters themselves, which G1-G13 all leave at their defaults. ----
+    import json
+    types14 = [
+        dict(drone=dict(motor_test_report_idx=1, mass=1200, drag_coefficients=[1.1, 2.3, 0.9], dimensions=[40, 22, 9],
+                        max_rates=360, rates_transition_rate=0.35, thrust_transition_rate=0.8),
+             simulator=dict(fps=500, gravity=9.81), steps=1000),
+        dict(drone=dict(motor_test_report_idx=2, mass=400, drag_coefficients=[0.6, 0.7, 2.0], dimensions=[15, 15, 4],
+                        max_rates=800, rates_transition_rate=1.0, thrust_transition_rate=0.2),
+             simulator=dict(fps=250, gravity=3.71), steps=1000),
+        dict(drone=dict(motor_test_report_idx=3, mass=950, drag_coefficients=[2.5, 1.0, 1.6], dimensions=[33, 18, 12],
+                        max_rates=90, rates_transition_rate=0.05, thrust_transition_rate=1.0),
+             simulator=dict(fps=2000, gravity=9.81), steps=1000),
+        dict(drone=dict(motor_test_report_idx=4, mass=620, drag_coefficients=[1.4, 1.4, 0.4], dimensions=[22, 27, 6],
+                        max_rates=1200, rates_transition_rate=0.6, thrust_transition_rate=0.45),
+             simulator=dict(fps=120, gravity=1.62), steps=600),
+    ]
+    ip = np.array([[0, 0, 30.0], [1.0, -2.0, 40.0], [0, 0, 15.0], [-3.0, 0.5, 60.0]])
+    iv = np.array([[2.0, 0.5, 0], [0, 0, 1.0], [-1.0, 1.0, 0.5], [0.5, 0, 0]])
+    io_ = np.array([[5.0, -10.0, 30.0], [0, 0, 0], [-25.0, 15.0, 120.0], [2.0, 3.0, -4.0]])
+    wind14 = np.array([[1.5, -0.5, 0.2], [0, 0, 0], [-3.0, 2.0, 0.0], [0.5, 0.5, -0.5]])
+    for k, ty in enumerate(types14):
+        prm = copy.deepcopy(P1k)
+        prm["drone"].update(ty["drone"])
+        prm["simulator"].update(ty["simulator"])
+        T14 = ty["steps"]
+        a = sticks.ema_noise(T14, [k], seed=1400)
+        a[..., 3] = np.clip(a[..., 3] * 1.5 - 0.2, -1, 1)
+        c, d = run_drone(Drone, prm, a[:, 0], ip[k], iv[k], io_[k], wind=wind14[k], stride=10)
+        thr = d.motor_test_report["Throttle"].values.astype(float)
+        thrust_n = d.n_motors * d.motor_test_report["Thrust"].values.astype(float) / 1000 * d.gravity
+        save(f"g14_drone_type_{k}", overrides=np.array(json.dumps(dict(drone=ty["drone"], simulator=ty["simulator"]))),
+             dt=float(d.dt), actions=a, init_position=ip[k:k + 1], init_velocity=iv[k:k + 1], init_ypr=io_[k:k + 1], wind=wind14[k],
+             thrust_poly=np.asarray(model_xy(thr, thrust_n).coeffs, float),
+             min_throttle_in_force=float(d.min_throttle_in_force), max_throttle_in_force=float(d.max_throttle_in_force),
+             cross_section_areas=d.cross_section_areas, mass=float(d.mass), **stack([c]))
+
     leftovers = [r for r, ds, _ in os.walk(REF) if "__pycache__" in ds]
     assert not leftovers, f"bytecode written into the reference mount: {leftovers}"
 

@@ -209,6 +209,12 @@ extern "C" int64_t fpvl_max_drones(void) { return FPV_MAX_DRONES; }
 extern "C" void fpvl_sincos_wide(double x, double* s, double* c) { fpv_sincos_wide(x, s, c); }
 extern "C" void fpvl_sincos_reduced(float x, float* s, float* c) { fpv_sincos_reduced(x, s, c); }
 extern "C" uint32_t fpvl_round_seed(uint32_t base, uint64_t step) { return fpv_round_seed(base, step); }
+// the reset kernel's attitude for a per-drone (roll, pitch, yaw) in degrees: q[4] = w, x, y, z
+extern "C" void fpvl_quat_from_rpy_deg(float roll, float pitch, float yaw, float q[4])
+{
+    const FpvQuat r = fpv_quat_from_rpy_deg(roll, pitch, yaw);
+    q[0] = r.w; q[1] = r.x; q[2] = r.y; q[3] = r.z;
+}
 
 // components.PID in the kernel's fp32 arithmetic over a sequence: k[8] = kP, kI, kD, dt, integral_clip,
 // min_output, max_output, derivative_transition_rate; st[4] = integral, prev_derivative, previous_error, is_first

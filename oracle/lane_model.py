@@ -31,9 +31,22 @@ def lib() -> C.CDLL:
     return _L
 
 
-def initial_state(p, n: int, position=None, velocity=None, ypr_deg=None, ld: Optional[int] = None) -> np.ndarray:
+def quat_from_rpy_deg(roll: float, pitch: float, yaw: float) -> np.ndarray:
+    """The reset kernel's own fp32 attitude for a per-drone ypr argument (fpv_quat_from_rpy_deg, csrc/fpv_math.h)."""
+    L = lib()
+    L.fpvl_quat_from_rpy_deg.argtypes = [C.c_float, C.c_float, C.c_float, C.c_void_p]
+    L.fpvl_quat_from_rpy_deg.restype = None
+    q = np.zeros(4, dtype=np.float32)
+    L.fpvl_quat_from_rpy_deg(float(np.float32(roll)), float(np.float32(pitch)), float(np.float32(yaw)), q.ctypes.data)
+    return q
+
+
+def initial_state(p, n: int, position=None, velocity=None, ypr_deg=None, ld: Optional[int] = None,
+                  as_reset_kernel: bool = False) -> np.ndarray:
     """SoA [rows, ld] fp32 state after a reset, built the way the float64 side builds it (host
-    double math, rounded once) - used as the common starting point of parity runs."""
+    double math, rounded once) - used as the common starting point of parity runs.  `as_reset_kernel=True`
+    forms the attitude of a per-drone `ypr_deg` with the reset kernel's own fp32 instructions instead
+    (fpv_quat_from_rpy_deg): what fpv_reset leaves in the state, bit for bit."""
     from fpyv_amd.params import ypr_to_quat
     rows = abi.state_rows(int(p.mode))
     ld = ld or (n + 63) // 64 * 64
@@ -44,7 +57,10 @@ def initial_state(p, n: int, position=None, velocity=None, ypr_deg=None, ld: Opt
         ang = np.broadcast_to(np.asarray(p.init_orientation_deg if ypr_deg is None else ypr_deg, float), (n, 3))
         s[0:3, :n] = pos.T
         s[3:6, :n] = vel.T
-        s[6:10, :n] = np.stack([ypr_to_quat(*a) for a in ang]).T
+        if as_reset_kernel and ypr_deg is not None:
+            s[6:10, :n] = np.stack([quat_from_rpy_deg(*a) for a in ang]).T
+        else:
+            s[6:10, :n] = np.stack([ypr_to_quat(*a) for a in ang]).T
     else:
         s[abi.QW, :n] = 1.0
         s[abi.R_FIRST, :n] = 1.0

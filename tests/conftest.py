@@ -19,6 +19,23 @@ def load_golden(name):
         return {k: z[k] for k in z.files}
 
 
+def params_for_golden(g):
+    """DroneParams of a capture that moved the drone type away from params.yaml (g14_*): the packaged defaults with the
+    capture's `overrides` (the drone / simulator keys the generator changed in the reference's params dict) applied,
+    derived by the build's own host code - thrust-curve fit of the selected motor block included."""
+    import copy
+    import json
+    import yaml
+    from fpyv_amd import params as P
+    with open(P.DEFAULT_PARAMS_PATH, encoding="utf-8") as f:
+        cfg = yaml.safe_load(f)
+    over = json.loads(str(g["overrides"]))
+    cfg = copy.deepcopy(cfg)
+    cfg["drone"].update(over["drone"])
+    cfg["simulator"].update(over["simulator"])
+    return P.params_from_dict(cfg, yaml_dir=os.path.dirname(os.path.abspath(P.DEFAULT_PARAMS_PATH)))
+
+
 @pytest.fixture(scope="session")
 def params_1k():
     from fpyv_amd import load_params

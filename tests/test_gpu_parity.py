@@ -56,6 +56,56 @@ def test_golden_profiles_vs_oracle_and_reference(params_1k, name):
     np.testing.assert_allclose(env.accel[:, :n].t().cpu().numpy(), g["accel"][:, -1], rtol=1e-4, atol=1e-4)
 
 
+@pytest.mark.parametrize("k", range(4))
+def test_other_drone_types_vs_reference_capture(k):
+    """Captures G14 on the GPU: four drone types with every constructor parameter away from params.yaml (mass, drag,
+    frame, max_rates 90-1200 deg/s, transition rates, motor block, fps 120-2000, gravity 1.62-9.81).  Single-step and
+    k-step kernels, 1e-5 against the oracle and against the reference's own numbers, bit-identical to the host build."""
+    from conftest import params_for_golden
+    g = load_golden(f"g14_drone_type_{k}")
+    p = params_for_golden(g)
+    n = g["actions"].shape[1]
+    ref = oracle.drone_initial_state(n, g["init_position"], g["init_velocity"], g["init_ypr"])
+    oracle.drone_run(p, ref, g["actions"].astype(np.float64), wind=g["wind"])
+    ref_direct = np.concatenate([g["state"][:, -1], g["R"][:, -1].reshape(n, 9), g["prev_rates"][:, -1],
+                                 g["prev_thrust"][:, -1:]], axis=1)
+    model = lane_model.initial_state(p, n, g["init_position"], g["init_velocity"], g["init_ypr"], as_reset_kernel=True)
+    start = model.copy()
+    lane_model.run(p, model, g["actions"], wind=g["wind"])
+    fresh = _drone_batch(p, n)
+    fresh.reset(position=g["init_position"], velocity=g["init_velocity"], ypr=g["init_ypr"])
+    assert np.array_equal(fresh.state.cpu().numpy()[:, :n], start[:, :n]), "reset kernel != host build of its arithmetic"
+    for per_step in (False, True):
+        env = _run_golden(p, g, per_step_calls=per_step)
+        got = env.state.cpu().numpy()
+        assert_parity(soa_vs_oracle(got, ref, n), REL_TOL, f"g14 type {k}")
+        assert_parity(soa_vs_oracle(got, ref_direct, n), REL_TOL, f"g14 type {k} (reference capture)")
+        assert np.array_equal(env.done_u8.cpu().numpy(), g["done"][:, -1])
+        assert np.array_equal(got[:, :n], model[:, :n]), "kernel and host build of the same arithmetic must agree bit for bit"
+
+
+def test_reset_kernel_equals_host_build(params_1k):
+    """fpv_reset with per-drone position / velocity / ypr (angles out to +-720 degrees) and a mask: every state row equals
+    the host build of the same instructions bit for bit; unmasked drones keep their state."""
+    rng = np.random.default_rng(12)
+    n = 777
+    pos, vel = rng.uniform(-50, 50, (n, 3)).astype(np.float32), rng.uniform(-5, 5, (n, 3)).astype(np.float32)
+    ypr = rng.uniform(-720, 720, (n, 3)).astype(np.float32)
+    env = _drone_batch(params_1k, n)
+    env.reset(position=pos, velocity=vel, ypr=ypr)
+    torch.cuda.synchronize()
+    model = lane_model.initial_state(params_1k, n, pos, vel, ypr, as_reset_kernel=True)
+    got = env.state.cpu().numpy()
+    assert np.array_equal(got[:, :n].view(np.uint32), model[:, :n].view(np.uint32))
+    mask = rng.random(n) < 0.3
+    env.reset(mask=mask)                                   # params' own pose for the masked drones only
+    torch.cuda.synchronize()
+    again = env.state.cpu().numpy()
+    assert np.array_equal(again[:, :n][:, ~mask], got[:, :n][:, ~mask])
+    fresh = lane_model.initial_state(params_1k, n)
+    assert np.array_equal(again[:, :n][:, mask], fresh[:, :n][:, mask])
+
+
 def test_step_return_triple_matches_reference(params_1k):
     """Drone.step -> (R.T, E(rates as radians), R_new @ acc), components.py:247-248."""
     g = load_golden("g3_ema_noise")

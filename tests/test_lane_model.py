@@ -4,7 +4,7 @@ Runs without a GPU; the GPU tests then require the gfx950 kernel to reproduce th
 import numpy as np
 import pytest
 
-from conftest import load_golden
+from conftest import load_golden, params_for_golden
 from oracle import lane_model, oracle
 from parity import REL_TOL, assert_parity, soa_vs_oracle
 
@@ -28,6 +28,21 @@ def test_fp32_within_1e5_after_1000_steps(params_1k, name):
     np.testing.assert_allclose(acc[:, :n].T, ref_acc, rtol=1e-4, atol=1e-4)   # third return value, R_new @ acc (an output: fp32 cancellation of ~100 m/s^2 terms)
     goal = params_1k.goal
     np.testing.assert_allclose(rew, -np.linalg.norm(ref[:, 0:3] - goal, axis=1), rtol=1e-5, atol=1e-5)
+
+
+@pytest.mark.parametrize("k", range(4))
+def test_other_drone_types_fp32_within_1e5(k):
+    """The kernel's fp32 arithmetic on the four other drone types of capture G14 (fps 120-2000, gravity 1.62-9.81,
+    max_rates 90-1200 deg/s - type 3 takes 20 degrees per step, the range-reduced sin/cos path), against the oracle
+    AND directly against what the reference produced."""
+    g = load_golden(f"g14_drone_type_{k}")
+    p = params_for_golden(g)
+    s, ref, acc, ref_acc, done, ref_done, rew, n = _both(p, g)
+    assert_parity(soa_vs_oracle(s, ref, n), REL_TOL, f"g14 type {k}")
+    ref_direct = np.concatenate([g["state"][:, -1], g["R"][:, -1].reshape(n, 9), g["prev_rates"][:, -1],
+                                 g["prev_thrust"][:, -1:]], axis=1)
+    assert_parity(soa_vs_oracle(s, ref_direct, n), REL_TOL, f"g14 type {k} (reference capture)")
+    assert np.array_equal(done, ref_done) and np.array_equal(done, g["done"][:, -1])
 
 
 def test_fps60_large_step_angles(params_60):
@@ -438,6 +453,21 @@ def test_guidance_override_fp32(params_1k):
             lane_model.set_override(None)
             lane_model.set_objects(())
     assert worst["pos_comp"] < 1e-5 and worst["quat_abs"] < 1e-5 and worst["qnorm"] < 5e-7, worst
+
+
+def test_reset_attitude_fp32_against_float64():
+    """fpv_quat_from_rpy_deg (the reset kernel's per-drone ypr -> quaternion, range-reduced fp32 sin/cos) against the
+    float64 host formula, over +-720 degrees: 5e-7 absolute (the fp32 half angle itself carries 2.4e-7 at 6.3 rad), unit norm."""
+    from fpyv_amd.params import ypr_to_quat
+    rng = np.random.default_rng(3)
+    ang = np.concatenate([rng.uniform(-720, 720, (500, 3)), [[0, 0, 0], [180, 0, 0], [0, 90, 0], [0, -90, 0], [0, 0, 360], [45, 45, 45]]])
+    worst = 0.0
+    for a in ang:
+        q32 = lane_model.quat_from_rpy_deg(*a).astype(np.float64)
+        q64 = ypr_to_quat(*np.float32(a).astype(np.float64))
+        worst = max(worst, np.abs(q32 - q64).max())
+        assert abs(np.linalg.norm(q32) - 1) < 3e-7
+    assert worst < 5e-7, worst
 
 
 def test_quat_from_rot_every_branch():

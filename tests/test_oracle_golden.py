@@ -5,7 +5,7 @@ then compares the HIP path with the oracle."""
 import numpy as np
 import pytest
 
-from conftest import load_golden
+from conftest import load_golden, params_for_golden
 from oracle import oracle
 
 TOL = 1e-12   # float64 restatement vs float64 reference, <= 10 000 steps
@@ -63,6 +63,24 @@ def test_config0_to_the_letter_default_fps60_zero_sticks_10k(params_60):
     np.testing.assert_allclose(s[0, 0:3], [2.64701726, 0, 3424.66753], rtol=2e-9)
     np.testing.assert_allclose(s[0, 5], 20.5456781, rtol=2e-9)          # terminal climb rate: thrust - weight = drag
     np.testing.assert_allclose(s[0, 6:15].reshape(3, 3), np.eye(3), atol=1e-15)
+
+
+@pytest.mark.parametrize("k", range(4))
+def test_other_drone_types_match_reference(k):
+    """Captures G14: four drone types with EVERY parameter Drone.__init__ reads (components.py:86-142) moved away from
+    params.yaml - mass, drag coefficients, frame dimensions, max_rates, both transition rates, the motor block of the
+    bench report (another thrust cubic), fps 120-2000, gravity 1.62-9.81 - flown with EMA-noise sticks, wind and a
+    tilted start.  The host derivation (thrust-curve fit, areas, 5 % / full-throttle forces) must reproduce the
+    reference's constants and the oracle the whole trajectory at 1e-12."""
+    g = load_golden(f"g14_drone_type_{k}")
+    p = params_for_golden(g)
+    assert abs(p.dt - float(g["dt"])) < 1e-18 and abs(p.mass - float(g["mass"])) < 1e-15
+    np.testing.assert_allclose(p.thrust_poly, g["thrust_poly"], rtol=1e-9, atol=1e-12)
+    np.testing.assert_allclose(p.cross_section_areas, g["cross_section_areas"], rtol=1e-15)
+    np.testing.assert_allclose([p.min_throttle_in_force, p.max_throttle_in_force],
+                               [float(g["min_throttle_in_force"]), float(g["max_throttle_in_force"])], rtol=1e-10)
+    s, _, worst = _replay_drone(p, g)
+    assert np.isfinite(s).all() and worst < TOL
 
 
 def test_ground_contact_done_sequence(params_1k):
