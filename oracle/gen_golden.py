@@ -294,6 +294,36 @@ def main():
          pid=np.array([pid_full[k] for k in ("roll", "pitch", "yaw")], float),
          **stack([run_racer(a, pid_full)]))
 
+    # ---- G15: another Racer - 7-inch props (inertia m r^2 with r = 3.5 in, racer_drone_test.py:70,83), every PID gain of
+    # every axis non-zero and different, a chirp on the rate set-points and a thrust that changes sign ----
+    def run_racer_prop(actions, pid_values, prop, stride=10):
+        T = actions.shape[0]
+        env = racer_mod.Racer(prop_size_inch=prop, pid_values=pid_values)
+        env.reset()
+        rec = {k: [] for k in ("omega", "quat_xyzw", "matrix", "position", "velocity", "i_error")}
+        snaps = sorted(set(list(range(stride, T + 1, stride)) + [T]))
+        with contextlib.redirect_stdout(io.StringIO()):
+            for t in range(T):
+                env.step(action=[float(x) for x in actions[t]])
+                if t + 1 in snaps:
+                    rec["omega"].append(np.array(env.angular_velocity, float))
+                    rec["quat_xyzw"].append(env.orientation.as_quat())
+                    rec["matrix"].append(env.orientation.as_matrix())
+                    rec["position"].append(env.position.copy())
+                    rec["velocity"].append(env.linear_velocity.copy())
+                    rec["i_error"].append(np.array([v.i_error for v in env.pid.values()], float))
+        out = {k: np.asarray(v) for k, v in rec.items()}
+        out["snap_steps"] = np.asarray(snaps)
+        out["inertia"] = np.asarray(env.I, float)
+        return out
+
+    pid15 = {"roll": [0.006, 0.03, 3e-6], "pitch": [0.009, 0.015, 1e-6], "yaw": [0.004, 0.02, 2e-6]}
+    t = np.arange(1000) * 1e-3
+    a = np.stack([2.5 * np.sin(2 * np.pi * (0.5 + 2 * t) * t), -1.5 * np.cos(2 * np.pi * 1.5 * t), 1.0 * np.sin(2 * np.pi * 0.7 * t),
+                  3 * np.cos(2 * np.pi * 1.0 * t)], axis=1).astype(np.float32)
+    save("g15_racer_prop7", dt=1e-3, actions=a[:, None, :], prop_size_inch=7.0,
+         pid=np.array([pid15[k] for k in ("roll", "pitch", "yaw")], float), **stack([run_racer_prop(a, pid15, 7)]))
+
     # ---- G11: components.PID (components.py:15-54) on seeded (current, target) sequences that reach the
     # integral clip, the 0.99 leak, the +-1 derivative clip, the derivative low-pass and both output clips ----
     from utils.components import PID as CPID

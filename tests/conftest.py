@@ -36,6 +36,20 @@ def params_for_golden(g):
     return P.params_from_dict(cfg, yaml_dir=os.path.dirname(os.path.abspath(P.DEFAULT_PARAMS_PATH)))
 
 
+def racer_params_for_golden(g):
+    """Mode-"racer" DroneParams of a Racer capture at dt = 1 ms: the capture's PID gains and - when the capture flew
+    another propeller size (g15) - the inertia the build's host code derives from `stepper.racer.prop_size_inch`."""
+    import copy
+    import yaml
+    from fpyv_amd import params as P
+    with open(P.DEFAULT_PARAMS_PATH, encoding="utf-8") as f:
+        cfg = copy.deepcopy(yaml.safe_load(f))
+    if "prop_size_inch" in g:
+        cfg["stepper"]["racer"]["prop_size_inch"] = float(g["prop_size_inch"])
+    p = P.params_from_dict(cfg, yaml_dir=os.path.dirname(os.path.abspath(P.DEFAULT_PARAMS_PATH)), mode="racer", fps=1000)
+    return p.replace(racer_pid=g["pid"], dt=float(g["dt"]))
+
+
 @pytest.fixture(scope="session")
 def params_1k():
     from fpyv_amd import load_params

@@ -374,13 +374,14 @@ def _racer_replay(p, g):
     return env, worst
 
 
-@pytest.mark.parametrize("name", ["g7_racer_main", "g8_racer_pid_thrust"])
+@pytest.mark.parametrize("name", ["g7_racer_main", "g8_racer_pid_thrust", "g15_racer_prop7"])
 def test_racer_vs_reference_capture(params_1k, name):
     """Racer.step AS WRITTEN (omega radians per step) against the reference captures at the north-star bar,
     1e-5 on position and quaternion, at every snapshot of the 1000 steps: the rate loop and the attitude
     increment run in float64 with (hi, lo) state rows (229 B per env-step)."""
+    from conftest import racer_params_for_golden
     g = load_golden(name)
-    p = params_1k.replace(mode=1, racer_pid=g["pid"])
+    p = racer_params_for_golden(g)
     env, worst = _racer_replay(p, g)
     assert env.algorithmic_bytes() == 229 and env.state.shape[0] == 29
     assert worst["quat"] < REL_TOL and worst["pos"] < REL_TOL and worst["omega"] < 1e-8, worst

@@ -5,7 +5,7 @@ then compares the HIP path with the oracle."""
 import numpy as np
 import pytest
 
-from conftest import load_golden, params_for_golden
+from conftest import load_golden, params_for_golden, racer_params_for_golden
 from oracle import oracle
 
 TOL = 1e-12   # float64 restatement vs float64 reference, <= 10 000 steps
@@ -113,11 +113,15 @@ def test_spot_value_constant_roll(params_1k):
     np.testing.assert_allclose(q, [0.17291149468075978, -0.9849373660325151, 0, 0], atol=1e-12)
 
 
-@pytest.mark.parametrize("name", ["g7_racer_main", "g8_racer_pid_thrust"])
+@pytest.mark.parametrize("name", ["g7_racer_main", "g8_racer_pid_thrust", "g15_racer_prop7"])
 def test_racer_step_matches_reference(params_1k, name):
+    """G7: the reference's own scenario; G8: every PID term and a thrust; G15: 7-inch props (another inertia,
+    derived by the build's host code), all nine gains non-zero, chirped set-points, a thrust that changes sign."""
     g = load_golden(name)
-    p = params_1k.replace(racer_pid=g["pid"], dt=float(g["dt"]))
+    p = racer_params_for_golden(g)
     np.testing.assert_allclose(p.racer_inertia, g["inertia"][0], rtol=1e-15)
+    if name == "g15_racer_prop7":
+        assert abs(p.racer_inertia[0] - 0.5 * (3.5 * 2.54 / 100) ** 2) < 1e-18 and p.racer_inertia[0] > 1.9 * params_1k.racer_inertia[0]
     acts = g["actions"].astype(np.float64)
     s = oracle.racer_initial_state(1)
     t0 = 0
