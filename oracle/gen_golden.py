@@ -257,6 +257,36 @@ def main():
                            [0, 0, 0, 0, 0, 0]], dtype=float),
          **stack(cs))
 
+    # ---- G16: objects OFF the ground, Ground FIRST in the list, a Target that stands still.  G10's cylinders stand on
+    # z = 0, where Cylinder.calculate_normal's test of the RELATIVE height against the ABSOLUTE band
+    # (components.py:718-720: `point = point - self.position`, then `self.position[2] < point[2] < ...`) cannot show.
+    # Here cylinder A spans z = 1.2 .. 3.2: a side contact at z = 1.8 gets a VERTICAL normal (relative height 0.6 is
+    # outside the band), one at z = 2.8 the radial one; a drone rising under the rim, one descending onto the top
+    # (no spring there - it crashes when a motor enters the band), a standing sphere, and a small raised cylinder
+    # next to a landing drone with the ground spring of the list's FIRST entry already in the sum. ----
+    cyl16a = Cylinder(np.array([3.0, 0.0, 1.2]), 1.0, 2.0, 4, 2, random=False)
+    cyl16b = Cylinder(np.array([-2.0, -2.0, 0.8]), 0.5, 0.6, 4, 2, random=False)
+    ip = np.array([[1.6, 0.0, 1.8], [1.6, 0.0, 2.8], [4.08, 0.0, 0.9], [3.0, 0.0, 3.35], [0.0, 2.9, 2.0], [-2.0, -1.34, 1.1]])
+    iv = np.array([[0.45, 0, 0], [0.45, 0, 0], [0, 0, 0.6], [0, 0, -0.4], [0, 0.4, 0], [0, 0, -0.3]])
+    io_ = np.zeros((6, 3))
+    acts = np.array([[0, 0, 0, hov], [0, 0, 0, hov], [0, 0, 0, hov], [0, 0, 0, hov - 0.01], [0, 0, 0, hov], [0, 0, 0, hov - 0.02]])
+    T16 = 800
+    a = np.stack([sticks.constant(T16, 1, x)[:, 0] for x in acts], axis=1)
+    cs, free = [], []
+    for k in range(len(acts)):
+        tgt = Target(np.array([0.0, 4.0, 2.0]), 0.8, 1, path=None)
+        objs = [ground, cyl16a, tgt, cyl16b]
+        c, _ = run_drone(Drone, P1k, a[:, k], ip[k], iv[k], io_[k], stride=1, object_list=objs)
+        f, _ = run_drone(Drone, P1k, a[:, k], ip[k], iv[k], io_[k], stride=T16, object_list=[])
+        cs.append(c)
+        free.append(np.abs(c["state"][-1] - f["state"][-1]).max())
+    print("G16: |state - free flight| at the end per drone:", np.round(free, 4), " done:", [int(c["done"].any()) for c in cs])
+    save("g16_objects_raised", dt=1e-3, actions=a, init_position=ip, init_velocity=iv, init_ypr=io_, wind=np.zeros(3),
+         deviation_from_free_flight=np.asarray(free),
+         objects=np.array([[0, 0, 0, 0, 0, 0], [1, 3.0, 0.0, 1.2, 1.0, 2.0], [2, 0.0, 4.0, 2.0, 0.8, 0.0],
+                           [1, -2.0, -2.0, 0.8, 0.5, 0.6]], dtype=float),
+         **stack(cs))
+
     # ---- G7/G8: Racer (rate PID -> torque) ----
     def run_racer(actions, pid_values, stride=10):
         T = actions.shape[0]

@@ -797,6 +797,49 @@ def test_object_list_collisions_vs_reference_capture(params_1k):
         env.step(a[0], object_list=[Ground()] * 9)
 
 
+def test_raised_objects_vs_reference_capture(params_1k):
+    """Capture G16 through the public API: object_list = [Ground, Cylinder (z = 1.2 .. 3.2), standing Target, small raised
+    Cylinder] - the cylinder normal's relative-vs-absolute height test of the reference (components.py:718-720), the rim
+    from below, the top, Ground first in the list.  Single steps and one k-step launch: crashes on the reference's
+    steps, survivors within 1e-5 of the reference's numbers, kernel == host build bit for bit."""
+    from fpyv_amd.objects import Cylinder, Ground, Target
+    g = load_golden("g16_objects_raised")
+    acts = g["actions"]
+    T, n = acts.shape[:2]
+    objs = [Ground(), Cylinder([3.0, 0.0, 1.2], 1.0, 2.0), Target([0.0, 4.0, 2.0], 0.8), Cylinder([-2.0, -2.0, 0.8], 0.5, 0.6)]
+    from fpyv_amd.objects import to_rows
+    assert np.allclose(np.asarray(to_rows(objs), dtype=float), g["objects"])
+    model = lane_model.initial_state(params_1k, n, g["init_position"], g["init_velocity"], g["init_ypr"])
+    start = torch.from_numpy(model[:, :n].copy()).to(DEV)
+    env, fused = _drone_batch(params_1k, n), _drone_batch(params_1k, n)
+    env.state[:, :n] = start
+    fused.state[:, :n] = start
+    a = torch.from_numpy(acts).to(DEV)
+    seq = np.zeros((n, T), dtype=np.uint8)
+    dones = torch.zeros((T, n), dtype=torch.uint8, device=DEV)
+    try:
+        lane_model.set_objects(tuple(tuple(o) for o in g["objects"]))
+        for t in range(T):
+            env.step(a[t], wind_velocity_vector=np.zeros(3), object_list=objs, return_imu=False)
+            seq[:, t] = env.done_u8.cpu().numpy()
+        lane_model.run(params_1k, model, acts)
+    finally:
+        lane_model.set_objects(())
+    fused.rollout(a, dones=dones, object_list=objs)          # the same 800 steps in ONE launch
+    torch.cuda.synchronize()
+    got = env.state.cpu().numpy()
+    assert np.array_equal(got[:, :n].view(np.uint32), model[:, :n].view(np.uint32)), "kernel != lane model (bitwise)"
+    assert torch.equal(fused.state, env.state) and np.array_equal(dones.cpu().numpy().T, seq)
+    first = lambda d: int(np.argmax(d)) if d.any() else -1      # noqa: E731
+    for i in range(n):
+        assert first(seq[i]) == first(g["done"][i]), "crash on exactly the reference's step"
+    ok = ~g["done"].any(axis=1)
+    ref = np.concatenate([g["state"][:, -1], g["R"][:, -1].reshape(n, 9), g["prev_rates"][:, -1],
+                          g["prev_thrust"][:, -1:]], axis=1)
+    err = soa_vs_oracle(np.ascontiguousarray(got[:, np.flatnonzero(ok)]), ref[ok], int(ok.sum()))
+    assert ok.sum() == 3 and err["pos_comp"] < REL_TOL and err["quat_abs"] < REL_TOL, err
+
+
 def test_config5_shard_invariance_8M(params_1k):
     """BASELINE config 5 at its full size on ONE GPU: 8 388 608 drones as one batch vs the same
     drones as 8 contiguous shards (what 8 ranks would own), in-kernel stick noise keyed by global

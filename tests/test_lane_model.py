@@ -330,6 +330,31 @@ def test_object_list_collisions_fp32(params_1k):
     assert err["pos_comp"] < REL_TOL and err["quat_abs"] < REL_TOL, err
 
 
+def test_raised_objects_fp32(params_1k):
+    """fp32 lane arithmetic on capture G16 (raised cylinders: the reference's relative-vs-absolute height test of the
+    cylinder normal; Ground first; standing sphere): crashes on the reference's steps, survivors within 1e-5."""
+    g = load_golden("g16_objects_raised")
+    acts = g["actions"]
+    T, n = acts.shape[:2]
+    s = lane_model.initial_state(params_1k, n, g["init_position"], g["init_velocity"], g["init_ypr"])
+    seq = np.zeros((n, T), dtype=np.uint8)
+    try:
+        lane_model.set_objects(tuple(tuple(o) for o in g["objects"]))
+        for t in range(T):
+            _, _, done, _ = lane_model.run(params_1k, s, acts[t:t + 1])
+            seq[:, t] = done
+    finally:
+        lane_model.set_objects(())
+    first = lambda d: int(np.argmax(d)) if d.any() else -1      # noqa: E731
+    for i in range(n):
+        assert first(seq[i]) == first(g["done"][i]), (i, first(seq[i]), first(g["done"][i]))
+    ok = ~g["done"].any(axis=1)
+    ref = np.concatenate([g["state"][:, -1], g["R"][:, -1].reshape(n, 9), g["prev_rates"][:, -1],
+                          g["prev_thrust"][:, -1:]], axis=1)
+    err = soa_vs_oracle(np.ascontiguousarray(s[:, np.flatnonzero(ok)]), ref[ok], int(ok.sum()))
+    assert ok.sum() == 3 and err["pos_comp"] < REL_TOL and err["quat_abs"] < REL_TOL, err
+
+
 def test_config1_10k_steps_with_kahan_compensation(params_1k):
     """The optional Kahan rows (fpv_buffers_t.pos_comp, [6][ld]: p and v) close the 10 000-step gap of
     config 1: from 1.2e-4 (plain fp32 sums) to < 1e-6 relative against the reference capture."""

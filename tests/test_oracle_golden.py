@@ -184,6 +184,30 @@ def test_object_list_collisions_match_reference(params_1k):
     assert g["done"][1].any() and g["done"][5].any() and not g["done"][0].any()
 
 
+def test_raised_objects_match_reference(params_1k):
+    """Capture G16: object_list = [Ground, Cylinder spanning z = 1.2 .. 3.2, standing Target, small raised Cylinder].
+    Pins what G10's cylinders (standing on z = 0) cannot show - Cylinder.calculate_normal tests the height RELATIVE to
+    the base against the ABSOLUTE band (components.py:718-720), so a side contact at z = 1.8 is pushed DOWN while one
+    at z = 2.8 is pushed out - plus the rim from below, the top (no spring: crash on entering the band), a sphere that
+    does not move, and the list order with Ground first."""
+    g = load_golden("g16_objects_raised")
+    acts = g["actions"].astype(np.float64)
+    T, n = acts.shape[:2]
+    p = params_1k.replace(objects=tuple(tuple(o) for o in g["objects"]))
+    s = oracle.drone_initial_state(n, g["init_position"], g["init_velocity"], g["init_ypr"])
+    for t in range(T):
+        _, accel, done = oracle.drone_run(p, s, acts[t:t + 1])
+        assert np.array_equal(done, g["done"][:, t]), t
+        assert np.abs(s[:, 0:6] - g["state"][:, t]).max() < 1e-11, t
+        assert np.abs(s[:, 6:15] - g["R"][:, t].reshape(n, 9)).max() < 1e-12
+    assert ((g["deviation_from_free_flight"] > 0.5) | g["done"].any(axis=1)).all(), "every drone of the capture must meet an object"
+    # the quirk itself: drone 0 (side contact at relative height 0.6) is driven DOWN
+    # (vz -3 m/s, forward speed untouched, until a motor enters the cylinder); drone 1 (relative 1.6) bounces back at its height
+    assert g["state"][0, 700, 5] < -2.5 and g["state"][0, 700, 3] > 0.44 and g["done"][0, 701]
+    assert abs(g["state"][1, -1, 2] - 2.8) < 0.02 and g["state"][1, -1, 3] < -0.4
+    assert g["done"][3].any() and not g["done"][1].any() and not g["done"][2].any() and not g["done"][4].any()
+
+
 def _cpid_params(p, g):
     return p.replace(mode=1, racer_pid=g["pid"], racer_pid_variant=1, pid_integral_clip=float(g["clips"][0]),
                      pid_min_output=float(g["clips"][1]), pid_max_output=float(g["clips"][2]),
