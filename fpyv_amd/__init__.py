@@ -8,4 +8,4 @@ One fused HIP kernel (gfx950) advances N independent drones per call, behind a c
 from .params import DroneParams, load_params, read_motor_test_report, MODE_DRONE, MODE_RACER  # noqa: F401
 
 __all__ = ["DroneParams", "load_params", "read_motor_test_report", "MODE_DRONE", "MODE_RACER"]
-__version__ = "0.2.0"
+__version__ = "0.3.0"

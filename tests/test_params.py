@@ -6,7 +6,7 @@ import numpy as np
 import pytest
 
 from conftest import load_golden
-from fpyv_amd import load_params, read_motor_test_report
+from fpyv_amd import read_motor_test_report
 from fpyv_amd.params import ypr_to_quat, DEFAULT_PARAMS_PATH, params_from_dict
 
 REF_CSV = "/root/reference/config/t_motos_f80_motor_test.csv"
