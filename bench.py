@@ -59,12 +59,15 @@ def _strip_comments(src):
 
 
 def kernel_source_hash():
-    """sha256 (16 hex digits) over the CODE of the kernel sources: comments and white space do not count."""
+    """sha256 (16 hex digits) over the CODE of the kernel sources - comments and white space do not count - and the
+    compiler flags the library is built with (a code-generation flag changes the kernels as surely as an edit does)."""
     h = hashlib.sha256()
     for p in KERNEL_SOURCES:
         with open(p, "r", encoding="utf-8") as f:
             h.update(_strip_comments(f.read()).encode("utf-8"))
         h.update(b"\0")
+    from __graft_entry__ import HIPCC_FLAGS
+    h.update(" ".join(f for f in HIPCC_FLAGS if not f.startswith("-W")).encode("utf-8"))
     return h.hexdigest()[:16]
 
 

@@ -260,9 +260,29 @@ __device__ __forceinline__ float4 apply_stick_noise(const FpvK& K, const FpvBufD
 #else
 #define FPV_EXP_STEP_ATTR
 #endif
-template <bool NOISE = false, bool OBJ = false, bool KAHAN = false, bool OVR = false>
-__global__ __launch_bounds__(kStepBlock) FPV_EXP_STEP_ATTR void fpv_drone_step_kernel(const FpvK K, const FpvBufD B, const int64_t n)
+// The single-step kernels take what their FIRST instructions need - the state and action bases, the row stride, n - as
+// plain leading scalars, ahead of the two argument structs.  The library is built with
+// -mllvm -amdgpu-kernarg-preload-count=12: on gfx950 the command processor then places this 12-dword prefix of the
+// kernel-argument segment in SGPRs at wave launch, so a wave issues its 15 vector loads at once instead of first
+// waiting for a scalar load of those pointers - a cold one at every kernel start, because the scalar cache and L2
+// are invalidated at the kernel boundary.  It is the head of the per-launch floor of a chain of dependent step
+// kernels (tools/exp/launch_floor.py).  (Firmware without the feature runs the compiler's compatibility
+// prologue, which loads the same prefix with s_load: same results either way.)  The structs that follow still carry
+// the same fields; fpv_step_view() overrides them, so their kernarg copies are never loaded.
+#define FPV_STEP_PARAMS float* __restrict__ a_state, const int64_t a_ld, const float4* __restrict__ a_action, \
+                        const int64_t a_action_ld, uint16_t* __restrict__ a_state_h, const int64_t n, const FpvK K, const FpvBufD B_
+__device__ __forceinline__ FpvBufD fpv_step_view(const FpvBufD& B_, float* st, int64_t ld, const float4* act, int64_t act_ld, uint16_t* sh)
 {
+    FpvBufD B = B_;
+    B.state = st; B.ld = ld; B.action = act; B.action_ld = act_ld; B.state_h = sh;
+    return B;
+}
+#define FPV_STEP_VIEW const FpvBufD B = fpv_step_view(B_, a_state, a_ld, a_action, a_action_ld, a_state_h)
+
+template <bool NOISE = false, bool OBJ = false, bool KAHAN = false, bool OVR = false>
+__global__ __launch_bounds__(kStepBlock) FPV_EXP_STEP_ATTR void fpv_drone_step_kernel(FPV_STEP_PARAMS)
+{
+    FPV_STEP_VIEW;
     const uint32_t i = blockIdx.x * (uint32_t)kStepBlock + threadIdx.x;    // n <= 2^28 (fpv_create)
     // lanes past the end leave at once (a ballot over the remaining lanes still yields the right done bits:
     // exited lanes contribute 0, and a wave whose lane 0 is gone is empty)
@@ -287,7 +307,7 @@ __global__ __launch_bounds__(kStepBlock) FPV_EXP_STEP_ATTR void fpv_drone_step_k
 #pragma unroll
         for (int k = 0; k < 6; ++k) kc[k] = row_at(ROW(B.pos_comp, k, B.ld), i);
     }
-    const FpvStepOut o = fpv_drone_step_lane<OBJ>(K, s, a.x, a.y, a.z, a.w, B.wx, B.wy, B.wz, &B.objs,
+    const FpvStepOut o = fpv_drone_step_lane<OBJ>(K, s, a.x, a.y, a.z, a.w, B.wx, B.wy, B.wz, &B_.objs,   // the table stays in the kernarg segment (a local copy of an indexed array would live in scratch)
                                                   KAHAN ? kc : nullptr, OVR ? ro : nullptr, to);
     // OBJ: the store addresses are formed only now - the 14 row-address pairs the compiler would otherwise carry from
     // the loads to the stores (28 VGPRs) come on top of the object pass's own registers (102 VGPRs, 4 waves per SIMD);
@@ -487,8 +507,9 @@ __global__ __launch_bounds__(kStepBlock) FPV_EXP_ROLL_ATTR void fpv_drone_rollou
 // wave transposes its 64 x 16 tile through LDS (row pitch 17 words: conflict-free writes) and
 // stores it as 4 fully coalesced 1-KiB float4 instructions.  This is the one place on the path
 // where LDS staging pays; the SoA state rows never need it.
-__global__ __launch_bounds__(kStepBlock) void fpv_drone_step_aos_kernel(const FpvK K, const FpvBufD B, const int64_t n)
+__global__ __launch_bounds__(kStepBlock) void fpv_drone_step_aos_kernel(FPV_STEP_PARAMS)
 {
+    FPV_STEP_VIEW;
     constexpr int kPitch = 17;
     __shared__ float tile[kStepBlock / 64][64 * kPitch];
     const uint32_t i = blockIdx.x * (uint32_t)kStepBlock + threadIdx.x;
@@ -580,8 +601,9 @@ __device__ __forceinline__ void st_thrust_pair_h(const FpvBufD& B, uint32_t i, b
     if (live && !(i & 1u)) row_at(const_cast<uint32_t*>(thrust_row_h(B)), i >> 1) = mine | (other << 16);
 }
 
-__global__ __launch_bounds__(kStepBlock) void fpv_drone_step_h_kernel(const FpvK K, const FpvBufD B, const int64_t n)
+__global__ __launch_bounds__(kStepBlock) void fpv_drone_step_h_kernel(FPV_STEP_PARAMS)
 {
+    FPV_STEP_VIEW;
     const uint32_t i = blockIdx.x * (uint32_t)kStepBlock + threadIdx.x;
     const bool live = i < n;                 // no early exit: the thrust-pair exchange needs whole lane pairs
     FpvStepOut o;
@@ -717,8 +739,9 @@ __device__ __forceinline__ void st_racer(float* __restrict__ st, int64_t ld, uin
 // PIDV = components.PID semantics (three extra rows).  The 181-byte variant (neither) is the
 // racer_omega_dt one.
 template <bool WIDE, bool PIDV>
-__global__ __launch_bounds__(kStepBlock) void fpv_racer_step_kernel(const FpvK K, const FpvBufD B, const int64_t n)
+__global__ __launch_bounds__(kStepBlock) void fpv_racer_step_kernel(FPV_STEP_PARAMS)
 {
+    FPV_STEP_VIEW;
     const uint32_t i = blockIdx.x * (uint32_t)kStepBlock + threadIdx.x;
     if (i >= n) return;
     FpvRacerState s;
@@ -1032,8 +1055,8 @@ struct DeviceGuard {
     DeviceGuard& operator=(const DeviceGuard&) = delete;
 };
 
-// ---- kernel selection: every step kernel has the signature (FpvK, FpvBufD, int64_t) ----------------
-typedef void (*StepKernel)(const FpvK, const FpvBufD, const int64_t);
+// ---- kernel selection: every step kernel has the signature FPV_STEP_PARAMS ------------------------------
+typedef void (*StepKernel)(float*, const int64_t, const float4*, const int64_t, uint16_t*, const int64_t, const FpvK, const FpvBufD);
 struct KernelChoice { StepKernel func; unsigned grid, block; };
 
 StepKernel drone_kernel(bool noise, bool obj, bool kahan)
@@ -1114,7 +1137,7 @@ int launch_step(fpv_env* h, const FpvBufD& d_in, hipStream_t s)
     FpvBufD d = d_in;
     d.step = h->launches;
     const KernelChoice c = choose_kernel(h, d);
-    hipLaunchKernelGGL(c.func, dim3(c.grid), dim3(c.block), 0, s, h->K, d, h->n);
+    hipLaunchKernelGGL(c.func, dim3(c.grid), dim3(c.block), 0, s, d.state, d.ld, d.action, d.action_ld, d.state_h, h->n, h->K, d);
     const hipError_t e = hipGetLastError();
     if (e != hipSuccess) return hip_fail(e, "step kernel launch");
     ++h->launches;                     // a refused launch leaves the step index where it was
@@ -1396,7 +1419,7 @@ int fpv_rollout_graph(fpv_handle_t h, const fpv_buffers_t* b, int k, int64_t act
         for (int t = 0; t < k; ++t) {
             FpvBufD d = graph_step_view(b, d0, t, action_stride, out_stride);
             const KernelChoice c = choose_kernel(h, d);
-            void* args[3] = {&K, &d, &n};                 // copied by hipGraphAddKernelNode
+            void* args[8] = {&d.state, &d.ld, &d.action, &d.action_ld, &d.state_h, &n, &K, &d};   // copied by hipGraphAddKernelNode
             hipKernelNodeParams np;
             memset(&np, 0, sizeof(np));
             np.func = reinterpret_cast<void*>(c.func);
@@ -1417,7 +1440,7 @@ int fpv_rollout_graph(fpv_handle_t h, const fpv_buffers_t* b, int k, int64_t act
         for (int t = 0; t < k; ++t) {
             FpvBufD d = graph_step_view(b, d0, t, action_stride, out_stride);
             const KernelChoice c = choose_kernel(h, d);
-            void* args[3] = {&K, &d, &n};
+            void* args[8] = {&d.state, &d.ld, &d.action, &d.action_ld, &d.state_h, &n, &K, &d};
             hipKernelNodeParams np;
             memset(&np, 0, sizeof(np));
             np.func = reinterpret_cast<void*>(c.func);
