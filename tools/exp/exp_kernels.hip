@@ -309,6 +309,31 @@ __global__ __launch_bounds__(128) void k_ramp(const FpvK K, const Buf B, const i
     st_drone(B.state, B.ld, i, s);
     __builtin_nontemporal_store(o.reward, &B.reward[i]); __builtin_nontemporal_store((uint8_t)(o.done ? 1 : 0), &B.done[i]);
 }
+// V8: issue priority.  The six resident waves of a SIMD receive their data at about the same time and then share the
+// vector ALU, so in the first generation each finishes its 231 instructions six times later than it could and no
+// store leaves before ~2 us.  MODE 1: four priority classes by (block + wave) so that a SIMD's waves finish one
+// after the other; MODE 2: by block only; MODE 3: everything at priority 3 (control: no relative difference).
+template <int MODE>
+__global__ __launch_bounds__(128) void k_prio(const FpvK K, const Buf B, const int64_t n)
+{
+    const uint32_t i = blockIdx.x * 128u + threadIdx.x;
+    if (i >= n) return;
+    FpvDroneState s;
+    float4 a = nt_load4(&B.action[i]);
+    ld_drone(B.state, B.ld, i, s);
+    const unsigned cls = MODE == 1 ? ((blockIdx.x + (threadIdx.x >> 6)) & 3u) : MODE == 2 ? (blockIdx.x & 3u) : 3u;
+    switch (cls) {                      // s_setprio takes an immediate
+        case 0: __builtin_amdgcn_s_setprio(0); break;
+        case 1: __builtin_amdgcn_s_setprio(1); break;
+        case 2: __builtin_amdgcn_s_setprio(2); break;
+        default: __builtin_amdgcn_s_setprio(3); break;
+    }
+    FpvStepOut o = fpv_drone_step_lane<false>(K, s, a.x, a.y, a.z, a.w, B.wx, B.wy, B.wz);
+    st_drone(B.state, B.ld, i, s);
+    __builtin_nontemporal_store(o.reward, &B.reward[i]); __builtin_nontemporal_store((uint8_t)(o.done ? 1 : 0), &B.done[i]);
+}
+#define PRI(id, M) case id: hipLaunchKernelGGL((k_prio<M>), dim3((unsigned)((n + 127) / 128)), dim3(128), 0, s, K, B, n); break;
+
 #define RMP(id, G, T) case id: hipLaunchKernelGGL((k_ramp<G, T>), dim3((unsigned)((n + 127) / 128)), dim3(128), 0, s, K, B, n); break;
 
 #define STG(id, SL, LB) case id: hipLaunchKernelGGL((k_stagger<SL, LB>), G(128), dim3(128), 0, s, K, B, n); break;
@@ -350,6 +375,7 @@ extern "C" int exp_step(const fpv_params_t* P, float* state, int64_t ld, const f
         case 502: hipLaunchKernelGGL((k_grp<64>), G(64), dim3(64), 0, s, K, B, n); break;
         STG(400, 0, 0) STG(401, 20, 0) STG(402, 50, 0) STG(403, 100, 0) STG(404, 200, 0) STG(405, 400, 0)
         STG(410, 0, 20480) STG(411, 0, 40960) STG(412, 0, 10240) STG(413, 50, 20480)
+        PRI(700, 0) PRI(701, 1) PRI(702, 2) PRI(703, 3)
         RMP(600, 3072, 0) RMP(601, 3072, 16) RMP(602, 3072, 32) RMP(603, 3072, 48) RMP(604, 3072, 64) RMP(605, 3072, 96) RMP(606, 3072, 128)
         RMP(610, 4096, 32) RMP(611, 4096, 64) RMP(612, 4096, 96) RMP(613, 2048, 32) RMP(614, 2048, 64) RMP(615, 8192, 64) RMP(616, 8192, 128)
         default: return -2;
