@@ -30,6 +30,8 @@ ap.add_argument("--rounds", type=int, default=8)
 ap.add_argument("--only", nargs="*", default=None)
 ap.add_argument("--extra", nargs="*", default=[], help="name=flag,flag,... additional variants")
 ap.add_argument("--lib", nargs="*", default=[], help="name=path/to/lib.so: a ready-built library (e.g. an older commit) as a variant")
+ap.add_argument("--geom", default="f32", choices=["f32", "kahan", "racerW", "racerD", "racerWC", "aos"],
+                help="which kernel family to time: the plain drone kernel, + Kahan rows, the Racer as written / omega*dt / components.PID, the AoS observation head")
 a = ap.parse_args()
 for e in a.extra:
     k, v = e.split("=", 1)
@@ -63,6 +65,10 @@ from fpyv_amd import _lib, load_params, sticks  # noqa: E402
 dev = torch.device("cuda:0")
 torch.zeros(1, device=dev)
 p = load_params(fps=1000, ceiling=100.0)
+if a.geom.startswith("racer"):
+    import numpy as np
+    p = p.replace(mode=1, racer_pid=np.asarray([[0.004, 0.02, 1e-6], [0.003, 0.01, 2e-6], [0.002, 0.005, 0.0]]),
+                  racer_omega_dt=(a.geom == "racerD"), racer_pid_variant=int(a.geom == "racerWC"), ceiling=100.0)
 cp = _lib.pack_params(p, auto_reset=True)
 n = a.n
 ring = 32 if n <= (1 << 21) else 4
@@ -73,6 +79,7 @@ for k in names:
     lib.fpv_create.argtypes = [C.c_void_p, C.c_int64, C.c_int, C.c_void_p]
     for f in (lib.fpv_rollout, lib.fpv_step_n):
         f.argtypes = [C.c_void_p, C.c_void_p, C.c_int, C.c_int64, C.c_int64, C.c_void_p]
+    lib.fpv_reset.argtypes = [C.c_void_p, C.c_void_p] + [C.c_void_p] * 5
     lib.fpv_recommended_ld.argtypes = [C.c_int64]
     lib.fpv_recommended_ld.restype = C.c_int64
     lib.fpv_last_error.restype = C.c_char_p
@@ -81,23 +88,29 @@ for k in names:
     assert rc == 0, lib.fpv_last_error()
     L[k], H[k] = lib, h
 ld = int(L[names[0]].fpv_recommended_ld(n))
-st = torch.zeros((14, ld), device=dev)
+st = torch.zeros((_lib.state_rows(int(p.mode)), ld), device=dev)
 rew = torch.zeros(n, device=dev)
 done = torch.zeros(n, dtype=torch.uint8, device=dev)
 b = _lib.FpvBuffers()
 b.state, b.ld, b.reward, b.done = st.data_ptr(), ld, rew.data_ptr(), done.data_ptr()
 b.action = acts.data_ptr()
+extra = None
+if a.geom == "kahan":
+    extra = torch.zeros((6, ld), device=dev)
+    b.pos_comp = extra.data_ptr()
+elif a.geom == "aos":
+    extra = torch.zeros((n, _lib.FPV_OBS_AOS_DIM), device=dev)
+    b.obs_aos = extra.data_ptr()
 
 
 def reset():
     st.zero_()
-    st[2] = 10
-    st[3] = 1
-    st[6] = 1
+    rc = L[names[0]].fpv_reset(H[names[0]], C.byref(b), None, None, None, None, None)
+    assert rc == 0, L[names[0]].fpv_last_error()
 
 
 e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-for api in ("fpv_rollout", "fpv_step_n"):
+for api in (("fpv_rollout",) if a.geom == "aos" else ("fpv_rollout", "fpv_step_n")):
     reps = (8 if n <= (1 << 21) else 16) * (6 if api == "fpv_step_n" else 1)      # ~6-8 ms per timing either way
     res = {k: [] for k in names}
     fin = {}
@@ -117,5 +130,5 @@ for api in ("fpv_rollout", "fpv_step_n"):
             fin[k] = st.clone()
     for k in names:
         med = statistics.median(res[k])
-        print(f"n={n} {api:12s} {k:12s}: median {med:8.3f} us/step  min {min(res[k]):8.3f}   {n / med / 1e3:8.2f} G env-steps/s   "
+        print(f"n={n} {a.geom:8s} {api:12s} {k:12s}: median {med:8.3f} us/step  min {min(res[k]):8.3f}   {n / med / 1e3:8.2f} G env-steps/s   "
               f"bitwise==first {bool(torch.equal(fin[k], fin[names[0]]))}", flush=True)
