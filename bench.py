@@ -582,6 +582,28 @@ def main(argv=None):
                                        "step-kernel launch at 2^23 drones, same process, before and after the kernel run"}}
         del big, acts_b, src, dst
 
+    # what a launch costs as a function of the population, on this box, in this process: the same kernel at half and at
+    # twice the headline population (both still inside the Infinity Cache).  With the headline's own time that gives
+    # the straight line t(n) = floor + bytes / rate (from 2^19 drones up the residuals are < 0.4 us):
+    # how much of the headline launch is the per-launch floor of a dependent kernel chain, and what the rest streams at
+    fit = None
+    if rank == 0 and world == 1 and not args.no_beyond_mall and args.api == "step" and n == (1 << 20) and not args.racer:
+        pts = []
+        for nn in (n // 2, 2 * n):
+            e = make_env(nn, False)
+            e.reset()
+            aa = sticks.ema_noise_device(8, nn, dev, seed=5)
+            run_on(e, aa, 40, 0, None)
+            torch.cuda.synchronize()
+            f0, f1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            f0.record()
+            run_on(e, aa, 400, 40, None)
+            f1.record()
+            torch.cuda.synchronize()
+            pts.append((e.algorithmic_bytes() * nn, f0.elapsed_time(f1) * 1e3 / 400))
+            del e, aa
+        fit = {"points_bytes_us": pts}
+
     if rank == 0:
         state_bytes = env.algorithmic_bytes()                                # 133 B fp32 / 89 B fp16 state
         kernel_s = dev_ms * 1e-3 / n_launches                                # avg launch-to-launch on the stream
@@ -629,8 +651,22 @@ def main(argv=None):
                          "cache_note": "at 2^20 drones the 59 MB state is re-read from the 256 MiB Infinity Cache (MALL) every step; "
                                        "only the action stream and reward/done cross HBM - `beyond_mall` is the same kernel at 2^23 drones",
                          "frac_beyond_mall": beyond["frac"] if beyond else None, "beyond_mall": beyond,
+                         "launch_time_fit": None,
                          "note": "avg = HIP-event time over the timed region / launches (includes inter-launch gaps)"},
         }
+        if fit is not None:
+            # least squares through (bytes, us) at 2^19, 2^20 (the headline run itself) and 2^21 drones
+            import numpy as np
+            pts = [fit["points_bytes_us"][0], (state_bytes * n, kernel_s * 1e6), fit["points_bytes_us"][1]]
+            A = np.array([[1.0, b_ / 1e6] for b_, _ in pts])
+            y = np.array([t_ for _, t_ in pts])
+            (t0, slope), *_ = np.linalg.lstsq(A, y, rcond=None)
+            out["roofline"]["launch_time_fit"] = {
+                "model": "avg_launch_us(n) = floor_us + algorithmic bytes / streaming rate, n = 2^19, 2^20, 2^21 drones (all inside the Infinity Cache)",
+                "drones": [n // 2, n, 2 * n], "avg_launch_us": [float(t_) for _, t_ in pts],
+                "floor_us": float(t0), "streaming_GBs": float(1.0 / slope * 1e3), "streaming_frac_of_peak": float(1.0 / slope * 1e3 / HBM_PEAK_GBS),
+                "floor_share_of_headline_launch": float(t0 / (kernel_s * 1e6)),
+                "max_residual_us": float(np.abs(A @ np.array([t0, slope]) - y).max())}
         if coll is not None:
             out["collective"] = coll
         if args.api == "rollout":
