@@ -228,6 +228,8 @@ def parse_args(argv=None):
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=20000)
     ap.add_argument("--warmup", type=int, default=200)
+    ap.add_argument("--default-stream", action="store_true",
+                    help="launch on the legacy default (null) stream instead of a stream of the run's own")
     ap.add_argument("--preheat-s", type=float, default=0.5,
                     help="seconds of untimed launches on a SCRATCH batch before the W warm-up steps, so the "
                          "GPU has left its idle clocks (the timed region is only K x ~25 us)")
@@ -394,6 +396,10 @@ def main(argv=None):
         raise SystemExit(f"rank {rank} needs GPU {local_rank}, this node has {torch.cuda.device_count()}")
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
+    if not args.default_stream:
+        # the whole run on a stream of its own instead of the legacy default stream: a launch on the null stream orders
+        # itself against every blocking stream of the process (a collective library's internal ones, for instance)
+        torch.cuda.set_stream(torch.cuda.Stream(device=dev))
     multi = world > 1 or args.force_dist
     if multi:
         if "MASTER_ADDR" not in os.environ:
