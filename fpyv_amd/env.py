@@ -501,6 +501,13 @@ class DroneBatch(_Batch):
         acc = self.accel[:, :self.n].t() if self.accel is not None else None
         return R.transpose(-1, -2), gyro, acc
 
+    def get_gravity_force_in_drone_ref_frame(self) -> torch.Tensor:
+        """Drone.get_gravity_force_in_drone_ref_frame (components.py:254-255), [num_envs, 3]: the reference multiplies
+        the gravity vector by R (body -> world), not by its transpose, and hard-wires g = 9.81 whatever
+        simulator.gravity says - reproduced as written."""
+        g = torch.tensor([0.0, 0.0, -9.81 * self.mass], dtype=torch.float32, device=self.device)   # kinematics.py:41-45
+        return self.rotation_matrix @ g
+
     def _set_override(self, rotation_matrix, thrust_force) -> None:
         if rotation_matrix is None:
             return                                   # components.py:230: thrust_force alone changes nothing

@@ -1638,6 +1638,18 @@ def test_random_drone_types_bitwise_and_1e5(params_1k, seed):
     assert_parity_random_type(got, ref, n, p, REL_TOL, f"random drone type {seed}")
 
 
+def test_gravity_force_helper_as_written(params_1k):
+    """Drone.get_gravity_force_in_drone_ref_frame = R @ [0, 0, -9.81 m] (components.py:254-255), R body -> world."""
+    env = _drone_batch(params_1k, 5)
+    env.reset(ypr=np.array([[0, 0, 0], [30, 0, 0], [0, 45, 0], [10, -20, 70], [180, 0, 0]], dtype=np.float32))
+    got = env.get_gravity_force_in_drone_ref_frame().cpu().numpy()
+    R = env.rotation_matrix.cpu().numpy().astype(np.float64)
+    want = R @ np.array([0, 0, -9.81 * params_1k.mass])
+    np.testing.assert_allclose(got, want, rtol=1e-5, atol=1e-5)
+    np.testing.assert_allclose(got[0], [0, 0, -9.81 * 0.75], atol=1e-6)
+    np.testing.assert_allclose(got[4], [0, 0, 9.81 * 0.75], atol=1e-5)      # rolled upside down
+
+
 def test_reference_scalar_attributes_of_drone(params_1k):
     """The attributes simulator.py reads off the Drone besides position / velocity / done (`throttle` :161,
     `prev_rates` / `prev_thrust` :64-65) and the thrust-curve helpers of components.py:136-142, against the
