@@ -259,7 +259,10 @@ int fpv_get_step_counter(fpv_handle_t h, uint64_t* step);
  * its SHAPE changes (k, strides, launch geometry, parameters, which optional buffers are present); new
  * buffer addresses alone are patched into the instantiated graph.  Frozen arguments mean no per-launch
  * step index, so handles with FPV_FLAG_STICK_NOISE or FPV_FLAG_FP16_STATE are served by the k-step kernel
- * (fpv_step_n: the same k steps bit for bit, and cheaper than a replay). */
+ * (fpv_step_n: the same k steps bit for bit, and cheaper than a replay).
+ * The same holds for a graph the CALLER captures around fpv_step / fpv_rollout (stream capture records the launches
+ * with the step index they had at capture time): fine for plain handles, wrong - a repeating noise stream - for
+ * FPV_FLAG_STICK_NOISE / FPV_FLAG_FP16_STATE handles, whose launches must be issued, not replayed. */
 int fpv_rollout_graph(fpv_handle_t h, const fpv_buffers_t* b, int k, int64_t action_stride,
                       int64_t out_stride, void* stream);
 
