@@ -429,6 +429,37 @@ def euler_zyx_matrix(angles: torch.Tensor) -> torch.Tensor:
                         -sp, cp * sr, cp * cr], dim=-1).reshape(angles.shape[:-1] + (3, 3))
 
 
+def matrix_to_euler_zyx(R: torch.Tensor) -> torch.Tensor:
+    """Rotation matrices [...,3,3] -> (roll, pitch, yaw) [...,3] in radians, the inverse of `euler_zyx_matrix`:
+    helper_functions.rotation_matrix_to_euler_angles (/root/reference/src/utils/helper_functions.py:47-62) as it
+    executes - its gimbal-lock branch is unreachable (`R[2,0] != 1 or R[2,0] != -1` is always true), so this is its
+    general branch for every input."""
+    x = torch.atan2(R[..., 2, 1], R[..., 2, 2])
+    y = torch.asin((-R[..., 2, 0]).clamp(-1.0, 1.0))
+    z = torch.atan2(R[..., 1, 0], R[..., 0, 0])
+    return torch.stack([x, y, z], dim=-1)
+
+
+def matrix_to_quat(R: torch.Tensor) -> torch.Tensor:
+    """Rotation matrices [...,3,3] -> unit quaternions (w,x,y,z) [...,4] with w >= 0.  Same rotation as
+    helper_functions.rotation_matrix_to_quaternion (helper_functions.py:65-80), which divides by 4 qw and so loses
+    its accuracy near half-turn attitudes; this one picks the largest of the four pivots (Shepperd), like the kernel's
+    fpv_quat_from_rot."""
+    m00, m11, m22 = R[..., 0, 0], R[..., 1, 1], R[..., 2, 2]
+    t = torch.stack([1 + m00 + m11 + m22, 1 + m00 - m11 - m22, 1 - m00 + m11 - m22, 1 - m00 - m11 + m22], dim=-1)
+    k = t.argmax(dim=-1)
+    r = torch.sqrt(t.gather(-1, k.unsqueeze(-1)).squeeze(-1).clamp_min(0)) * 2          # 4 * |largest component|
+    a, b, c = R[..., 2, 1] - R[..., 1, 2], R[..., 0, 2] - R[..., 2, 0], R[..., 1, 0] - R[..., 0, 1]
+    d, e, f = R[..., 0, 1] + R[..., 1, 0], R[..., 0, 2] + R[..., 2, 0], R[..., 1, 2] + R[..., 2, 1]
+    q0 = torch.stack([r / 4, a / r, b / r, c / r], dim=-1)
+    q1 = torch.stack([a / r, r / 4, d / r, e / r], dim=-1)
+    q2 = torch.stack([b / r, d / r, r / 4, f / r], dim=-1)
+    q3 = torch.stack([c / r, e / r, f / r, r / 4], dim=-1)
+    kk = k.unsqueeze(-1)
+    q = torch.where(kk == 0, q0, torch.where(kk == 1, q1, torch.where(kk == 2, q2, q3)))
+    return torch.where(q[..., :1] < 0, -q, q)
+
+
 class DroneBatch(_Batch):
     """N reference `Drone`s stepped by one HIP kernel (mode "drone")."""
 
@@ -500,6 +531,11 @@ class DroneBatch(_Batch):
         gyro = euler_zyx_matrix(rates)            # deg/s values used as radians, as the reference does (:247)
         acc = self.accel[:, :self.n].t() if self.accel is not None else None
         return R.transpose(-1, -2), gyro, acc
+
+    @property
+    def euler_angles(self) -> torch.Tensor:
+        """[num_envs, 3] (roll, pitch, yaw) in radians of the current attitude (helper_functions.py:47-62)."""
+        return matrix_to_euler_zyx(self.rotation_matrix)
 
     def get_gravity_force_in_drone_ref_frame(self) -> torch.Tensor:
         """Drone.get_gravity_force_in_drone_ref_frame (components.py:254-255), [num_envs, 3]: the reference multiplies

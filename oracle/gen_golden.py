@@ -523,6 +523,17 @@ def main():
              min_throttle_in_force=float(d.min_throttle_in_force), max_throttle_in_force=float(d.max_throttle_in_force),
              cross_section_areas=d.cross_section_areas, mass=float(d.mass), **stack([c]))
 
+    # ---- G17: the rotation helpers next to the step (helper_functions.py:39-80, :100-117): Euler -> matrix -> Euler,
+    # matrix <-> quaternion, on seeded attitudes (pitch kept inside +-89 degrees: the reference's own formula) ----
+    from utils import helper_functions as hf
+    rng = np.random.default_rng(17)
+    ang = np.stack([rng.uniform(-np.pi, np.pi, 64), rng.uniform(-1.55, 1.55, 64), rng.uniform(-np.pi, np.pi, 64)], axis=1)
+    mats = np.stack([hf.euler_angles_to_rotation_matrix(*a_) for a_ in ang])
+    save("g17_rotation_helpers", euler_in=ang, matrix=mats,
+         euler_out=np.stack([hf.rotation_matrix_to_euler_angles(m) for m in mats]),
+         quat_wxyz=np.stack([hf.rotation_matrix_to_quaternion(m) for m in mats]),
+         matrix_from_quat=np.stack([hf.quaternion_to_rotation_matrix(hf.rotation_matrix_to_quaternion(m)) for m in mats]))
+
     leftovers = [r for r, ds, _ in os.walk(REF) if "__pycache__" in ds]
     assert not leftovers, f"bytecode written into the reference mount: {leftovers}"
 

@@ -94,3 +94,25 @@ def test_min_throttle_assert(params_1k):
     cfg["simulator"]["gravity"] = -9.81      # flips the sign of the bench thrust -> 5 % thrust < 0
     with pytest.raises(ValueError, match="minimum throttle"):
         params_from_dict(cfg)
+
+
+def test_rotation_helpers_against_the_reference():
+    """Capture G17: helper_functions' Euler -> matrix -> Euler and matrix <-> quaternion (helper_functions.py:39-80,
+    :100-117) on 64 seeded attitudes; the build's torch helpers (fpyv_amd.env) run on CPU tensors here."""
+    import torch
+    from fpyv_amd.env import euler_zyx_matrix, matrix_to_euler_zyx, matrix_to_quat, quat_to_matrix
+    g = load_golden("g17_rotation_helpers")
+    ang = torch.from_numpy(g["euler_in"])
+    R = euler_zyx_matrix(ang)
+    np.testing.assert_allclose(R.numpy(), g["matrix"], atol=1e-14)
+    np.testing.assert_allclose(matrix_to_euler_zyx(torch.from_numpy(g["matrix"])).numpy(), g["euler_out"], atol=1e-12)
+    q = matrix_to_quat(torch.from_numpy(g["matrix"]))
+    assert bool((q[:, 0] >= 0).all()) and float((q.norm(dim=1) - 1).abs().max()) < 1e-14
+    np.testing.assert_allclose(q.numpy(), g["quat_wxyz"], atol=1e-9)              # the reference's own form loses digits near half turns
+    np.testing.assert_allclose(quat_to_matrix(q).numpy(), g["matrix"], atol=1e-13)
+    np.testing.assert_allclose(quat_to_matrix(torch.from_numpy(g["quat_wxyz"])).numpy(), g["matrix_from_quat"], atol=1e-13)
+    # half-turn attitudes, where 1 + trace vanishes and the reference's formula divides by ~0: the build's stays exact
+    half = torch.tensor([[[1.0, 0, 0], [0, -1, 0], [0, 0, -1]], [[-1.0, 0, 0], [0, 1, 0], [0, 0, -1]], [[-1.0, 0, 0], [0, -1, 0], [0, 0, 1]]],
+                        dtype=torch.float64)
+    qh = matrix_to_quat(half)
+    np.testing.assert_allclose(quat_to_matrix(qh).numpy(), half.numpy(), atol=1e-15)
