@@ -26,6 +26,8 @@ void fpvl_set_pos_comp(float* c);
 void fpvl_set_override(const float* rot, const float* thrust);
 void fpvl_pid_run(const double k[8], float st[4], int T, const float* current, const float* target, float* out);
 void fpvl_sincos_wide(double x, double* s, double* c);
+void fpvl_sincos_reduced(float x, float* s, float* c);
+void fpvl_quat_from_rpy_deg(float roll, float pitch, float yaw, float q[4]);
 }
 
 static uint32_t g_lcg = 12345u;
@@ -83,6 +85,15 @@ int main()
     objs.obj[0] = {2, 0.3f, -0.2f, 0.9f, 0.35f, 0.0f};
     objs.obj[1] = {1, 1.2f, 0.4f, 0.0f, 0.5f, 1.1f};
     objs.obj[2] = {0, 0, 0, 0, 0, 0};
+    // the reset kernel's attitude and the range-reduced sin / cos behind it, out to angles no reset will ever see
+    for (int k = 0; k < 2000; ++k) {
+        float q[4], sn, cs;
+        const float big = (float)(urand() * (k % 7 == 0 ? 1.0e6 : 720.0));
+        fpvl_quat_from_rpy_deg(big, (float)(urand() * 90.0), (float)(urand() * 720.0), q);
+        fpvl_sincos_reduced(big, &sn, &cs);
+        const double nn = (double)q[0] * q[0] + (double)q[1] * q[1] + (double)q[2] * q[2] + (double)q[3] * q[3];
+        if (!(fabs(nn - 1.0) < 1e-5) || !(fabs((double)sn * sn + (double)cs * cs - 1.0) < 1e-5)) { fprintf(stderr, "reset attitude: not unit\n"); return 3; }
+    }
     const int sizes[4] = {1, 63, 257, 1000};
     for (int si = 0; si < 4; ++si) {
         const int64_t n = sizes[si], ld = (n + 63) / 64 * 64;
