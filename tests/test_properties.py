@@ -55,3 +55,26 @@ def test_done_flag_is_exactly_any_motor_below_ground(z, roll, pitch):
     _, _, done, _ = lane_model.run(P, s, np.zeros((1, 4), np.float32), steps=1)
     if np.min(np.abs(motors_z)) > 1e-5:            # away from the fp32 decision boundary
         assert bool(done[0]) == bool((motors_z < 0).any())
+
+
+@settings(max_examples=20, deadline=None)
+@given(seed=st.integers(0, 2 ** 31 - 1), n=st.integers(2, 90), cut=st.integers(1, 89), step0=st.sampled_from([0, 5, 2 ** 32 - 3]),
+       rseed=st.integers(0, 2 ** 32 - 1))
+def test_fp16_state_does_not_depend_on_the_shard_a_drone_is_in(seed, n, cut, step0, rseed):
+    """fp16 storage: the stochastic rounding of a drone is keyed by its GLOBAL id (and the step index, and the buffer's
+    rounding seed), so a population stepped as one batch and as two shards with drone_id_offset = the shard's first id
+    ends in the same half-precision bits - odd cuts included, where the thrust halves of the two neighbours of the cut
+    no longer share a word - and across the 2^32 step boundary."""
+    cut = 1 + (cut - 1) % (n - 1)
+    rng = np.random.default_rng(seed)
+    steps = 12
+    acts = rng.uniform(-1, 1, (steps, n, 4)).astype(np.float32)
+    whole_pos, whole_sh = lane_model.split_half(lane_model.initial_state(P, n))
+    lane_model.run_h(P, whole_pos, whole_sh, acts, seed0=rseed, step0=step0)
+    whole = lane_model.join_half(whole_pos, whole_sh)
+    for lo, hi in ((0, cut), (cut, n)):
+        m = hi - lo
+        pos, sh = lane_model.split_half(lane_model.initial_state(P, m))
+        lane_model.run_h(P, pos, sh, np.ascontiguousarray(acts[:, lo:hi]), seed0=rseed, step0=step0, drone_id_offset=lo)
+        part = lane_model.join_half(pos, sh)
+        assert np.array_equal(part[:, :m].view(np.uint32), whole[:, lo:hi].view(np.uint32)), (lo, hi)
