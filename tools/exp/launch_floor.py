@@ -21,9 +21,26 @@ from fpyv_amd.env import DroneBatch  # noqa: E402
 
 dev = torch.device("cuda", 0)
 params = load_params(fps=1000, ceiling=100.0)
+geom = sys.argv[1] if len(sys.argv) > 1 else "f32"        # f32 | fp16 | kahan | racerW | racerD
 rows = []
-for n in (1 << 12, 1 << 14, 1 << 16, 1 << 17, 1 << 18, 5 << 16, 6 << 16, 7 << 16, 1 << 19, 3 << 18, 1 << 20, 5 << 18, 3 << 19, 7 << 18, 1 << 21):
-    env = DroneBatch(params, n, device=dev, auto_reset=True, with_accel=False)
+sizes = (1 << 12, 1 << 14, 1 << 16, 1 << 17, 1 << 18, 5 << 16, 6 << 16, 7 << 16, 1 << 19, 3 << 18, 1 << 20, 5 << 18, 3 << 19, 7 << 18, 1 << 21)
+if geom != "f32":
+    sizes = (1 << 12, 1 << 18, 1 << 19, 3 << 18, 1 << 20, 3 << 19, 1 << 21)
+
+
+def make(n):
+    if geom.startswith("racer"):
+        from fpyv_amd.env import RacerBatch
+        rp = params.replace(mode=1, racer_pid=np.asarray([[0.004, 0.02, 1e-6], [0.003, 0.01, 2e-6], [0.002, 0.005, 0.0]]),
+                            racer_omega_dt=(geom == "racerD"), ceiling=100.0)
+        return RacerBatch(rp, n, device=dev, auto_reset=True)
+    return DroneBatch(params, n, device=dev, auto_reset=True, with_accel=False, fp16_state=(geom == "fp16"),
+                      kahan_position=(geom == "kahan"))
+
+
+print(f"# kernel family: {geom}")
+for n in sizes:
+    env = make(n)
     env.reset()
     k = 32
     acts = sticks.ema_noise_device(k, n, dev, seed=7)
