@@ -20,7 +20,7 @@ n = int(sys.argv[2]) if len(sys.argv) > 2 else 1 << 20
 params = load_params(fps=1000, ceiling=100.0)
 acts = sticks.ema_noise_device(32, n, dev, seed=3)
 base = (-n) % 1024                                   # pads are given relative to the next multiple of 1024 floats (4 KiB)
-pads = tuple(base + x for x in (0, 64, 128, 256, 512, 768, 1024, 1280, 2048, 2304, 3072, 4096, 8192))
+pads = tuple(base + x for x in (0, 256, 512, 1024, 2048, 4096, 6144, 8192, 10240, 16384))
 envs = {}
 for pad in pads:
     e = DroneBatch(params, n, device=dev, auto_reset=True, with_accel=False, fp16_state=(geom == "fp16"), kahan_position=(geom == "kahan"))
