@@ -73,3 +73,25 @@ def test_under_a_launcher_the_world_size_must_match():
     env = dict(_clean_env(), RANK="0", LOCAL_RANK="0", WORLD_SIZE="3", MASTER_ADDR="127.0.0.1", MASTER_PORT="29999")
     r = subprocess.run([sys.executable, BENCH, "--gpus", "2", "--stub-step"], capture_output=True, text=True, timeout=120, env=env)
     assert r.returncode != 0 and "WORLD_SIZE=3" in r.stderr
+
+
+def test_the_drivers_own_launcher_in_the_drivers_shape_four_ranks():
+    """What the round-end driver runs for N > 1, to the letter - `python -m torch.distributed.run --nnodes=1
+    --nproc-per-node N --master-addr 127.0.0.1 --master-port P bench.py --gpus N --steps 20 --warmup 5` - with the stub
+    step (no GPU here) at four ranks: RANK / WORLD_SIZE / MASTER_* come from the launcher, nothing is self-launched, rank 0
+    prints exactly one line, the short shape's bucket (16 steps) and its flushed tail (9 rows) both travel."""
+    import socket
+    with socket.socket() as sk:
+        sk.bind(("127.0.0.1", 0))
+        port = sk.getsockname()[1]
+    r = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "4", "--master-addr", "127.0.0.1",
+                        "--master-port", str(port), BENCH, "--gpus", "4", "--steps", "20", "--warmup", "5", "--stub-step",
+                        "--drones-per-gpu", "4099"], capture_output=True, text=True, timeout=400, env=_clean_env())
+    assert r.returncode == 0, r.stderr[-3000:]
+    lines = [ln for ln in r.stdout.splitlines() if ln.strip().startswith("{")]
+    assert len(lines) == 1, f"rank 0 must print exactly one JSON line, got {lines}"
+    out = json.loads(lines[0])
+    assert out["n_gpus"] == 4 and out["steps"] == 20 and out["warmup"] == 5 and out["gather_ok"] is True
+    c = out["collective"]
+    assert c["world_seen"] == 4 and c["rank_ids_gathered"] == [0, 1, 2, 3] and len(c["per_rank_ms_per_step"]["all"]) == 4
+    assert c["gather"]["block_steps"] == 16 and c["gather"]["collectives_launched"] == 2
