@@ -862,6 +862,28 @@ __global__ __launch_bounds__(kBlock) void fpv_reset_kernel(const FpvK K, const F
     }
 }
 
+// The return value of Drone.step for every drone (components.py:247-248): rotation_matrix.T and the "angular velocity
+// matrix" E(rates) as [n][3][3] row-major, R_new @ acceleration as [n][3] (copied from the step kernel's accel rows).
+// One lane per drone; the outputs are what a caller of the reference's API reads on the host side of the boundary
+// (36-byte lane stride: a convenience path, not the hot one - the zero-copy SoA state is the observation).
+__global__ __launch_bounds__(kBlock) void fpv_return_triple_kernel(const float* __restrict__ st, const int64_t ld,
+                                                                   const float* __restrict__ accel, float* __restrict__ rt,
+                                                                   float* __restrict__ gyro, float* __restrict__ acc, const int64_t n)
+{
+    const int64_t i = (int64_t)blockIdx.x * kBlock + threadIdx.x;
+    if (i >= n) return;
+    FpvQuat q;
+    q.w = st[FPV_QW * ld + i]; q.x = st[FPV_QX * ld + i]; q.y = st[FPV_QY * ld + i]; q.z = st[FPV_QZ * ld + i];
+    float a[9], g[9];
+    fpv_return_matrices(q, st[FPV_RX * ld + i], st[FPV_RY * ld + i], st[FPV_RZ * ld + i], a, g);
+#pragma unroll
+    for (int k = 0; k < 9; ++k) { rt[9 * i + k] = a[k]; gyro[9 * i + k] = g[k]; }
+    if (acc) {
+#pragma unroll
+        for (int k = 0; k < 3; ++k) acc[3 * i + k] = accel[(int64_t)k * ld + i];
+    }
+}
+
 // components.PID.__call__ for n drones (components.py:43-54): one lane per drone, four state rows.
 __global__ __launch_bounds__(kBlock) void fpv_pid_kernel(const FpvPidK<float> P, float* __restrict__ st, const int64_t ld,
                                                          const int64_t n, const float* __restrict__ current,
@@ -1454,6 +1476,22 @@ int fpv_rollout_graph(fpv_handle_t h, const fpv_buffers_t* b, int k, int64_t act
     const hipError_t e = hipGraphLaunch(h->graph_exec, (hipStream_t)stream);
     if (e != hipSuccess) return hip_fail(e, "hipGraphLaunch");
     h->launches += (uint64_t)k;
+    return FPV_OK;
+}
+
+int fpv_return_triple(fpv_handle_t h, const fpv_buffers_t* b, float* rt, float* gyro, float* acc, void* stream)
+{
+    if (!h || !b || !b->state || !rt || !gyro) return fail(FPV_EINVAL, "null argument");
+    if (h->mode != FPV_MODE_DRONE || (h->K.flags & FPV_FLAG_FP16_STATE))
+        return fail(FPV_EINVAL, "fpv_return_triple reads the fp32 drone state (Drone.step's return value)");
+    if (b->ld < h->n) return fail(FPV_EALIGN, "fpv_buffers_t.ld is smaller than the number of drones");
+    if (acc && !b->accel) return fail(FPV_EINVAL, "R @ acceleration needs fpv_buffers_t.accel (the step kernel writes it there)");
+    const DeviceGuard dev(h->device);
+    if (dev.rc != FPV_OK) return dev.rc;
+    hipLaunchKernelGGL(fpv_return_triple_kernel, dim3((unsigned)((h->n + kBlock - 1) / kBlock)), dim3(kBlock), 0, (hipStream_t)stream,
+                       b->state, b->ld, b->accel, rt, gyro, acc, h->n);
+    const hipError_t e = hipGetLastError();
+    if (e != hipSuccess) return hip_fail(e, "return-triple kernel launch");
     return FPV_OK;
 }
 

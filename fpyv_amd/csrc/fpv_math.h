@@ -196,6 +196,26 @@ FPV_HD FpvRot fpv_rot(FpvQuat q)
     return R;
 }
 
+// The first two members of Drone.step's return triple (components.py:247-248) for one drone:
+//   rt[9]   = rotation_matrix.T, row-major - the attitude AFTER the step;
+//   gyro[9] = euler_angles_to_rotation_matrix(*rates) = Rz(rates_z) Ry(rates_y) Rx(rates_x) with the low-passed rates,
+//             DEGREES PER SECOND, used as radians (quirk Q6) - tens to hundreds of radians, hence the reduced sin / cos.
+// (The third member, R_new @ acc, is the step kernel's `accel` output.)
+FPV_HD void fpv_return_matrices(FpvQuat q, float rx, float ry, float rz, float rt[9], float gyro[9])
+{
+    const FpvRot R = fpv_rot(q);
+    rt[0] = R.r00; rt[1] = R.r10; rt[2] = R.r20;
+    rt[3] = R.r01; rt[4] = R.r11; rt[5] = R.r21;
+    rt[6] = R.r02; rt[7] = R.r12; rt[8] = R.r22;
+    float sr, cr, sp, cp, sy, cy;
+    fpv_sincos_reduced(rx, &sr, &cr);
+    fpv_sincos_reduced(ry, &sp, &cp);
+    fpv_sincos_reduced(rz, &sy, &cy);
+    gyro[0] = cy * cp; gyro[1] = fmaf(cy * sp, sr, -(sy * cr)); gyro[2] = fmaf(cy * sp, cr, sy * sr);      // helper_functions.py:39-44
+    gyro[3] = sy * cp; gyro[4] = fmaf(sy * sp, sr, cy * cr);    gyro[5] = fmaf(sy * sp, cr, -(cy * sr));
+    gyro[6] = -sp;     gyro[7] = cp * sr;                       gyro[8] = cp * cr;
+}
+
 // q <- normalise(q + q (x) d) for a small-ish quaternion increment d = (dw, dx, dy, dz) (i.e. the
 // full factor is 1 + d).  First-order renormalisation: |q|^2 - 1 stays at rounding level because
 // it is corrected every step.

@@ -540,6 +540,15 @@ class DroneBatch(_Batch):
                 self._override_keep = None
         if not return_imu:
             return None
+        if not self.fp16_state:
+            # one small kernel (fpv_return_triple) instead of ~30 tensor operations: fresh tensors every call, like the
+            # reference's fresh arrays (a caller may keep them across steps)
+            rt = torch.empty((self.n, 3, 3), dtype=torch.float32, device=self.device)
+            gyro = torch.empty((self.n, 3, 3), dtype=torch.float32, device=self.device)
+            acc = torch.empty((self.n, 3), dtype=torch.float32, device=self.device) if self.accel is not None else None
+            _lib.check(self._L.fpv_return_triple(self._handle, self._buf_ref, rt.data_ptr(), gyro.data_ptr(),
+                                                 acc.data_ptr() if acc is not None else None, self._stream()))
+            return rt, gyro, acc
         R = self.rotation_matrix
         rates = self.rows_f32(_lib.RX, _lib.RZ + 1)
         gyro = euler_zyx_matrix(rates)            # deg/s values used as radians, as the reference does (:247)

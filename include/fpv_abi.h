@@ -245,6 +245,13 @@ int fpv_rollout(fpv_handle_t h, const fpv_buffers_t* b, int k, int64_t action_st
 int fpv_step_n(fpv_handle_t h, const fpv_buffers_t* b, int k, int64_t action_stride,
                int64_t out_stride, void* stream);
 
+/* Drone.step's RETURN VALUE for every drone (components.py:247-248), after a step: rt [n][3][3] = rotation_matrix.T,
+ * gyro [n][3][3] = euler_angles_to_rotation_matrix(*rates) - the low-passed rates in deg/s used as radians, as the
+ * reference does -, acc [n][3] = rotation_matrix @ acceleration (copied from fpv_buffers_t.accel, which the step wrote;
+ * null = not wanted).  One small kernel instead of a few dozen tensor operations on the host side of the boundary;
+ * fp32 drone state only. */
+int fpv_return_triple(fpv_handle_t h, const fpv_buffers_t* b, float* rt, float* gyro, float* acc, void* stream);
+
 /* The 64-bit step index that keys the stick-noise stream (Philox4x32-10 counter = global drone id, step index; key =
  * noise_seed) and the stochastic rounding counts the steps a handle has launched, from 0: set it to resume / replay a
  * run, read it to checkpoint one.  2^64 steps do not wrap in practice (2^32 took 5.5 h at the k-step kernel's rate,

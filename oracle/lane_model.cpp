@@ -209,6 +209,12 @@ extern "C" int64_t fpvl_max_drones(void) { return FPV_MAX_DRONES; }
 extern "C" void fpvl_sincos_wide(double x, double* s, double* c) { fpv_sincos_wide(x, s, c); }
 extern "C" void fpvl_sincos_reduced(float x, float* s, float* c) { fpv_sincos_reduced(x, s, c); }
 extern "C" uint32_t fpvl_round_seed(uint32_t base, uint64_t step) { return fpv_round_seed(base, step); }
+// the first two members of Drone.step's return triple as the kernel forms them: q = (w, x, y, z), rates in deg/s
+extern "C" void fpvl_return_matrices(const float q[4], const float rates[3], float rt[9], float gyro[9])
+{
+    FpvQuat Q; Q.w = q[0]; Q.x = q[1]; Q.y = q[2]; Q.z = q[3];
+    fpv_return_matrices(Q, rates[0], rates[1], rates[2], rt, gyro);
+}
 // the reset kernel's attitude for a per-drone (roll, pitch, yaw) in degrees: q[4] = w, x, y, z
 extern "C" void fpvl_quat_from_rpy_deg(float roll, float pitch, float yaw, float q[4])
 {

@@ -31,6 +31,20 @@ def lib() -> C.CDLL:
     return _L
 
 
+def return_matrices(state: np.ndarray, n: int):
+    """(rt [n,3,3], gyro [n,3,3]) of Drone.step's return triple from a [14, ld] fp32 state, by the kernel's own
+    instructions (fpv_return_matrices, csrc/fpv_math.h)."""
+    L = lib()
+    L.fpvl_return_matrices.argtypes = [C.c_void_p] * 4
+    L.fpvl_return_matrices.restype = None
+    rt, gy = np.zeros((n, 9), dtype=np.float32), np.zeros((n, 9), dtype=np.float32)
+    for i in range(n):
+        q = np.ascontiguousarray(state[6:10, i], dtype=np.float32)
+        r = np.ascontiguousarray(state[10:13, i], dtype=np.float32)
+        L.fpvl_return_matrices(q.ctypes.data, r.ctypes.data, rt[i].ctypes.data, gy[i].ctypes.data)
+    return rt.reshape(n, 3, 3), gy.reshape(n, 3, 3)
+
+
 def quat_from_rpy_deg(roll: float, pitch: float, yaw: float) -> np.ndarray:
     """The reset kernel's own fp32 attitude for a per-drone ypr argument (fpv_quat_from_rpy_deg, csrc/fpv_math.h)."""
     L = lib()

@@ -124,6 +124,37 @@ def test_step_return_triple_matches_reference(params_1k):
     assert env.done.dtype == torch.bool and not env.done.any()
 
 
+def test_return_triple_kernel_equals_host_build_and_torch_form(params_1k):
+    """fpv_return_triple (what DroneBatch.step returns for fp32 state): rotation_matrix.T and E(rates) for 777 drones after
+    300 steps of noise sticks, bit for bit the host build of the same instructions, within 2e-6 / 2e-4 of the float64
+    formula (rates of tens of deg/s used as radians), the accel rows copied through; one launch instead of ~30."""
+    n = 777
+    env = _drone_batch(params_1k, n)
+    env.reset()
+    a = torch.from_numpy(sticks.ema_noise(300, range(n), seed=9)).to(DEV)
+    env.rollout(a[:299])
+    RT, gyro, acc = env.step(a[299])
+    torch.cuda.synchronize()
+    st = env.state.cpu().numpy()
+    rt_h, gy_h = lane_model.return_matrices(st, n)
+    assert np.array_equal(RT.cpu().numpy().view(np.uint32), rt_h.view(np.uint32))
+    assert np.array_equal(gyro.cpu().numpy().view(np.uint32), gy_h.view(np.uint32))
+    assert torch.equal(acc, env.accel[:, :n].t())
+    q = st[6:10, :n].T.astype(np.float64)
+    np.testing.assert_allclose(RT.cpu().numpy(), np.transpose(oracle.quat_to_matrix(q), (0, 2, 1)), atol=2e-6)
+    r = st[10:13, :n].T.astype(np.float64)
+    cr, sr, cp, sp, cy, sy = np.cos(r[:, 0]), np.sin(r[:, 0]), np.cos(r[:, 1]), np.sin(r[:, 1]), np.cos(r[:, 2]), np.sin(r[:, 2])
+    E = np.stack([cy * cp, cy * sp * sr - sy * cr, cy * sp * cr + sy * sr, sy * cp, sy * sp * sr + cy * cr, sy * sp * cr - cy * sr,
+                  -sp, cp * sr, cp * cr], axis=1).reshape(n, 3, 3)
+    np.testing.assert_allclose(gyro.cpu().numpy(), E, atol=2e-4)
+    assert np.abs(r).max() > 20, "the scenario must reach rates of tens of deg/s"
+    # fp16 handles keep the tensor-op form; a batch built without accel rows returns None for the third member
+    lean = _drone_batch(params_1k, 8, with_accel=False)
+    lean.reset()
+    out = lean.step(a[0, :8].contiguous())
+    assert out[2] is None and out[0].shape == (8, 3, 3)
+
+
 def test_default_fps60(params_60):
     g = load_golden("g1b_fps60_sin")
     n = g["actions"].shape[1]
