@@ -398,7 +398,14 @@ class _Batch:
 
     @property
     def rotation_matrix(self) -> torch.Tensor:
-        """[num_envs, 3, 3], computed from the quaternion (helper_functions.py:100-117)."""
+        """[num_envs, 3, 3] body -> world, computed from the quaternion (helper_functions.py:100-117): for fp32 drone
+        state by the return-triple kernel (one launch; the transpose of its R.T output is a view), otherwise by tensor
+        operations."""
+        if self.mode == MODE_DRONE and not self.fp16_state:
+            rt = torch.empty((self.n, 3, 3), dtype=torch.float32, device=self.device)
+            gy = torch.empty((self.n, 3, 3), dtype=torch.float32, device=self.device)
+            _lib.check(self._L.fpv_return_triple(self._handle, self._buf_ref, rt.data_ptr(), gy.data_ptr(), None, self._stream()))
+            return rt.transpose(-1, -2)
         return quat_to_matrix(self.quaternion)
 
 def as_drone_params(params: Any, mode: int, default_fps: Optional[float] = None) -> DroneParams:

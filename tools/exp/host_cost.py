@@ -38,4 +38,6 @@ for _ in range(2):
     t(lambda i: e.step(ring[i & 63], return_imu=False), "DroneBatch.step(ring[i], ...): a fresh view object per step")
     t(lambda i: e.step(a), "DroneBatch.step(same tensor): with the reference's return triple")
     t(lambda i: ve.step(a), "FpvVecEnv.step(same tensor) -> (obs, reward, done, info)")
+    t(lambda i: e.rotation_matrix, "DroneBatch.rotation_matrix (no step)")
+    t(lambda i: e.euler_angles, "DroneBatch.euler_angles (no step)")
     print()
