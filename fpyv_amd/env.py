@@ -93,6 +93,7 @@ class _Batch:
         self.obs_aos = (torch.zeros((self.n, _lib.FPV_OBS_AOS_DIM), **f32) if with_obs_aos else None)
         self._bcast_action = None
         self._objects = None            # the bound fpv_objects_t (None = no collision world bound)
+        self._object_rows = None
         self._last_action, self._last_action_ptr = None, 0
         self._override_keep = None
         self._done_bits_keep = None
@@ -279,7 +280,9 @@ class _Batch:
         from .objects import to_rows
         rows = to_rows(object_list)
         if rows:
-            self._objects = _lib.pack_objects(rows)
+            if rows != self._object_rows or self._objects is None:      # a world that did not move is not re-packed
+                self._objects = _lib.pack_objects(rows)
+                self._object_rows = rows
             self._buf.objects = C.addressof(self._objects)
         else:
             self._objects = None
@@ -665,10 +668,16 @@ class FpvVecEnv:
         self.object_list = list(object_list)
         self.obs_dim = 13
         self.action_dim = 4
+        self._obs_view = None
 
     @property
     def obs(self) -> torch.Tensor:
-        return self.batch.rows_f32(0, 13)
+        if self._obs_view is None:
+            v = self.batch.rows_f32(0, 13)
+            if self.batch.fp16_state:
+                return v                     # a converted copy: made afresh every time
+            self._obs_view = v               # fp32 storage: a view of the state tensor, which never moves
+        return self._obs_view
 
     def reset(self, mask=None) -> torch.Tensor:
         self.batch.reset(mask=mask)
