@@ -18,6 +18,11 @@ a = torch.zeros((n, 4), device=dev)
 ring = torch.zeros((64, n, 4), device=dev)
 ve = FpvVecEnv(load_params(fps=1000, ceiling=100.0), num_envs=n, device=dev)
 ve.reset()
+from fpyv_amd.pid import PID  # noqa: E402
+pid = PID(0.1, 2.0, 0.05, dt=1e-3, integral_clip=100.0, min_output=1.5, max_output=80.0, num_envs=n, device=dev)
+cur, tgt = torch.rand(n, device=dev), torch.rand(n, device=dev)
+Rg = torch.eye(3, device=dev).expand(n, 3, 3).contiguous()
+fg = torch.full((n,), 7.0, device=dev)
 L, h, ref, stream = e._L, e._handle, e._buf_ref, e._stream()
 e._step_raw(a)
 
@@ -38,6 +43,9 @@ for _ in range(2):
     t(lambda i: e.step(ring[i & 63], return_imu=False), "DroneBatch.step(ring[i], ...): a fresh view object per step")
     t(lambda i: e.step(a), "DroneBatch.step(same tensor): with the reference's return triple")
     t(lambda i: ve.step(a), "FpvVecEnv.step(same tensor) -> (obs, reward, done, info)")
+    t(lambda i: pid(cur, 1.5), "PID.__call__(current tensor, scalar target)")
+    t(lambda i: pid(cur, tgt), "PID.__call__(current tensor, target tensor)")
+    t(lambda i: e.step(a, rotation_matrix=Rg, thrust_force=fg, return_imu=False), "DroneBatch.step(..., rotation_matrix=[n,3,3], thrust_force=[n])")
     t(lambda i: e.rotation_matrix, "DroneBatch.rotation_matrix (no step)")
     t(lambda i: e.euler_angles, "DroneBatch.euler_angles (no step)")
     print()
