@@ -1843,3 +1843,26 @@ def test_two_ranks_rehearsed_on_one_gpu(params_1k, tmp_path, api):
                 assert np.array_equal(bits, gathered[rank, t - first]), f"rank {rank} step {t}"
         assert set_rows >= 3, "several of the flushed rows must carry set bits"
         assert np.array_equal(ref.state.cpu().numpy().view(np.uint32), np.load(tmp_path / f"state_rank{rank}.npy").view(np.uint32))
+
+
+def test_sharded_example_under_the_launcher_two_ranks_on_one_gpu():
+    """examples/sharded_vec_env.py - a population cut into contiguous shards, in-kernel sticks keyed by the global drone id,
+    the k-step kernel writing one mask row per step into DoneGather's bucket - under `python -m torch.distributed.run` with two
+    ranks on GPU 0 over gloo: the gathered masks agree with the ranks' own done flags and rank 0's shard equals its slice of
+    the unsharded run bit for bit (the script asserts both)."""
+    import os
+    import socket
+    import subprocess
+    import sys
+    from conftest import REPO
+    with socket.socket() as sk:
+        sk.bind(("127.0.0.1", 0))
+        port = sk.getsockname()[1]
+    env = {k: v for k, v in os.environ.items() if k not in ("RANK", "LOCAL_RANK", "WORLD_SIZE", "MASTER_ADDR", "MASTER_PORT", "LOCAL_WORLD_SIZE")}
+    r = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1",
+                        "--master-port", str(port), os.path.join(REPO, "examples", "sharded_vec_env.py"), "--drones", "65536", "--steps", "150",
+                        "--block", "64", "--backend", "gloo", "--all-ranks-on-gpu0", "--check"],
+                       capture_output=True, text=True, timeout=600, env=env)
+    assert r.returncode == 0, (r.stdout + r.stderr)[-3000:]
+    assert "2 ranks x 32768 drones, 150 steps" in r.stdout and "(must agree)" in r.stdout
+    assert "equals its slice of the unsharded run bit for bit" in r.stdout
