@@ -31,7 +31,7 @@ R_OMEGA, R_IERR, R_LERR, R_FIRST, R_OMEGA_LO, R_IERR_LO, R_DFILT = 10, 13, 16, 1
 
 # every symbol include/fpv_abi.h declares
 EXPORTS = ("fpv_abi_version", "fpv_sizeof", "fpv_state_rows", "fpv_algorithmic_bytes", "fpv_handle_algorithmic_bytes", "fpv_create", "fpv_destroy",
-           "fpv_reset", "fpv_step", "fpv_rollout", "fpv_step_n", "fpv_rollout_graph", "fpv_return_triple", "fpv_set_params", "fpv_set_step_counter", "fpv_get_step_counter", "fpv_recommended_ld",
+           "fpv_reset", "fpv_step", "fpv_rollout", "fpv_step_n", "fpv_rollout_graph", "fpv_return_triple", "fpv_widen_state", "fpv_set_params", "fpv_set_step_counter", "fpv_get_step_counter", "fpv_recommended_ld",
            "fpv_diag_stream_copy", "fpv_diag_stream_copy_wide", "fpv_pid_reset", "fpv_pid_call", "fpv_comm_unique_id", "fpv_comm_create", "fpv_comm_destroy", "fpv_comm_info",
            "fpv_allgather_done", "fpv_allgather_f32", "fpv_last_error",
            "fpv_error_name")
@@ -181,6 +181,7 @@ def lib() -> C.CDLL:
     L.fpv_rollout_graph.argtypes = [vp, pb, C.c_int, i64, i64, vp]
     L.fpv_step_n.argtypes = [vp, pb, C.c_int, i64, i64, vp]
     L.fpv_return_triple.argtypes = [vp, pb, vp, vp, vp, vp]
+    L.fpv_widen_state.argtypes = [vp, pb, vp, i64, vp]
     L.fpv_set_params.argtypes = [vp, pp]
     L.fpv_set_step_counter.argtypes = [vp, C.c_uint64]
     L.fpv_get_step_counter.argtypes = [vp, C.POINTER(C.c_uint64)]

@@ -884,6 +884,27 @@ __global__ __launch_bounds__(kBlock) void fpv_return_triple_kernel(const float* 
     }
 }
 
+// fp16 state storage -> the 14 fp32 rows of the state (fpv_abi.h row numbering) for whoever reads the state on the host
+// side of the boundary (an observation, a log): the position rows copied, every stored half WIDENED AS IT IS (no
+// renormalisation of the quaternion: this is what is stored).  One launch instead of a dozen tensor operations.
+__global__ __launch_bounds__(kBlock) void fpv_widen_state_kernel(const float* __restrict__ pos, const uint16_t* __restrict__ sh16,
+                                                                 const int64_t ld, float* __restrict__ out, const int64_t out_ld,
+                                                                 const int64_t n)
+{
+    const int64_t i = (int64_t)blockIdx.x * kBlock + threadIdx.x;
+    if (i >= n) return;
+    const uint32_t* __restrict__ sh = reinterpret_cast<const uint32_t*>(sh16);
+#pragma unroll
+    for (int k = 0; k < 3; ++k) out[(int64_t)k * out_ld + i] = pos[(int64_t)k * ld + i];
+#pragma unroll
+    for (int k = 0; k < FPV_HALF_PAIR_ROWS; ++k) {
+        const uint32_t w = sh[(int64_t)k * ld + i];
+        out[(int64_t)(3 + 2 * k) * out_ld + i] = fpv_f16_to_f32((uint16_t)w);
+        out[(int64_t)(4 + 2 * k) * out_ld + i] = fpv_f16_to_f32((uint16_t)(w >> 16));
+    }
+    out[(int64_t)FPV_THRUST * out_ld + i] = fpv_f16_to_f32(sh16[(int64_t)2 * FPV_HALF_PAIR_ROWS * ld + i]);
+}
+
 // components.PID.__call__ for n drones (components.py:43-54): one lane per drone, four state rows.
 __global__ __launch_bounds__(kBlock) void fpv_pid_kernel(const FpvPidK<float> P, float* __restrict__ st, const int64_t ld,
                                                          const int64_t n, const float* __restrict__ current,
@@ -1476,6 +1497,21 @@ int fpv_rollout_graph(fpv_handle_t h, const fpv_buffers_t* b, int k, int64_t act
     const hipError_t e = hipGraphLaunch(h->graph_exec, (hipStream_t)stream);
     if (e != hipSuccess) return hip_fail(e, "hipGraphLaunch");
     h->launches += (uint64_t)k;
+    return FPV_OK;
+}
+
+int fpv_widen_state(fpv_handle_t h, const fpv_buffers_t* b, float* out, int64_t out_ld, void* stream)
+{
+    if (!h || !b || !b->state || !out) return fail(FPV_EINVAL, "null argument");
+    if (h->mode != FPV_MODE_DRONE || !(h->K.flags & FPV_FLAG_FP16_STATE) || !b->state_h)
+        return fail(FPV_EINVAL, "fpv_widen_state is for FPV_FLAG_FP16_STATE handles (fp32 state is already fp32 rows)");
+    if (b->ld < h->n || out_ld < h->n) return fail(FPV_EALIGN, "ld / out_ld smaller than the number of drones");
+    const DeviceGuard dev(h->device);
+    if (dev.rc != FPV_OK) return dev.rc;
+    hipLaunchKernelGGL(fpv_widen_state_kernel, dim3((unsigned)((h->n + kBlock - 1) / kBlock)), dim3(kBlock), 0, (hipStream_t)stream,
+                       b->state, b->state_h, b->ld, out, out_ld, h->n);
+    const hipError_t e = hipGetLastError();
+    if (e != hipSuccess) return hip_fail(e, "widen kernel launch");
     return FPV_OK;
 }
 

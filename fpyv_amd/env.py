@@ -124,12 +124,12 @@ class _Batch:
         storage format; a zero-copy view for fp32 storage, a converted copy for fp16 rows."""
         if not self.fp16_state:
             return self.state[r0:r1, :self.n].t()
-        parts = []
-        if r0 < 3:
-            parts.append(self.state[r0:min(r1, 3), :self.n])
-        if r1 > 3:
-            parts.append(self.half_rows()[max(r0, 3) - 3:r1 - 3, :self.n].float())
-        return torch.cat(parts, dim=0).t()
+        if r1 <= 3:
+            return self.state[r0:r1, :self.n].t()
+        # one launch (fpv_widen_state) into a fresh [14, ld] tensor: a copy, like before, valid for as long as the caller keeps it
+        wide = torch.empty((_lib.FPV_DRONE_ROWS, self.ld), dtype=torch.float32, device=self.device)
+        _lib.check(self._L.fpv_widen_state(self._handle, self._buf_ref, wide.data_ptr(), self.ld, self._stream()))
+        return wide[r0:r1, :self.n].t()
 
     def half_rows(self) -> torch.Tensor:
         """[11, ld] binary16 values of the fp16 storage, row r-3 = state value r (vx .. thrust): a copy

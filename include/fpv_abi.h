@@ -252,6 +252,11 @@ int fpv_step_n(fpv_handle_t h, const fpv_buffers_t* b, int k, int64_t action_str
  * fp32 drone state only. */
 int fpv_return_triple(fpv_handle_t h, const fpv_buffers_t* b, float* rt, float* gyro, float* acc, void* stream);
 
+/* FPV_FLAG_FP16_STATE handles: the whole state as 14 fp32 rows out[14][out_ld] (same row numbering as the fp32 state) -
+ * position rows copied, every stored half widened as it is (no renormalisation: this is the stored state).  For a
+ * caller that reads the state each step (an observation); one launch. */
+int fpv_widen_state(fpv_handle_t h, const fpv_buffers_t* b, float* out, int64_t out_ld, void* stream);
+
 /* The 64-bit step index that keys the stick-noise stream (Philox4x32-10 counter = global drone id, step index; key =
  * noise_seed) and the stochastic rounding counts the steps a handle has launched, from 0: set it to resume / replay a
  * run, read it to checkpoint one.  2^64 steps do not wrap in practice (2^32 took 5.5 h at the k-step kernel's rate,

@@ -155,6 +155,27 @@ def test_return_triple_kernel_equals_host_build_and_torch_form(params_1k):
     assert out[2] is None and out[0].shape == (8, 3, 3)
 
 
+def test_fp16_state_widened_by_one_kernel_equals_the_tensor_form(params_1k):
+    """fpv_widen_state (what rows_f32 / position / velocity / quaternion / FpvVecEnv.obs read for fp16 storage): every
+    stored half widened as it is, position rows copied - bit for bit what half_rows() assembles with tensor operations,
+    at a ragged size, after a flight."""
+    from fpyv_amd.env import FpvVecEnv
+    n = 4099
+    env = _drone_batch(params_1k, n, fp16_state=True, with_accel=False)
+    env.reset()
+    a = torch.from_numpy(sticks.ema_noise(50, range(n), seed=4)).to(DEV)
+    env.rollout(a)
+    got = env.rows_f32(0, 14)                                   # [n, 14]
+    want = torch.cat([env.state[:3, :n], env.half_rows()[:, :n].float()], dim=0).t()
+    assert got.shape == (n, 14) and torch.equal(got, want)
+    assert torch.equal(env.quaternion, want[:, 6:10]) and torch.equal(env.position, want[:, 0:3]) and torch.equal(env.prev_thrust, want[:, 13])
+    ve = FpvVecEnv(params_1k, num_envs=64, device=DEV, fp16_state=True)
+    o0 = ve.reset()
+    o1, r, d, info = ve.step(a[0, :64].contiguous())
+    assert o1.shape == (64, 13) and o1.data_ptr() != o0.data_ptr() and bool(torch.isfinite(o1).all())
+    assert torch.equal(o1, torch.cat([ve.batch.state[:3, :64], ve.batch.half_rows()[:10, :64].float()], dim=0).t())
+
+
 def test_default_fps60(params_60):
     g = load_golden("g1b_fps60_sin")
     n = g["actions"].shape[1]
