@@ -78,3 +78,26 @@ def test_fp16_state_does_not_depend_on_the_shard_a_drone_is_in(seed, n, cut, ste
         lane_model.run_h(P, pos, sh, np.ascontiguousarray(acts[:, lo:hi]), seed0=rseed, step0=step0, drone_id_offset=lo)
         part = lane_model.join_half(pos, sh)
         assert np.array_equal(part[:, :m].view(np.uint32), whole[:, lo:hi].view(np.uint32)), (lo, hi)
+
+
+@settings(max_examples=60, deadline=None)
+@given(q=st.lists(st.floats(-1, 1, allow_nan=False), min_size=4, max_size=4), tiny=st.floats(0, 1e-7))
+def test_rotation_helpers_round_trip_for_any_attitude(q, tiny):
+    """fpyv_amd.env.matrix_to_quat / quat_to_matrix / matrix_to_euler_zyx / euler_zyx_matrix on arbitrary unit quaternions
+    (half turns included - w within `tiny` of zero - where the reference's own matrix -> quaternion formula divides by ~0):
+    the matrix survives both round trips to 1e-12, the quaternion comes back with w >= 0 and unit norm."""
+    import torch
+    from fpyv_amd.env import euler_zyx_matrix, matrix_to_euler_zyx, matrix_to_quat, quat_to_matrix
+    v = np.array(q, dtype=np.float64)
+    if np.linalg.norm(v[1:]) < 1e-3:
+        v[1] = 1.0
+    v[0] *= tiny if tiny > 0 and abs(v[0]) < 0.5 else 1.0          # sometimes: an (almost) exact half turn
+    v /= np.linalg.norm(v)
+    R = quat_to_matrix(torch.from_numpy(v)[None])
+    assert float((R @ R.transpose(-1, -2) - torch.eye(3, dtype=torch.float64)).abs().max()) < 1e-14
+    back = matrix_to_quat(R)
+    assert float(back[0, 0]) >= 0 and abs(float(back.norm()) - 1) < 1e-14
+    assert float((quat_to_matrix(back) - R).abs().max()) < 1e-12
+    e = matrix_to_euler_zyx(R)
+    if abs(float(R[0, 2, 0])) < 1 - 1e-9:                          # away from gimbal lock the Euler round trip is exact too
+        assert float((euler_zyx_matrix(e) - R).abs().max()) < 1e-9
