@@ -200,14 +200,15 @@ struct RollOut {
     // launch that neither stores reward/done per step nor tracks episodes, and is not the last one: only the
     // optional per-step done_bits row is left of it
     // `live` = false: a lane that runs the step but owns no drone (fpv_drone_rollout_h_kernel's shadow lanes) - it
-    // stores nothing and does not vote; the per-step pointers stay wave-uniform because every lane advances them
+    // stores nothing (the mask word included: a wave is live exactly when its lane 0 is) and does not vote; the
+    // per-step pointers stay wave-uniform because every lane advances them
     template <bool QUIET = false>
     __device__ __forceinline__ void step(uint32_t i, int t, float reward, bool done, bool live = true)
     {
         const bool last = !QUIET && t == last_t;
         if (bp && (bits_stride || last)) {
             const unsigned long long mask = __ballot(live && done);
-            if ((threadIdx.x & 63) == 0) bp[i >> 6] = mask;
+            if ((threadIdx.x & 63) == 0 && live) bp[i >> 6] = mask;      // a wave whose lane 0 owns no drone is wholly dead: no word is its own
         }
         if (!QUIET) {
             if ((out_stride || last) && live) {
@@ -262,7 +263,8 @@ __device__ __forceinline__ float4 apply_stick_noise(const FpvK& K, const FpvBufD
 #endif
 // The single-step kernels take what their FIRST instructions need - the state and action bases, the row stride, n - as
 // plain leading scalars, ahead of the two argument structs.  The library is built with
-// -mllvm -amdgpu-kernarg-preload-count=12: on gfx950 the command processor then places this 12-dword prefix of the
+// -mllvm -amdgpu-kernarg-preload-count=6 (six leading 8-byte arguments = 12 dwords): on gfx950 the command processor then
+// places this 12-dword prefix of the
 // kernel-argument segment in SGPRs at wave launch, so a wave issues its 15 vector loads at once instead of first
 // waiting for a scalar load of those pointers - a cold one at every kernel start, because the scalar cache and L2
 // are invalidated at the kernel boundary.  It is the head of the per-launch floor of a chain of dependent step
@@ -667,7 +669,9 @@ __global__ __launch_bounds__(kStepBlock) void fpv_drone_rollout_h_kernel(const F
             const FpvStepOut o = one_step(A, ap, true, true, t, std::true_type{});
             if (bp) {
                 const unsigned long long mask = __ballot(live && o.done);
-                if ((threadIdx.x & 63) == 0) bp[i0 >> 6] = mask;          // lane 0 of a launched wave is always live
+                // with 128-thread workgroups the LAST wave of the grid can be wholly dead (n % 128 in 1..64): its lane 0
+                // owns no drone and no mask word - the word at i0 >> 6 would be the next row's first word
+                if ((threadIdx.x & 63) == 0 && live) bp[i0 >> 6] = mask;
                 bp += bstride;
             }
         }

@@ -156,7 +156,8 @@ class _Batch:
             return None
         # hottest path: the very tensor object of the previous step (a policy that writes its output in place), still at
         # the same address: everything below was checked then
-        if action is self._last_action and action.data_ptr() == self._last_action_ptr:
+        if action is self._last_action and action.data_ptr() == self._last_action_ptr and action.shape == self._ashape:
+            self._keepalive = action                 # a rollout in between may have replaced what `throttle` reports
             return self._last_action_ptr
         self._last_action = None
         # hot path: a contiguous float32 [num_envs, 4] tensor on the env's device
@@ -381,6 +382,7 @@ class _Batch:
             _lib.check(fn(self._handle, C.byref(b), int(k), stride, out_stride, self._stream()))
             self._steps_launched = (self._steps_launched + int(k)) & 0xFFFFFFFFFFFFFFFF
             self._keepalive = actions               # what `throttle` reports: the last step's sticks
+            self._last_action = None                # the next step() re-validates its tensor (b.action / action_ld were rewritten here)
         finally:
             b.reward, b.done = saved
 

@@ -1345,6 +1345,61 @@ def test_step_n_other_modes_bitwise(params_1k, kind):
                 assert bool((a.last_length > 0).any()), "the ceiling must end some episodes"
 
 
+@pytest.mark.parametrize("kind", ["f32", "fp16", "racer", "racer_written"])
+def test_step_n_strided_done_rows_stay_inside_their_row(params_1k, kind):
+    """Per-step done-mask rows (done_bits_stride > 0) of the k-step kernels for every state family, at populations whose
+    LAST wave of the grid is wholly dead (n % 128 in 1..64: a 128-thread workgroup launches a second wave that owns no
+    drone).  The bucket is [k, words + 1] with stride words + 1 and a sentinel in the extra column: a wave that stores a
+    mask word it does not own writes exactly there (or, with stride = words, into the next step's row).  Rows must
+    equal those of k single-step launches, sentinels untouched - with and without reward/done leaving per step (the
+    quiet loop and the RollOut::step path store the mask in different places)."""
+    from fpyv_amd.env import DroneBatch, RacerBatch
+    rng = np.random.default_rng(11)
+    SENT = -0x0123456789ABCDF
+    for n, k in ((1, 9), (64, 8), (4096 + 3, 21), (128 * 7 + 33, 12)):
+        assert 1 <= n % 128 <= 64
+        if kind in ("f32", "fp16"):
+            p = params_1k.replace(ceiling=10.0005)         # 0.5 mm above the start height: the ceiling ends episodes within the k steps
+            mk = lambda: DroneBatch(p, n, device=DEV, fp16_state=(kind == "fp16"), rounding_seed=5, auto_reset=True, with_accel=False)   # noqa: E731
+            acts = torch.from_numpy(sticks.ema_noise(k, range(n), seed=3)).to(DEV)
+            acts[..., 3] = torch.from_numpy(rng.uniform(0.2, 1, (k, n)).astype(np.float32)).to(DEV)
+        else:
+            pid = np.array([[0.004, 0.02, 1e-6], [0.003, 0.01, 2e-6], [0.002, 0.005, 0]])
+            p = params_1k.replace(mode=1, racer_pid=pid, racer_omega_dt=(kind == "racer"), ceiling=2e-5)
+            mk = lambda: RacerBatch(p, n, device=DEV, auto_reset=True)   # noqa: E731
+            acts = torch.from_numpy(np.concatenate([rng.uniform(-6, 6, (k, n, 3)), rng.uniform(0, 8, (k, n, 1))], axis=2).astype(np.float32)).to(DEV)
+        words = (n + 63) // 64
+        for per_step_out in (False, True):
+            a, b = mk(), mk()
+            a.reset(); b.reset()
+            ba = torch.full((k, words + 1), SENT, dtype=torch.int64, device=DEV)
+            bb = torch.full((k, words + 1), SENT, dtype=torch.int64, device=DEV)
+            a.set_done_bits_target(ba, stride_words=words + 1)
+            b.set_done_bits_target(bb, stride_words=words + 1)
+            out_a = dict(dones=torch.zeros((k, n), dtype=torch.uint8, device=DEV)) if per_step_out else {}
+            out_b = dict(dones=torch.zeros((k, n), dtype=torch.uint8, device=DEV)) if per_step_out else {}
+            a.rollout(acts, fused=False, **out_a)
+            b.rollout(acts, fused=True, **out_b)
+            torch.cuda.synchronize()
+            tag = (kind, n, k, per_step_out)
+            assert bool((bb[:, words] == SENT).all()) and bool((ba[:, words] == SENT).all()), f"{tag}: a dead wave stored a mask word"
+            assert torch.equal(ba, bb), tag
+            assert torch.equal(a.state, b.state), tag
+            assert n < 64 or int((bb[:, :words] != 0).sum()) > 0, f"{tag}: the ceiling must set some bits"
+            if per_step_out:
+                unpacked = ((bb[:, :words].cpu().numpy().view(np.uint64)[:, :, None] >> np.arange(64, dtype=np.uint64)) & np.uint64(1))
+                assert np.array_equal(unpacked.reshape(k, -1)[:, :n].astype(np.uint8), out_b["dones"].cpu().numpy()), tag
+        # the tight bucket of the collective path (stride == words): the stray word of the old code was row t + 1, word 0
+        a, b = mk(), mk()
+        a.reset(); b.reset()
+        ba, bb = (torch.zeros((k + 1, words), dtype=torch.int64, device=DEV) for _ in range(2))
+        ba[k], bb[k] = SENT, SENT
+        a.set_done_bits_target(ba, stride_words=words); b.set_done_bits_target(bb, stride_words=words)
+        a.rollout(acts, fused=False); b.rollout(acts, fused=True)
+        torch.cuda.synchronize()
+        assert torch.equal(ba, bb) and bool((bb[k] == SENT).all()), (kind, n, k, "tight")
+
+
 def test_config2_full_size_1000_steps_fused_noise_vs_oracle(params_1k):
     """BASELINE configs[2] at its full size and length: 2^20 drones x 1000 steps of in-kernel EMA-noise
     sticks.  The applied sticks of 4096 sampled drones (block / wave edges + random) are captured from
@@ -1725,6 +1780,15 @@ def test_reference_scalar_attributes_of_drone(params_1k):
     acts = torch.rand((5, 7, 4), device=DEV) * 2 - 1
     env.rollout(acts)
     assert torch.equal(env.throttle, acts[-1, :, 3])
+    # step(A); rollout(...); step(A) with the SAME tensor object: the in-place-policy fast path of _action_ptr must report A
+    # again (it used to leave `throttle` on the rollout's batch), and a tensor re-shaped in place is validated again
+    env.step(a, return_imu=False)
+    env.rollout(acts)
+    env.step(a, return_imu=False)
+    assert torch.equal(env.throttle, a[:, 3])
+    a.resize_(8, 4)
+    with pytest.raises(ValueError):
+        env.step(a, return_imu=False)
 
 
 def test_force_multiplier_pid_built_and_reset_like_the_reference(params_1k):
