@@ -157,8 +157,9 @@ def cpu_baseline(params, seconds_budget=12.0):
 
 
 def spawn_ranks(n_ranks, argv, port=None, python=sys.executable, wall_limit_s=1500.0):
-    """`bench.py --gpus N` outside torchrun: start N fresh child processes (one rank per GPU) BEFORE this
-    process touches the GPU, forward rank 0's stdout (the one JSON line), return the first non-zero exit code.
+    """`bench.py --gpus N` outside torchrun: be the launcher - start N fresh child processes (one per rank, each of
+    which becomes that rank's GPU-free supervisor, see supervise_rank) BEFORE this process touches the GPU, forward
+    rank 0's stdout (the one JSON line), return the first non-zero exit code.
     Never re-execs: the parent only watches.  ALL children are polled together: the first rank that exits non-zero
     (no GPU, an import error, the non-finite-state assert) ends the job at once - its siblings would otherwise sit in
     the rendezvous, an all-gather or a barrier until the backend's own 10-30 min timeout - and `wall_limit_s` bounds
@@ -171,7 +172,8 @@ def spawn_ranks(n_ranks, argv, port=None, python=sys.executable, wall_limit_s=15
     procs = []
     for r in range(n_ranks):
         env = dict(os.environ, RANK=str(r), LOCAL_RANK=str(r), WORLD_SIZE=str(n_ranks), LOCAL_WORLD_SIZE=str(n_ranks),
-                   MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), HSA_ENABLE_IPC_MODE_LEGACY="0")
+                   MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+        env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")      # a caller's value wins (it is recorded in collective.ipc_mode)
         procs.append(subprocess.Popen([python, os.path.abspath(__file__)] + list(argv), env=env,
                                       stdout=(None if r == 0 else subprocess.DEVNULL)))
 
@@ -208,6 +210,86 @@ def spawn_ranks(n_ranks, argv, port=None, python=sys.executable, wall_limit_s=15
     return 0
 
 
+def supervise_rank(args, raw_argv):
+    """One rank of an N-rank job as the launcher started it - by torchrun (the driver's way) or by spawn_ranks.  This
+    process stays GPU-FREE: it agrees with its peers over gloo on CPU tensors (fpyv_amd.dist.RankSupervisor) and runs
+    everything that touches the GPU in fresh child processes it can stop by their PID, so the job cannot come back
+    empty-handed because RCCL would not start on this node:
+      1. RCCL preflight in fresh children (init + one all-gather of the rank ids, wall limit) with the caller's
+         HSA_ENABLE_IPC_MODE_LEGACY; when that fails, once more with the other value;
+      2. the worker (`--worker --collective rccl`) per rank; if the preflight failed, or the workers fail or hang, fresh
+         workers once more with the done mask over gloo (host-staged), and as the last resort with no exchange;
+      3. rank 0 prints the accepted worker's JSON line, with what happened in collective.{requested, backend, ipc_mode,
+         fallback_reason, preflight, attempts}.  Non-zero exit only when every attempt failed.
+    Loop being sharded: /root/reference/src/core/simulator.py:83-156."""
+    from fpyv_amd import dist as fd
+    watch_parent()
+    with stdout_to_stderr():                     # gloo announces itself on stdout
+        sup = fd.RankSupervisor()
+    rank = sup.rank
+    ipc_caller = os.environ.get(fd.IPC_ENV)
+    ipc_mode = ipc_caller
+    stub_pf = args.stub_preflight if args.stub_step else None
+    preflights, attempts, final = [], [], None
+    if args.rehearse_on_one_gpu:
+        plan = ["gloo"]                          # RCCL refuses two ranks on one device
+    elif args.collective != "auto":
+        plan = [args.collective]
+    else:
+        plan = ["rccl", "gloo", "none"]
+        if not args.no_preflight:
+            res = sup.preflight(ipc_caller, args.preflight_timeout_s, stub_pf)
+            preflights.append(res)
+            if not res["ok"]:
+                alt = fd.other_ipc_mode(ipc_caller)
+                if rank == 0:
+                    print(f"bench.py: RCCL preflight failed with {fd.IPC_ENV}={ipc_caller!r} ({'; '.join(res['reasons'])[:300]}); trying {alt!r}", file=sys.stderr)
+                res = sup.preflight(alt, args.preflight_timeout_s, stub_pf)
+                preflights.append(res)
+                if res["ok"]:
+                    ipc_mode = alt
+                else:
+                    plan = ["gloo", "none"]
+    requested = "rccl" if args.collective == "auto" else args.collective
+    for mode in plan:
+        port = sup.pick_port()
+        cmd = [sys.executable, os.path.abspath(__file__)] + list(raw_argv) + ["--worker", "--collective", mode]
+        r = fd.run_child(cmd, sup.child_env(port, ipc_mode), args.attempt_timeout_s, capture_stdout=(rank == 0), on_start=sup.track)
+        line, ok_local = None, r["rc"] == 0
+        if rank == 0 and ok_local:
+            cand = [ln for ln in r["stdout"].splitlines() if ln.lstrip().startswith("{")]
+            try:
+                line = json.loads(cand[-1])
+            except (IndexError, ValueError):
+                ok_local = False
+        why = None if ok_local else (f"no result within {args.attempt_timeout_s:.0f} s" if r["timed_out"] else f"exit code {r['rc']}: {r['stderr_tail']}")
+        ok = sup.all_ok(ok_local)
+        reasons = sup.gather_reasons(why)
+        attempts.append({"collective": mode, "ipc_mode": ipc_mode, "ok": ok, "seconds": round(r["seconds"], 2), "reasons": reasons})
+        if ok:
+            final = line
+            break
+        if rank == 0:
+            print(f"bench.py: the run with --collective {mode} failed ({'; '.join(reasons)[:400]})"
+                  + ("; starting fresh workers with the next fallback" if mode != plan[-1] else "; no fallback left"), file=sys.stderr)
+    done = bool(attempts) and attempts[-1]["ok"]
+    if rank == 0 and done:
+        c = final.setdefault("collective", {})
+        used = attempts[-1]["collective"]
+        why = None
+        if used != requested:
+            failed_pf = [x for x in preflights if not x["ok"]]
+            failed_at = [x for x in attempts if not x["ok"]]
+            why = ("RCCL preflight failed: " + "; ".join(failed_pf[0]["reasons"]) if failed_pf and not any(x["collective"] == "rccl" for x in attempts)
+                   else "run failed: " + "; ".join(failed_at[0]["reasons"]) if failed_at else "unknown")[:600]
+        c.update(requested=requested, used=used, ipc_mode=ipc_mode, ipc_mode_of_caller=ipc_caller,
+                 ipc_mode_source=os.environ.get("FPV_BENCH_IPC_MODE_SOURCE"), fallback_reason=why,
+                 preflight=preflights, attempts=attempts)
+        print(json.dumps(final), flush=True)
+    sup.close()
+    return 0 if done else 1
+
+
 class stdout_to_stderr:
     """The driver reads exactly ONE JSON line on stdout; RCCL and gloo print banners there when the first
     communicator comes up, so fd 1 points at stderr while that happens."""
@@ -221,6 +303,19 @@ class stdout_to_stderr:
         sys.stdout.flush()
         os.dup2(self.saved, 1)
         os.close(self.saved)
+
+
+def watch_parent():
+    """A worker whose supervisor is gone (killed by the launcher's own limit) must not live on as an orphan holding a
+    GPU: a daemon thread leaves as soon as the parent PID changes."""
+    import threading
+    ppid = os.getppid()
+
+    def loop():
+        while os.getppid() == ppid:
+            time.sleep(0.5)
+        os._exit(3)
+    threading.Thread(target=loop, daemon=True).start()
 
 
 def parse_args(argv=None):
@@ -267,6 +362,26 @@ def parse_args(argv=None):
                          "own final state to this directory (the test compares them with a single-process run)")
     ap.add_argument("--spawn-timeout-s", type=float, default=1500.0,
                     help="self-launched ranks (--gpus N outside a launcher): wall-clock limit of the whole job")
+    ap.add_argument("--collective", choices=["auto", "rccl", "gloo", "none"], default="auto",
+                    help="N > 1: what carries the done mask and the job's barriers.  auto (default): RCCL if a preflight in fresh "
+                         "child processes brings it up (with the caller's HSA_ENABLE_IPC_MODE_LEGACY, then once with the other value), "
+                         "else gloo (host-staged), else no exchange at all - the line says which (collective.backend, "
+                         "collective.fallback_reason).  An explicit value is used as given, without preflight or fallback")
+    ap.add_argument("--worker", action="store_true",
+                    help="INTERNAL: this process is the GPU-touching worker of one rank, started by its supervisor (supervise_rank)")
+    ap.add_argument("--no-preflight", action="store_true", help="N > 1, --collective auto: skip the RCCL preflight (fallbacks stay)")
+    ap.add_argument("--preflight-timeout-s", type=float, default=90.0,
+                    help="wall limit of one RCCL preflight (init + one all-gather in fresh children; torch is already in the page "
+                         "cache by then, so this is GPU + RCCL bring-up time only)")
+    ap.add_argument("--attempt-timeout-s", type=float, default=600.0, help="wall limit of one attempt of the N-rank run")
+    ap.add_argument("--pg-timeout-s", type=float, default=180.0, help="process-group timeout inside a worker: a rank whose peer died leaves its collective after this long")
+    ap.add_argument("--sustained-steps", type=int, default=2000,
+                    help="N = 1, --api step: after the contract's K timed steps, this many more launches at the headline size, HIP-event "
+                         "timed (roofline.sustained): the steady state next to the driver's short shape; 0 = skip")
+    ap.add_argument("--stub-preflight", choices=["ok", "fail", "hang"], default="ok",
+                    help="TEST ONLY (with --stub-step): what the preflight children do")
+    ap.add_argument("--stub-fail-collective", choices=["", "rccl", "gloo", "all"], default="",
+                    help="TEST ONLY (with --stub-step): workers started with this --collective (or all) exit 1 after the rendezvous")
     ap.add_argument("--stub-fail-rank", type=int, default=-1,
                     help="TEST ONLY (tests/test_bench_spawn.py): this rank exits 1 before it joins the process group")
     ap.add_argument("--stub-step", action="store_true",
@@ -275,12 +390,14 @@ def parse_args(argv=None):
     return ap.parse_args(argv)
 
 
-def collective_report(dist, world_env, rank, dev, gather, local_ms_per_step):
+def collective_report(dist, world_env, rank, dev, gather, local_ms_per_step, collective=None, physics_ms=None):
     """What lets a reader of the N-rank line verify that the collective really spanned N ranks without trusting the
     headline number: the world size the process group reports once it is up, the backend and its library version, an
     all-gather of every rank's id (must come back as 0..N-1, in order) and of every rank's own ms per step."""
     import torch
-    out = {"backend": None, "world_env": world_env, "world_seen": 1, "rank_ids_gathered": [0], "library_version": None}
+    out = {"backend": None, "world_env": world_env, "world_seen": 1, "rank_ids_gathered": [0], "library_version": None,
+           "ipc_mode": os.environ.get("HSA_ENABLE_IPC_MODE_LEGACY"),
+           "done_mask_exchange": None if gather is None else {"rccl": "RCCL all-gather over xGMI", "gloo": "gloo all-gather, host-staged (fallback)"}.get(collective, collective)}
     if dist is None or not dist.is_initialized():
         return out
     world = dist.get_world_size()
@@ -294,6 +411,13 @@ def collective_report(dist, world_env, rank, dev, gather, local_ms_per_step):
     out["rank_ids_gathered"] = [int(x) for x in got.cpu()]
     per = [float(x) for x in all_ms.cpu()]
     out["per_rank_ms_per_step"] = {"min": min(per), "max": max(per), "all": per}
+    if physics_ms is not None:
+        # the same kernels with the mask exchange switched off, HIP-event timed on each rank's own launch stream after
+        # the timed region: what the physics alone costs per step on every GPU of the job, whatever carried the masks
+        ms = torch.tensor([physics_ms], dtype=torch.float64, device=dev)
+        dist.all_gather_into_tensor(all_ms, ms)
+        per = [float(x) for x in all_ms.cpu()]
+        out["per_rank_physics_only_ms_per_step"] = {"min": min(per), "max": max(per), "all": per}
     if out["backend"] == "nccl":
         try:
             out["library_version"] = "RCCL/NCCL " + ".".join(str(v) for v in torch.cuda.nccl.version())
@@ -309,17 +433,23 @@ def collective_report(dist, world_env, rank, dev, gather, local_ms_per_step):
     return out
 
 
-def run_stub(args, world, rank):
-    """The N-rank plumbing on CPU tensors over gloo with a no-op step (see --stub-step)."""
+def run_stub(args, world, rank, collective="rccl"):
+    """The N-rank plumbing on CPU tensors over gloo with a no-op step (see --stub-step).  `collective` is what the
+    supervisor asked for ("rccl" is played by gloo here: there is no GPU); --stub-fail-collective makes the workers of
+    one kind fail after the rendezvous, the way a collective that does not come up would."""
     import torch
     import torch.distributed as dist
-    from fpyv_amd.dist import DoneGather
+    from fpyv_amd.dist import DoneGather, gloo_env_fixups
     if world > 1:
+        gloo_env_fixups()
         with stdout_to_stderr():                 # gloo, like RCCL, announces itself on stdout
             dist.init_process_group(backend="gloo")
             dist.barrier()
+        if args.stub_fail_collective in (collective, "all"):
+            print(f"stub: the {collective} collective of rank {rank} fails", file=sys.stderr)
+            raise SystemExit(1)
     words = (args.drones_per_gpu + 63) // 64
-    gather = DoneGather((words,), torch.int64, "cpu", block=args.gather_block) if world > 1 else None
+    gather = DoneGather((words,), torch.int64, "cpu", block=args.gather_block) if world > 1 and collective != "none" and not args.no_gather else None
     if world > 1:
         dist.barrier()
     t0 = time.perf_counter()
@@ -337,11 +467,13 @@ def run_stub(args, world, rank):
         tt = torch.tensor([elapsed], dtype=torch.float64)
         dist.all_reduce(tt, op=dist.ReduceOp.MAX)
         elapsed = float(tt.item())
-        last = gather.result((args.steps - 1) // args.gather_block)            # a flushed bucket holds only its filled rows
-        ok = all(int(last[r, (args.steps - 1) % args.gather_block, 0]) == r * 1000 + args.steps - 1 for r in range(world))
+        ok = True
+        if gather is not None:
+            last = gather.result((args.steps - 1) // args.gather_block)        # a flushed bucket holds only its filled rows
+            ok = all(int(last[r, (args.steps - 1) % args.gather_block, 0]) == r * 1000 + args.steps - 1 for r in range(world))
     else:
         ok = True
-    coll = collective_report(dist if world > 1 else None, world, rank, "cpu", gather, local * 1e3 / max(args.steps, 1))
+    coll = collective_report(dist if world > 1 else None, world, rank, "cpu", gather, local * 1e3 / max(args.steps, 1), collective=collective)
     if rank == 0:
         print(json.dumps({"metric": "stub", "value": 0.0, "unit": "env-steps/s", "n_gpus": world, "steps": args.steps,
                           "warmup": args.warmup, "data": "stub", "gather_ok": bool(ok), "ms_per_step": elapsed * 1e3 / max(args.steps, 1),
@@ -356,8 +488,10 @@ def run_stub(args, world, rank):
 def main(argv=None):
     # multi-process GPU work on this pool needs dmabuf IPC (the host driver has no legacy IPC): without it RCCL fails
     # with "hipIpcGetMemHandle: invalid argument".  Set before anything loads the HIP runtime.
-    os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    os.environ.setdefault("FPV_BENCH_IPC_MODE_SOURCE", "caller's environment" if "HSA_ENABLE_IPC_MODE_LEGACY" in os.environ else "bench.py default")
+    os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")       # setdefault: a caller's value wins and is recorded (collective.ipc_mode)
     args = parse_args(argv)
+    raw_argv = sys.argv[1:] if argv is None else list(argv)
     in_rank = "WORLD_SIZE" in os.environ and "RANK" in os.environ
     if args.gpus > 1 and not in_rank:
         # self-launch: nothing in this process has touched the GPU yet (device_count() does not initialise it)
@@ -367,7 +501,7 @@ def main(argv=None):
             if have < args.gpus:
                 raise SystemExit(f"bench.py --gpus {args.gpus} needs {args.gpus} GPUs on this node, found {have}; "
                                  f"run with --gpus {max(have, 1)} (or --force-dist to rehearse the collective path on one GPU)")
-        raise SystemExit(spawn_ranks(args.gpus, sys.argv[1:] if argv is None else argv, wall_limit_s=args.spawn_timeout_s))
+        raise SystemExit(spawn_ranks(args.gpus, raw_argv, wall_limit_s=args.spawn_timeout_s))
 
     if args.gather_block <= 0:
         args.gather_block = 64 if args.steps + args.warmup >= 256 else 16
@@ -378,8 +512,13 @@ def main(argv=None):
         raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}")
     if rank == args.stub_fail_rank:
         raise SystemExit(1)                                  # TEST ONLY: a rank that dies before the rendezvous
+    if world > 1 and not args.worker:
+        raise SystemExit(supervise_rank(args, raw_argv))     # this process stays GPU-free; the worker is a fresh child
+    if args.worker:
+        watch_parent()
+    collective = "gloo" if args.rehearse_on_one_gpu else ("rccl" if args.collective == "auto" else args.collective)
     if args.stub_step:
-        raise SystemExit(run_stub(args, world, rank))
+        raise SystemExit(run_stub(args, world, rank, collective))
 
     import torch
     import torch.distributed as dist
@@ -404,11 +543,15 @@ def main(argv=None):
     if multi:
         if "MASTER_ADDR" not in os.environ:
             os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT="29517", RANK="0", WORLD_SIZE="1")
+        import datetime
+        from fpyv_amd.dist import gloo_env_fixups
+        pg_timeout = datetime.timedelta(seconds=args.pg_timeout_s)
         with stdout_to_stderr():
-            if args.rehearse_on_one_gpu:
-                dist.init_process_group(backend="gloo")
-            else:
-                dist.init_process_group(backend="nccl", device_id=dev)
+            if collective == "rccl":
+                dist.init_process_group(backend="nccl", device_id=dev, timeout=pg_timeout)
+            else:                                    # "gloo": the masks travel host-staged; "none": barriers and the MAX only
+                gloo_env_fixups()
+                dist.init_process_group(backend="gloo", timeout=pg_timeout)
             warm = torch.zeros(1, device=dev)
             dist.all_reduce(warm)
             torch.cuda.synchronize()
@@ -438,7 +581,7 @@ def main(argv=None):
 
     gather = None
     words = (n + 63) // 64
-    if multi and not args.no_gather:
+    if multi and not args.no_gather and collective != "none":
         gather = DoneGather((words,), torch.int64, dev, block=args.gather_block)
         gather.warm_up()                    # RCCL's first-use costs stay out of a short timed region
     returns_all, returns_work = None, None
@@ -525,7 +668,6 @@ def main(argv=None):
         t = torch.tensor([elapsed], dtype=torch.float64, device=dev)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = float(t.item())
-        coll = collective_report(dist, world, rank, dev, gather, local_elapsed * 1e3 / args.steps)
 
     assert bool(torch.isfinite(env.state).all()), "non-finite state after the benchmark"
     if args.dump_gathered and gather is not None:
@@ -535,6 +677,40 @@ def main(argv=None):
         if rank == 0:        # [world, rows, words] masks of the bucket that holds the last step
             np.save(os.path.join(args.dump_gathered, "gathered_last_bucket.npy"), gather.result(last_t // args.gather_block).cpu().numpy())
         np.save(os.path.join(args.dump_gathered, f"state_rank{rank}.npy"), env.state.cpu().numpy())
+
+    def timed_leg(e, acts, k, t_base):
+        """k more steps of the same kind on the launch stream, HIP-event timed, no exchange: (us per launch, launches)."""
+        a0, a1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        before = launches[0]
+        a0.record()
+        run_on(e, acts, k, t_base, None)
+        a1.record()
+        torch.cuda.synchronize()
+        nl = launches[0] - before
+        launches[0] = before
+        return a0.elapsed_time(a1) * 1e3 / max(nl, 1), nl
+
+    physics_ms = None
+    if multi:
+        # the physics alone, per rank, after the timed region: the mask goes back to the batch's own word row (a k-step
+        # launch must not keep writing rows of a bucket that is no longer being gathered)
+        env.set_done_bits_target(None)
+        k2 = max(args.gather_block, min(400, max(args.steps, 64)))
+        us, nl = timed_leg(env, actions, k2, args.warmup + args.steps)
+        physics_ms = us * 1e-3 * nl / k2
+        coll = collective_report(dist, world, rank, dev, gather, local_elapsed * 1e3 / args.steps, collective=collective, physics_ms=physics_ms)
+
+    # the steady state beside the driver's short shape (20 timed launches are 0.5 ms: the clock also holds the first
+    # launch's latency and the closing synchronise): the same env, the same ring, HIP events around `--sustained-steps`
+    # further launches at the headline population
+    sustained = None
+    if rank == 0 and world == 1 and not multi and args.api == "step" and args.sustained_steps > 0:
+        us, nl = timed_leg(env, actions, args.sustained_steps, args.warmup + args.steps)
+        gbs = env.algorithmic_bytes() * n / (us * 1e-6) / 1e9
+        sustained = {"launches": nl, "avg_launch_us": us, "achieved": gbs, "unit": "GB/s", "frac": gbs / HBM_PEAK_GBS,
+                     "env_steps_per_s": n / (us * 1e-6),
+                     "what": f"{nl} consecutive env.step() launches at {n} drones after the timed region, HIP events on the launch stream"}
+        assert bool(torch.isfinite(env.state).all()), "non-finite state after the sustained leg"
 
     # the same kernel with its state far outside the 256 MiB Infinity Cache (2^23 drones: 470 MB of state):
     # what a GPU-filling population sees; the 2^20-drone state (59 MB) lives in that cache between steps
@@ -657,13 +833,17 @@ def main(argv=None):
                          "cache_note": "at 2^20 drones the 59 MB state is re-read from the 256 MiB Infinity Cache (MALL) every step; "
                                        "only the action stream and reward/done cross HBM - `beyond_mall` is the same kernel at 2^23 drones",
                          "frac_beyond_mall": beyond["frac"] if beyond else None, "beyond_mall": beyond,
+                         "sustained": sustained,
                          "launch_time_fit": None,
                          "note": "avg = HIP-event time over the timed region / launches (includes inter-launch gaps)"},
         }
         if fit is not None:
-            # least squares through (bytes, us) at 2^19, 2^20 (the headline run itself) and 2^21 drones
+            # least squares through (bytes, us) at 2^19, 2^20 and 2^21 drones; the 2^20 point is the sustained leg of this
+            # very env (thousands of launches, like the 400-launch legs of the two other sizes) when there is one, else
+            # the timed region itself
             import numpy as np
-            pts = [fit["points_bytes_us"][0], (state_bytes * n, kernel_s * 1e6), fit["points_bytes_us"][1]]
+            head_us = sustained["avg_launch_us"] if sustained else kernel_s * 1e6
+            pts = [fit["points_bytes_us"][0], (state_bytes * n, head_us), fit["points_bytes_us"][1]]
             A = np.array([[1.0, b_ / 1e6] for b_, _ in pts])
             y = np.array([t_ for _, t_ in pts])
             (t0, slope), *_ = np.linalg.lstsq(A, y, rcond=None)
@@ -671,7 +851,8 @@ def main(argv=None):
                 "model": "avg_launch_us(n) = floor_us + algorithmic bytes / streaming rate, n = 2^19, 2^20, 2^21 drones (all inside the Infinity Cache)",
                 "drones": [n // 2, n, 2 * n], "avg_launch_us": [float(t_) for _, t_ in pts],
                 "floor_us": float(t0), "streaming_GBs": float(1.0 / slope * 1e3), "streaming_frac_of_peak": float(1.0 / slope * 1e3 / HBM_PEAK_GBS),
-                "floor_share_of_headline_launch": float(t0 / (kernel_s * 1e6)),
+                "headline_point": "roofline.sustained" if sustained else "the timed region",
+                "floor_share_of_headline_launch": float(t0 / head_us),
                 "max_residual_us": float(np.abs(A @ np.array([t0, slope]) - y).max())}
         if coll is not None:
             out["collective"] = coll
@@ -704,12 +885,17 @@ def main(argv=None):
                             "achieved_Glane_inst_per_s": rate, "peak_Glane_inst_per_s": VALU_PEAK_GINST, "frac": rate / VALU_PEAK_GINST}
             out["roofline"]["valu"] = valu
             out["roofline"]["valu_unavailable"] = why
-            out["roofline"]["bound"] = "valu"
             if valu is not None:
-                out["roofline"].update(achieved=valu["achieved_Glane_inst_per_s"], peak=VALU_PEAK_GINST, unit="G lane-instructions/s",
-                                       frac=valu["frac"])
-            out["roofline"]["note"] = ("bound = vector-ALU issue (256 CUs x 4 SIMD-32 x 2.4 GHz = 78.6 T lane-instructions/s); "
-                                       "`hbm_view` keeps the algorithmic-bytes figures of the same run; " + out["roofline"]["note"])
+                # priced against the issue peak only with a counted instruction mix for exactly this configuration; without
+                # one the line keeps bound = "hbm" and its algorithmic-bytes figures (an HBM fraction labelled as a VALU
+                # bound would be a number about nothing)
+                out["roofline"].update(bound="valu", achieved=valu["achieved_Glane_inst_per_s"], peak=VALU_PEAK_GINST,
+                                       unit="G lane-instructions/s", frac=valu["frac"])
+                out["roofline"]["note"] = ("bound = vector-ALU issue (256 CUs x 4 SIMD-32 x 2.4 GHz = 78.6 T lane-instructions/s); "
+                                           "`hbm_view` keeps the algorithmic-bytes figures of the same run; " + out["roofline"]["note"])
+            else:
+                out["roofline"]["note"] = ("the k-step kernel is bound by vector-ALU issue, but no instruction count is on file for this "
+                                           "configuration (valu_unavailable): the figures shown are the algorithmic-bytes (HBM) view; " + out["roofline"]["note"])
         if not args.no_cpu_baseline and world == 1:
             out["cpu_baseline"] = cpu_baseline(params)
         print(json.dumps(out), flush=True)

@@ -60,6 +60,81 @@ def test_overall_wall_clock_limit_of_self_launched_ranks():
     assert "still running after 6 s" in r.stderr
 
 
+def _run_stub(extra, env=None, timeout=300):
+    import time
+    t0 = time.monotonic()
+    r = subprocess.run([sys.executable, BENCH, "--gpus", "2", "--steps", "40", "--warmup", "2", "--stub-step", "--drones-per-gpu", "1000"] + extra,
+                       capture_output=True, text=True, timeout=timeout, env=env or _clean_env())
+    lines = [ln for ln in r.stdout.splitlines() if ln.strip().startswith("{")]
+    return r, lines, time.monotonic() - t0
+
+
+def test_preflight_failure_falls_back_to_gloo_and_says_so():
+    """RCCL that does not come up must not cost the line.  The preflight children fail (with the
+    caller's IPC mode, then with the other one); fresh workers run with the done mask over gloo, and the line says what
+    happened."""
+    r, lines, _ = _run_stub(["--stub-preflight", "fail"])
+    assert r.returncode == 0, r.stderr[-3000:]
+    assert len(lines) == 1
+    c = json.loads(lines[0])["collective"]
+    assert c["requested"] == "rccl" and c["used"] == "gloo" and c["backend"] == "gloo"
+    assert "preflight failed" in c["fallback_reason"] and "rank 0" in c["fallback_reason"]
+    assert [p["ok"] for p in c["preflight"]] == [False, False] and [p["ipc_mode"] for p in c["preflight"]] == ["0", "1"]
+    assert [a["collective"] for a in c["attempts"]] == ["gloo"] and c["attempts"][0]["ok"]
+    assert c["world_seen"] == 2 and c["rank_ids_gathered"] == [0, 1] and c["gather"]["collectives_launched"] >= 1
+    assert c["done_mask_exchange"].startswith("gloo")
+
+
+def test_preflight_that_hangs_is_stopped_at_its_limit():
+    r, lines, took = _run_stub(["--stub-preflight", "hang", "--preflight-timeout-s", "3"])
+    assert r.returncode == 0, r.stderr[-3000:]
+    c = json.loads(lines[0])["collective"]
+    assert c["used"] == "gloo" and "no answer within 3 s" in c["fallback_reason"]
+    assert took < 120, took
+
+
+def test_callers_ipc_mode_is_honoured_and_recorded():
+    """bench.py used to hard-set HSA_ENABLE_IPC_MODE_LEGACY=0 in every child; now a caller's value travels to the
+    preflight and the workers and is written into the line; without one the default is 0 and the line says it is ours."""
+    env = dict(_clean_env(), HSA_ENABLE_IPC_MODE_LEGACY="1")
+    r, lines, _ = _run_stub([], env=env)
+    assert r.returncode == 0, r.stderr[-3000:]
+    c = json.loads(lines[0])["collective"]
+    assert c["ipc_mode"] == "1" and c["ipc_mode_of_caller"] == "1" and c["ipc_mode_source"] == "caller's environment"
+    assert c["used"] == "rccl" and c["fallback_reason"] is None and c["preflight"][0]["ok"] and c["preflight"][0]["ipc_mode"] == "1"
+    env = _clean_env()
+    env.pop("HSA_ENABLE_IPC_MODE_LEGACY", None)
+    r, lines, _ = _run_stub([], env=env)
+    assert r.returncode == 0, r.stderr[-3000:]
+    c = json.loads(lines[0])["collective"]
+    assert c["ipc_mode"] == "0" and c["ipc_mode_source"] == "bench.py default"
+
+
+def test_a_run_that_fails_in_the_collective_is_repeated_with_the_fallback():
+    r, lines, _ = _run_stub(["--stub-fail-collective", "rccl"])
+    assert r.returncode == 0, r.stderr[-3000:]
+    assert len(lines) == 1, "only the accepted attempt's line is printed"
+    c = json.loads(lines[0])["collective"]
+    assert [(a["collective"], a["ok"]) for a in c["attempts"]] == [("rccl", False), ("gloo", True)]
+    assert c["used"] == "gloo" and c["fallback_reason"].startswith("run failed") and "exit code 1" in c["fallback_reason"]
+    assert "the run with --collective rccl failed" in r.stderr
+
+
+def test_when_every_fallback_fails_the_job_fails_within_the_limit():
+    r, lines, took = _run_stub(["--stub-fail-collective", "all"])
+    assert r.returncode != 0 and not lines
+    assert "no fallback left" in r.stderr and took < 120, took
+
+
+def test_an_explicit_collective_is_used_as_given():
+    r, lines, _ = _run_stub(["--collective", "none"])
+    assert r.returncode == 0, r.stderr[-3000:]
+    c = json.loads(lines[0])["collective"]
+    assert c["used"] == "none" and c["requested"] == "none" and c["preflight"] == [] and "gather" not in c and c["done_mask_exchange"] is None
+    r, lines, _ = _run_stub(["--collective", "rccl", "--stub-fail-collective", "rccl"])
+    assert r.returncode != 0 and not lines, "an explicit backend has no fallback"
+
+
 def test_refuses_more_gpus_than_the_node_has():
     import torch
     have = torch.cuda.device_count()

@@ -98,3 +98,36 @@ def test_world2_gloo_done_allgather_matches_single_process(tmp_path):
                               for r in range(world)])
         assert np.array_equal(got, done), f"step {t}: gathered mask != concatenation of shard masks"
     assert any_done, "the scenario must actually produce done flags"
+
+
+def _choose_worker(rank, world, port, stub, out_dir, ipc):
+    import json
+    from fpyv_amd.dist import IPC_ENV, choose_backend
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world), LOCAL_RANK=str(rank))
+    if ipc is None:
+        os.environ.pop(IPC_ENV, None)
+    else:
+        os.environ[IPC_ENV] = ipc
+    c = choose_backend(limit_s=20.0, stub=stub)
+    # the default group is the gloo control plane the ranks agreed on: it must still work for the caller
+    t = torch.tensor([rank + 1])
+    dist.all_reduce(t)
+    c["sum"] = int(t)
+    with open(os.path.join(out_dir, f"choice_{rank}.json"), "w") as f:
+        json.dump(c, f)
+    dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("stub,ipc", [("ok", "1"), ("fail", None)])
+def test_choose_backend_world2(tmp_path, stub, ipc):
+    """A program that is its own rank process (examples/sharded_vec_env.py) decides before it touches the GPU whether
+    RCCL comes up: preflight in fresh children (here the gloo stub), agreement over gloo, the caller's IPC mode first."""
+    import json
+    mp.spawn(_choose_worker, args=(2, _free_port(), stub, str(tmp_path), ipc), nprocs=2, join=True)
+    c0, c1 = (json.load(open(tmp_path / f"choice_{r}.json")) for r in range(2))
+    assert c0["backend"] == c1["backend"] and c0["sum"] == c1["sum"] == 3
+    if stub == "ok":
+        assert c0["backend"] == "nccl" and c0["ipc_mode"] == "1" and c0["fallback_reason"] is None and len(c0["preflight"]) == 1
+    else:
+        assert c0["backend"] == "gloo" and "preflight failed" in c0["fallback_reason"]
+        assert [p["ipc_mode"] for p in c0["preflight"]] == ["0", "1"]          # the default first, then the other value

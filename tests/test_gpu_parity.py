@@ -1949,5 +1949,5 @@ def test_sharded_example_under_the_launcher_two_ranks_on_one_gpu():
                         "--block", "64", "--backend", "gloo", "--all-ranks-on-gpu0", "--check"],
                        capture_output=True, text=True, timeout=600, env=env)
     assert r.returncode == 0, (r.stdout + r.stderr)[-3000:]
-    assert "2 ranks x 32768 drones, 150 steps" in r.stdout and "(must agree)" in r.stdout
+    assert "2 ranks x 32768 drones over gloo, 150 steps" in r.stdout and "(must agree)" in r.stdout
     assert "equals its slice of the unsharded run bit for bit" in r.stdout
