@@ -333,6 +333,10 @@ def parse_args(argv=None):
     ap.add_argument("--api", choices=["rollout", "step", "rollout-launches"], default="step",
                     help="step (headline): one Python env.step() = one launch per step; rollout: the k-step kernel "
                          "(fpv_step_n), one launch per ring span; rollout-launches: k single-step launches from one C call")
+    ap.add_argument("--partitions", type=int, default=1,
+                    help="--api step only, N = 1: step the population as this many column partitions, each an independent kernel "
+                         "chain on its own stream (FpvVecEnv.step_async / step_wait, the split-phase API a closed-loop caller can "
+                         "use): the chains hide part of each other's per-launch floor.  A labelled line, not the headline")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-beyond-mall", action="store_true",
                     help="skip the extra short run at 2^23 drones (state 470 MB > the 256 MiB Infinity Cache)")
@@ -571,8 +575,18 @@ def main(argv=None):
                           with_done_bits=with_bits, fp16_state=args.fp16_state,
                           track_episodes=bool(multi and args.gather_returns))
 
-    env = make_env(n, multi)
-    env.reset()
+    venv = None
+    if args.partitions > 1:
+        if args.api != "step" or multi or args.racer or args.fp16_state:
+            raise SystemExit("--partitions needs --api step on one GPU with fp32 drone state (no --force-dist / --racer / --fp16-state)")
+        from fpyv_amd.env import FpvVecEnv
+        venv = FpvVecEnv(params, num_envs=n, device=dev, auto_reset=not args.no_auto_reset, track_episodes=False,
+                         partitions=args.partitions)
+        venv.reset()
+        env = venv.batch
+    else:
+        env = make_env(n, multi)
+        env.reset()
 
     total = args.steps + args.warmup
     ring = max(1, min(args.ring, total))
@@ -589,11 +603,25 @@ def main(argv=None):
         returns_all = torch.zeros(dist.get_world_size() * n, dtype=torch.float32, device=dev)
 
     launches = [0]
+    part_slices = {}
+    part_ranges = [venv.partition_range(kk) for kk in range(venv.partitions)] if venv is not None else []
 
     def run_on(e, acts, k, t_base, g):
         """k steps.  api=step: k launches; api=rollout: one k-step-kernel launch per ring span (and per gather bucket)."""
         nonlocal returns_work
         rlen = acts.shape[0]
+        if venv is not None and e is env:
+            # split phase: every partition's chain gets its step t; nothing joins the chains between steps (a policy
+            # would sit between step_wait(part) and step_async(part) of ONE partition while the other one steps)
+            sl = part_slices.setdefault(acts.data_ptr(), [[acts[r][lo:hi] for lo, hi in part_ranges] for r in range(rlen)])
+            for t in range(t_base, t_base + k):
+                row = sl[t % rlen]
+                for kk in range(venv.partitions):
+                    venv.step_async(kk, row[kk], ready=True)
+                launches[0] += 1                    # one full-population step (= `partitions` overlapping launches)
+            for kk in range(venv.partitions):
+                venv.step_wait(kk)                  # the caller's stream (and its timing events) follow every chain
+            return
         if args.api == "step":
             for t in range(t_base, t_base + k):
                 if g is not None:
@@ -715,7 +743,7 @@ def main(argv=None):
     # the same kernel with its state far outside the 256 MiB Infinity Cache (2^23 drones: 470 MB of state):
     # what a GPU-filling population sees; the 2^20-drone state (59 MB) lives in that cache between steps
     beyond = None
-    if rank == 0 and world == 1 and not args.no_beyond_mall and args.api == "step":
+    if rank == 0 and world == 1 and not args.no_beyond_mall and args.api == "step" and venv is None:
         nb = 1 << 23
         big = make_env(nb, False)
         big.reset()
@@ -769,7 +797,7 @@ def main(argv=None):
     # the straight line t(n) = floor + bytes / rate (from 2^19 drones up the residuals are < 0.4 us):
     # how much of the headline launch is the per-launch floor of a dependent kernel chain, and what the rest streams at
     fit = None
-    if rank == 0 and world == 1 and not args.no_beyond_mall and args.api == "step" and n == (1 << 20) and not args.racer:
+    if rank == 0 and world == 1 and not args.no_beyond_mall and args.api == "step" and n == (1 << 20) and not args.racer and venv is None:
         pts = []
         for nn in (n // 2, 2 * n):
             e = make_env(nn, False)
@@ -823,6 +851,8 @@ def main(argv=None):
                        + f"{n} drones/GPU, EMA-noise sticks (noise_smooth_test profile), fp32 math, dt=1ms, "
                        + ("no auto-reset" if args.no_auto_reset else f"in-kernel auto-reset on ground contact or |z|>{args.ceiling:g} m"),
                        "drones_per_gpu": n, "global_drones": n * world, "action_ring": ring, "api": args.api,
+                       "partitions": (venv.partitions if venv is not None else 1),
+                       "partition_streams": (venv.stream_report if venv is not None else None),
                        "steps_per_launch": steps_per_launch,
                        "parallelism": f"shard{world}" + ("+allgather(done_bits x" + str(args.gather_block) + " steps"
                                                               + (", last_return" if args.gather_returns else "") + ")" if gather is not None else "")},
@@ -837,6 +867,9 @@ def main(argv=None):
                          "launch_time_fit": None,
                          "note": "avg = HIP-event time over the timed region / launches (includes inter-launch gaps)"},
         }
+        if venv is not None:
+            out["roofline"]["note"] = (f"split phase: one step = {venv.partitions} launches on {venv.partitions} streams that overlap; avg_launch_us is the "
+                                       "time per full-population step, achieved = 133 B x n / that; " + out["roofline"]["note"])
         if fit is not None:
             # least squares through (bytes, us) at 2^19, 2^20 and 2^21 drones; the 2^20 point is the sustained leg of this
             # very env (thousands of launches, like the 400-launch legs of the two other sizes) when there is one, else

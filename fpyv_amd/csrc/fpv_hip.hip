@@ -955,6 +955,17 @@ __global__ __launch_bounds__(kBlock) void fpv_diag_copy4_kernel(fpv_v4f* __restr
     if (i < n4) dst[i] = src[i];
 }
 
+// A wave that idles for `ticks` of the 100 MHz constant-rate clock, at most `max_iter` sleeps (an exit every lane reaches
+// whatever the clock does): a kernel of known duration on one CU (fpv_diag_busy).
+__global__ __launch_bounds__(64) void fpv_diag_busy_kernel(const unsigned long long ticks, const int max_iter)
+{
+    const unsigned long long t0 = wall_clock64();
+    for (int it = 0; it < max_iter; ++it) {
+        if (wall_clock64() - t0 >= ticks) break;
+        __builtin_amdgcn_s_sleep(32);
+    }
+}
+
 thread_local std::string g_err;
 
 int fail(int code, const std::string& msg)
@@ -1374,6 +1385,17 @@ int fpv_diag_stream_copy_wide(float* dst, const float* src, int64_t n_floats, vo
                        reinterpret_cast<const fpv_v4f*>(src), n4);
     const hipError_t e = hipGetLastError();
     if (e != hipSuccess) return hip_fail(e, "diag wide copy launch");
+    return FPV_OK;
+}
+
+int fpv_diag_busy(double microseconds, void* stream)
+{
+    if (!(microseconds > 0.0) || microseconds > 1000.0) return fail(FPV_EINVAL, "fpv_diag_busy: 0 < microseconds <= 1000");
+    const unsigned long long ticks = (unsigned long long)(microseconds * 100.0);       // wall_clock64: 100 MHz on gfx950
+    // one s_sleep(32) is 32 x 64 clocks ~ 1 us at 2 GHz: the iteration cap is ~4x the requested time
+    hipLaunchKernelGGL(fpv_diag_busy_kernel, dim3(1), dim3(64), 0, (hipStream_t)stream, ticks, (int)(microseconds * 4.0) + 64);
+    const hipError_t e = hipGetLastError();
+    if (e != hipSuccess) return hip_fail(e, "diag busy launch");
     return FPV_OK;
 }
 

@@ -413,6 +413,103 @@ class _Batch:
             return rt.transpose(-1, -2)
         return quat_to_matrix(self.quaternion)
 
+
+class _Partition:
+    """Columns [lo, hi) of a parent batch as a stepper of their own: the SAME device tensors (every pointer is the
+    parent's, moved by `lo` elements; the row stride is the parent's), its own C handle (n = hi - lo drones, global
+    ids continuing the parent's: `drone_id_offset + lo`), its own stream.  A partition's steps form an independent
+    chain of kernels; chains of different partitions overlap on the GPU, which hides a part of each other's per-launch
+    floor.  `lo` is a multiple of 128 - whole workgroups, whole done-mask words, 16-byte aligned rows."""
+
+    def __init__(self, parent: "_Batch", lo: int, hi: int, stream: Optional[torch.cuda.Stream]):
+        if parent.fp16_state:
+            raise ValueError("partitions need fp32 state (the fp16 thrust row packs TWO drones per word: a column offset is not a pointer offset)")
+        if lo % 128 or not lo < hi <= parent.n:
+            raise ValueError("a partition starts at a multiple of 128 drones and is not empty")
+        self.parent, self.lo, self.hi, self.n = parent, lo, hi, hi - lo
+        self.stream = stream if stream is not None else torch.cuda.Stream(device=parent.device)
+        self._stream_ptr = self.stream.cuda_stream
+        self._L = parent._L
+        kw = dict(parent._pack_kw, drone_id_offset=int(parent._pack_kw.get("drone_id_offset", 0)) + lo)
+        auto = bool(parent._cparams.flags & _lib.FPV_FLAG_AUTO_RESET)
+        self._cparams = _lib.pack_params(parent.params, auto_reset=auto, **kw)
+        self._handle = C.c_void_p()
+        _lib.check(self._L.fpv_create(C.byref(self._cparams), self.n, parent._dev_index, C.byref(self._handle)))
+        self._buf = _lib.FpvBuffers()
+        self._buf_ref = C.byref(self._buf)
+        self._ashape, self._keep = torch.Size((self.n, 4)), None
+        self.steps_launched = 0
+        self.rebind()
+
+    def rebind(self) -> None:
+        """Point this partition's fpv_buffers_t at the parent's tensors (again, after the parent re-bound something)."""
+        pb, b, lo = self.parent._buf, self._buf, self.lo
+        off = lambda base, elem_bytes, per_drone=1: (base + lo * elem_bytes * per_drone) if base else None  # noqa: E731
+        b.state, b.ld = off(pb.state, 4), pb.ld
+        b.reward, b.done = off(pb.reward, 4), off(pb.done, 1)
+        b.done_bits = (pb.done_bits + (lo // 64) * 8) if pb.done_bits else None
+        b.accel, b.pos_comp, b.noise_state = off(pb.accel, 4), off(pb.pos_comp, 4), off(pb.noise_state, 4)
+        b.ep_return, b.ep_length = off(pb.ep_return, 4), off(pb.ep_length, 4)
+        b.last_return, b.last_length = off(pb.last_return, 4), off(pb.last_length, 4)
+        b.action_out, b.obs_aos = off(pb.action_out, 4, 4), off(pb.obs_aos, 4, _lib.FPV_OBS_AOS_DIM)
+        b.wind[0], b.wind[1], b.wind[2] = pb.wind[0], pb.wind[1], pb.wind[2]
+        b.rounding_seed, b.state_h, b.objects = pb.rounding_seed, None, pb.objects
+        b.done_bits_stride = 0
+
+    def action_ptr(self, action: Any) -> Optional[int]:
+        if action is None:
+            if not self.parent.stick_noise:
+                raise ValueError("action=None is only meaningful with stick_noise=True (pure noise sticks)")
+            return None
+        st = self.parent.state
+        if type(action) is torch.Tensor and action.dtype is torch.float32 and action.device == st.device:
+            if action.shape == self._ashape and action.is_contiguous():               # [n_p, 4] rows (a row slice of [N, 4] is one)
+                self._buf.action_ld = 0
+                self._keep = action
+                return action.data_ptr()
+            if (action.dim() == 2 and action.shape[0] == 4 and action.shape[1] == self.n and self.n != 4
+                    and action.stride(1) == 1 and action.stride(0) >= self.n):         # SoA [4, n_p] (a column slice of [4, N] is one)
+                self._buf.action_ld = action.stride(0)
+                self._keep = action
+                return action.data_ptr()
+        raise ValueError(f"a partition's action is a float32 tensor on the env's device, [{self.n}, 4] contiguous rows or "
+                         f"[4, {self.n}] with unit column stride (slices of a full-size tensor qualify)")
+
+    def launch(self, action: Any) -> None:
+        b = self._buf
+        b.action = self.action_ptr(action)
+        rc = self._L.fpv_step(self._handle, self._buf_ref, self._stream_ptr)
+        if rc < 0:
+            _lib.check(rc)
+        self.steps_launched += 1
+
+    def set_step_counter(self, step: int) -> None:
+        _lib.check(self._L.fpv_set_step_counter(self._handle, int(step)))
+        self.steps_launched = int(step)
+
+    def close(self) -> None:
+        if getattr(self, "_handle", None) is not None and self._handle.value:
+            self._L.fpv_destroy(self._handle)
+            self._handle = C.c_void_p()
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+
+def partition_bounds(n: int, parts: int) -> Sequence[Tuple[int, int]]:
+    """`parts` contiguous column ranges of n drones, every start a multiple of 128 (whole workgroups and mask words),
+    sizes as equal as that allows; fewer ranges than asked for when n is too small to give each one a workgroup."""
+    if parts < 1:
+        raise ValueError("partitions must be >= 1")
+    blocks = (n + 127) // 128
+    parts = max(1, min(parts, blocks))
+    cuts = [min(n, (blocks * k // parts) * 128) for k in range(parts)] + [n]
+    return [(cuts[k], cuts[k + 1]) for k in range(parts)]
+
+
 def as_drone_params(params: Any, mode: int, default_fps: Optional[float] = None) -> DroneParams:
     """DroneParams | params.yaml-shaped dict (what the reference passes to Drone(), components.py:73) |
     path of such a YAML | None (packaged defaults) -> DroneParams in the requested mode."""
@@ -648,14 +745,29 @@ class FpvVecEnv:
     state store IS the observation write.  reward = -|p - goal| (the reference defines none for
     `Drone`); done = ground contact (reference) or |z| > ceiling (build); with auto_reset the lane is
     re-initialised in the same kernel and obs already shows the fresh episode.
+
+    **Split phase** (`partitions=P`, gym's VectorEnv step_async / step_wait per partition): the population is cut into P
+    contiguous column ranges of the SAME tensors, each stepped by its own chain of kernels on its own stream:
+
+        env = FpvVecEnv(params, num_envs=N, partitions=2)
+        env.reset()
+        for t in range(T):
+            for part in range(env.partitions):
+                obs, reward, done, info = env.step_wait(part)     # views of this partition's drones, after its last step
+                env.step_async(part, policy(obs))                 # returns at once; the other partition's step is in flight
+
+    While the policy looks at partition A, partition B steps, and the two kernel chains overlap on the GPU - each hides a
+    part of the other's per-launch floor (17 % of a 2^20-drone launch).  Drones keep their GLOBAL ids, so
+    every buffer is bit-identical to the unpartitioned env's after the same number of steps, whatever P is.  `step()`
+    still advances all drones (step_async + step_wait over all partitions).
     """
 
     def __init__(self, params: Optional[DroneParams] = None, num_envs: int = 1, device: Any = "cuda:0",
                  mode: str = "drone", auto_reset: bool = True, track_episodes: bool = True,
-                 wind: Sequence[float] = (0.0, 0.0, 0.0), object_list=(), **batch_options: Any):
+                 wind: Sequence[float] = (0.0, 0.0, 0.0), object_list=(), partitions: int = 1, **batch_options: Any):
         """`batch_options` go to DroneBatch / RacerBatch (stick_noise=, noise_seed=, drone_id_offset=,
         fp16_state=, with_obs_aos=, kahan_position=, with_done_bits=, ...); `object_list` is the
-        collision world of every step (fpyv_amd.objects)."""
+        collision world of every step (fpyv_amd.objects); `partitions` > 1 enables step_async / step_wait."""
         if mode not in ("drone", "racer"):
             raise ValueError(f'mode must be "drone" or "racer", got {mode!r}')
         params = params if params is not None else load_params(fps=1000)
@@ -671,6 +783,21 @@ class FpvVecEnv:
         self.obs_dim = 13
         self.action_dim = 4
         self._obs_view = None
+        self._parts: list = []
+        self.stream_report: Optional[Dict[str, Any]] = None
+        if int(partitions) > 1:
+            self.batch._buf.wind[0], self.batch._buf.wind[1], self.batch._buf.wind[2] = self.wind
+            bounds = partition_bounds(self.num_envs, int(partitions))
+            if len(bounds) > 1:
+                # streams whose kernel chains really overlap - with each other and with the caller's stream (where a policy
+                # runs): measured, not assumed (fpyv_amd/streams.py; ~10 ms, once)
+                from .streams import overlapping_streams
+                with torch.cuda.device(self.batch.device):
+                    streams, self.stream_report = overlapping_streams(self.batch.device, len(bounds),
+                                                                      avoid=[torch.cuda.current_stream(self.batch.device)])
+                self._parts = [_Partition(self.batch, lo, hi, st) for (lo, hi), st in zip(bounds, streams)]
+                self._part_views = [None] * len(self._parts)
+        self.partitions = max(1, len(self._parts))
 
     @property
     def obs(self) -> torch.Tensor:
@@ -683,17 +810,104 @@ class FpvVecEnv:
 
     def reset(self, mask=None) -> torch.Tensor:
         self.batch.reset(mask=mask)
+        if self._parts:                      # the partitions' chains start after the reset (enqueued on the caller's stream)
+            cur = torch.cuda.current_stream(self.batch.device)
+            for P in self._parts:
+                P.stream.wait_stream(cur)
+                if mask is None:
+                    P.set_step_counter(self.batch._steps_launched)
         return self.obs
 
     def step(self, action) -> Tuple[torch.Tensor, torch.Tensor, torch.Tensor, Dict[str, Any]]:
+        if self._parts:
+            soa = action is not None and action.dim() == 2 and action.shape[0] == 4 and action.shape[1] == self.num_envs != 4
+            for k, P in enumerate(self._parts):
+                self.step_async(k, None if action is None else action[:, P.lo:P.hi] if soa else action[P.lo:P.hi])
+            for k in range(len(self._parts)):
+                self.step_wait(k)
+            return self.obs, self.batch.reward, self.batch.done, self._info(self.batch, 0, self.num_envs)
         if self.object_list or self.batch._buf.objects:
             self.batch._set_objects(self.object_list)
         self.batch._step_raw(action, self.wind)
+        return self.obs, self.batch.reward, self.batch.done, self._info(self.batch, 0, self.num_envs)
+
+    @staticmethod
+    def _info(batch, lo: int, hi: int) -> Dict[str, Any]:
         info: Dict[str, Any] = {}
-        if self.batch.last_return is not None:
-            info["episode_return"] = self.batch.last_return
-            info["episode_length"] = self.batch.last_length
-        return self.obs, self.batch.reward, self.batch.done, info
+        if batch.last_return is not None:
+            whole = lo == 0 and hi == batch.n
+            info["episode_return"] = batch.last_return if whole else batch.last_return[lo:hi]
+            info["episode_length"] = batch.last_length if whole else batch.last_length[lo:hi]
+        return info
+
+    # -- split phase ------------------------------------------------------------------------------
+    def partition_range(self, part: int) -> Tuple[int, int]:
+        """[lo, hi): the drones of partition `part` (columns of every per-drone tensor of the env)."""
+        P = self._part(part)
+        return P.lo, P.hi
+
+    def stream(self, part: int) -> torch.cuda.Stream:
+        """The stream partition `part` steps on.  A policy run under `with torch.cuda.stream(env.stream(part))` is
+        ordered with that partition's steps by the stream itself: step_async / step_wait then add no cross-stream waits."""
+        return self._part(part).stream
+
+    def _part(self, part: int) -> _Partition:
+        if not self._parts:
+            raise RuntimeError("this env was built with partitions=1: use step(), or build it with partitions=2")
+        return self._parts[part]
+
+    def step_async(self, part: int, action, ready: bool = False) -> None:
+        """Enqueue one step of partition `part` on its own stream and return at once.  `action`: this partition's sticks,
+        [n_p, 4] rows or [4, n_p] SoA (slices of full-size tensors qualify).  The step is ordered after whatever the
+        caller's current stream has enqueued so far (the policy that produced `action`), unless that IS the partition's
+        stream or `ready=True` says the tensor is already complete (pre-generated sticks)."""
+        P = self._part(part)
+        if not ready:
+            cur = torch.cuda.current_stream(self.batch.device)
+            if cur != P.stream:
+                P.stream.wait_stream(cur)
+        if self.object_list or self.batch._buf.objects:
+            self.batch._set_objects(self.object_list)
+            P._buf.objects = self.batch._buf.objects
+        P.launch(action)
+
+    def step_wait(self, part: int, sync: bool = True) -> Tuple[torch.Tensor, torch.Tensor, torch.Tensor, Dict[str, Any]]:
+        """(obs, reward, done, info) of partition `part` - views of its columns - ordered after its last enqueued step:
+        the caller's current stream waits for the partition's stream (on the device, not on the host).  `sync=False`
+        skips that wait for a caller who works on the partition's own stream."""
+        P = self._part(part)
+        if sync:
+            cur = torch.cuda.current_stream(self.batch.device)
+            if cur != P.stream:
+                cur.wait_stream(P.stream)
+        v = self._part_views[part]
+        if v is None:
+            b = self.batch
+            v = self._part_views[part] = (b.state[:13, P.lo:P.hi].t(), b.reward[P.lo:P.hi], b.done[P.lo:P.hi])
+        return v[0], v[1], v[2], self._info(self.batch, P.lo, P.hi)
+
+    def state_dict(self) -> Dict[str, Any]:
+        """The batch's checkpoint; with partitions the step counters of all of them (they key the stick-noise streams)."""
+        for k in range(len(self._parts)):
+            self.step_wait(k)
+        d = self.batch.state_dict()
+        if self._parts:
+            d["partition_step_counters"] = [P.steps_launched for P in self._parts]
+            d["step_counter"] = min(d["partition_step_counters"])        # what an unpartitioned env continues from
+        return d
+
+    def load_state_dict(self, d: Dict[str, Any]) -> None:
+        self.batch.load_state_dict(d)
+        if self._parts:
+            ctr = d.get("partition_step_counters") or [d["step_counter"]] * len(self._parts)
+            if len(ctr) != len(self._parts):
+                raise ValueError("checkpoint was taken with a different number of partitions")
+            cur = torch.cuda.current_stream(self.batch.device)
+            for P, c in zip(self._parts, ctr):
+                P.set_step_counter(c)
+                P.stream.wait_stream(cur)
 
     def close(self) -> None:
+        for P in self._parts:
+            P.close()
         self.batch.close()

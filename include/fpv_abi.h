@@ -30,7 +30,11 @@ extern "C" {
 /* 4: 64-bit step counter (fpv_set_step_counter takes uint64_t, fpv_get_step_counter added; the stick-noise stream is
  *    unchanged below 2^32 steps and no longer repeats beyond); fpv_set_tuning removed (2 / 4 drones per lane and
  *    256-thread workgroups lost every measurement); fpv_comm_info added; fpv_step_n reads action rows only. */
-#define FPV_ABI_VERSION 4
+/* 5: fpv_diag_busy added (a time-bounded one-wave kernel: lets a host tell whether two streams sit on different
+ *    hardware queues - the split-phase API picks its partition streams that way); the in-kernel stick-noise generator
+ *    rebuilt for cost (Philox4x32-7, division-free logarithm): streams differ from ABI <= 4 (the reference's profile is
+ *    unseeded, /root/reference/tests/noise_smooth_test.py:6-12: there never was a stream to stay compatible with). */
+#define FPV_ABI_VERSION 5
 
 enum {
     FPV_OK = 0,
@@ -292,6 +296,12 @@ int fpv_diag_stream_copy(float* dst, const float* src, int64_t n_floats, void* s
 /* the same copy with 16 bytes per lane (n_floats a multiple of 4, 16-byte aligned pointers): the streaming ceiling of
  * the chip on this box - bench.py times it beside the step kernel at 2^23 drones (roofline.beyond_mall.copy_ceiling_GBs) */
 int fpv_diag_stream_copy_wide(float* dst, const float* src, int64_t n_floats, void* stream);
+/* one wave that does nothing for about `microseconds` (0 < microseconds <= 1000; bounded by the constant-rate clock AND by
+ * an iteration count, so every lane leaves) on `stream` of the current device: a kernel of known duration that occupies one
+ * CU.  Two streams whose chains of such kernels take as long together as one chain alone run on different hardware
+ * queues (fpyv_amd.streams.overlapping_streams); the runtime shares a queue between streams once it has handed out all
+ * it has, and chains on a shared queue do not overlap. */
+int fpv_diag_busy(double microseconds, void* stream);
 
 /* ---- multi-GPU: contiguous shards, one process (or thread) per GPU, RCCL over xGMI ---------------------------
  * The physics needs no collective (drones are independent); the only exchange of the path is the all-gather of the

@@ -577,6 +577,92 @@ def test_vec_env_surface(params_1k):
     assert set(np.unique(raw)) <= {0, 1}
 
 
+@pytest.mark.parametrize("case", ["plain2", "noise3", "racer2", "objects2"])
+def test_split_phase_partitions_are_bitwise_the_single_batch(params_1k, case):
+    """FpvVecEnv(partitions=P): step_async(part, action) / step_wait(part) - each partition its own handle, stream and
+    kernel chain over column ranges of the SAME tensors, drones keyed by their global id.  Closed loop (a linear policy
+    on each partition's observation view, computed on the caller's stream while the other partition steps) for 200
+    steps with in-kernel auto-reset: every buffer equals the unpartitioned env driven by the same policy, bit for bit -
+    state, reward, done, the bit-packed mask, episode bookkeeping, the noise rows, the applied sticks."""
+    from fpyv_amd.env import FpvVecEnv, partition_bounds
+    from fpyv_amd.objects import Cylinder, Ground
+    n, T = 128 * 37 + 55, 200                       # the last partition ends in a ragged wave
+    parts = 3 if case == "noise3" else 2
+    p = params_1k.replace(ceiling=10.3, noise_gain=0.8)
+    kw = dict(num_envs=n, device=DEV, auto_reset=True, track_episodes=True, with_done_bits=True)
+    if case == "noise3":
+        kw.update(stick_noise=True, noise_seed=99, drone_id_offset=5000, with_action_out=True)
+    if case == "racer2":
+        pid = np.array([[0.004, 0.02, 1e-6], [0.003, 0.01, 2e-6], [0.002, 0.005, 0]])
+        p = params_1k.replace(mode=1, racer_pid=pid, ceiling=3e-3)
+        kw.update(mode="racer")
+    if case == "objects2":
+        p = p.replace(init_position=np.array([0.0, 0.0, 0.12]), ceiling=3.0)       # low start, low throttle: the ground ends episodes
+        kw.update(object_list=[Ground(), Cylinder(position=[1.5, 0.2, 0.0], radius=0.4, height=1.0)], wind=(0.4, -0.1, 0.0))
+    one, split = FpvVecEnv(p, **kw), FpvVecEnv(p, partitions=parts, **kw)
+    assert split.partitions == parts and [split.partition_range(k) for k in range(parts)] == list(partition_bounds(n, parts))
+    assert all(lo % 128 == 0 for lo, _ in partition_bounds(n, parts)) and partition_bounds(n, parts)[-1][1] == n
+    torch.manual_seed(3)
+    W = torch.randn(4, 13, device=DEV) * (0.02 if case != "racer2" else 0.5)
+    bias = torch.tensor([0.0, 0.0, 0.0, 3.0 if case == "racer2" else -0.9 if case == "objects2" else 0.4], device=DEV)
+    policy = lambda o: torch.tanh(o @ W.t()) + bias        # noqa: E731  ([n, 13] view -> [n, 4] rows)
+    obs = one.reset()
+    split.reset()
+    for _ in range(T):
+        obs, _, _, _ = one.step(policy(obs).contiguous())
+    hits = 0
+    for t in range(T):
+        for k in range(parts):
+            o, r, d, info = split.step_wait(k)                 # views of this partition's columns after ITS last step
+            split.step_async(k, policy(o).contiguous())        # the other partition's step is in flight meanwhile
+    for k in range(parts):
+        o, r, d, info = split.step_wait(k)
+        lo, hi = split.partition_range(k)
+        assert o.shape == (hi - lo, 13) and r.shape == (hi - lo,) and d.dtype == torch.bool and info["episode_length"].shape == (hi - lo,)
+        assert o.data_ptr() == split.batch.state.data_ptr() + 4 * lo          # a view, not a copy
+    torch.cuda.synchronize()
+    a, b = one.batch, split.batch
+    for name in ("state", "reward", "done_u8", "done_bits", "ep_return", "ep_length", "last_return", "last_length", "noise_state", "action_out"):
+        x, y = getattr(a, name, None), getattr(b, name, None)
+        if x is not None:
+            assert torch.equal(x, y), (case, name)
+    assert int(a.last_length.max()) > 0, "auto-reset must have ended episodes"
+    # step(): all partitions at once, still the same bits; a checkpoint of the split env continues in an unpartitioned one
+    act = (torch.rand((n, 4), device=DEV) * 2 - 1) * (1.0 if case != "racer2" else 4.0)
+    one.step(act); split.step(act)
+    torch.cuda.synchronize()
+    assert torch.equal(a.state, b.state) and torch.equal(a.done_u8, b.done_u8)
+    ck = split.state_dict()
+    assert ck["partition_step_counters"] == [T + 1] * parts and ck["step_counter"] == T + 1
+    third = FpvVecEnv(p, **kw)
+    third.reset()
+    third.batch.load_state_dict({k: v for k, v in ck.items() if k != "partition_step_counters"})
+    one.step(act); third.step(act)
+    torch.cuda.synchronize()
+    assert torch.equal(a.state, third.batch.state)
+    for e in (one, split, third):
+        e.close()
+
+
+def test_split_phase_api_errors(params_1k):
+    from fpyv_amd.env import FpvVecEnv
+    env = FpvVecEnv(params_1k, num_envs=1000, device=DEV)
+    with pytest.raises(RuntimeError):
+        env.step_async(0, torch.zeros((1000, 4), device=DEV))
+    with pytest.raises(ValueError):
+        FpvVecEnv(params_1k, num_envs=1000, device=DEV, partitions=2, fp16_state=True)
+    two = FpvVecEnv(params_1k, num_envs=1000, device=DEV, partitions=2)
+    two.reset()
+    lo, hi = two.partition_range(1)
+    with pytest.raises(ValueError):
+        two.step_async(1, torch.zeros((1000, 4), device=DEV))               # the partition's own slice is what it takes
+    full = torch.zeros((4, 1000), device=DEV)
+    two.step_async(1, full[:, lo:hi])                                        # SoA column slice of a full-size tensor
+    two.step_async(0, torch.zeros((1000, 4), device=DEV)[:lo], ready=True)
+    assert FpvVecEnv(params_1k, num_envs=100, device=DEV, partitions=4).partitions == 1   # too small to cut: one workgroup
+    torch.cuda.synchronize()
+
+
 @pytest.mark.parametrize("name", ["g7_racer_main", "g8_racer_pid_thrust"])
 def test_vec_env_racer_mode_vs_reference_capture(params_1k, name):
     """FpvVecEnv(mode="racer"): the gym surface over Racer.step (racer_drone_test.py:95-103) against the reference
