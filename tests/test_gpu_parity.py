@@ -597,7 +597,7 @@ def test_split_phase_partitions_are_bitwise_the_single_batch(params_1k, case):
         p = params_1k.replace(mode=1, racer_pid=pid, ceiling=3e-3)
         kw.update(mode="racer")
     if case == "objects2":
-        p = p.replace(init_position=np.array([0.0, 0.0, 0.12]), ceiling=3.0)       # low start, low throttle: the ground ends episodes
+        p = p.replace(init_position=np.array([0.0, 0.0, 0.12]), init_velocity=np.array([1.0, 0.0, -3.0]), ceiling=3.0)   # diving: the ground ends episodes
         kw.update(object_list=[Ground(), Cylinder(position=[1.5, 0.2, 0.0], radius=0.4, height=1.0)], wind=(0.4, -0.1, 0.0))
     one, split = FpvVecEnv(p, **kw), FpvVecEnv(p, partitions=parts, **kw)
     assert split.partitions == parts and [split.partition_range(k) for k in range(parts)] == list(partition_bounds(n, parts))
