@@ -32,7 +32,7 @@ sys.path.insert(0, REPO)
 
 HBM_PEAK_GBS = 8000.0   # MI355X HBM3E peak, /opt/skills/guides/MI355X_MICROARCH.md "HBM3E peak BW"
 VALU_PEAK_GINST = 256 * 4 * 32 * 2.4   # lane-instructions/ns: 256 CUs x 4 SIMD-32 x 2.4 GHz (same guide)
-KERNEL_SOURCES = [os.path.join(REPO, "fpyv_amd", "csrc", f) for f in ("fpv_hip.hip", "fpv_math.h", "fpv_addr.h", "fpv_derive.h")]
+KERNEL_SOURCES = [os.path.join(REPO, "fpyv_amd", "csrc", f) for f in ("fpv_hip.hip", "fpv_math.h", "fpv_addr.h", "fpv_derive.h", "fpv_normal_table.h")]
 
 
 def _strip_comments(src):

@@ -236,14 +236,27 @@ struct RollOut {
     }
 };
 
-// EMA stick noise: read 4 state floats, one Philox4x32-10 block -> 4 normals, write them back,
+// The inverse-CDF table of the stick-noise generator (fpv_normal_from_word): 128 rows x 16 bytes in device memory, staged
+// into LDS by every workgroup of a NOISE kernel - each lane then reads one row per normal with ONE ds_read_b128 at an
+// address it computes from its random word.  (Half of all lanes read the top binade's rows: same-address reads are
+// broadcast, not serialised.)  The staging runs BEFORE any lane leaves the kernel: every thread of the workgroup
+// reaches the barrier.
+__device__ const FpvNormalRow g_normal_table[FPV_NTAB_ROWS] = FPV_NTAB_DATA;
+
+__device__ __forceinline__ void stage_normal_table(FpvNormalRow* lds)
+{
+    for (int r = threadIdx.x; r < FPV_NTAB_ROWS; r += kStepBlock) lds[r] = g_normal_table[r];
+    __syncthreads();
+}
+
+// EMA stick noise: read 4 state floats, one Philox4x32-7 block -> 4 normals, write them back,
 // perturb the action.  With no caller action (B.action null) the sticks are the pure noise profile.
-__device__ __forceinline__ float4 apply_stick_noise(const FpvK& K, const FpvBufD& B, uint32_t i, float4 a)
+__device__ __forceinline__ float4 apply_stick_noise(const FpvK& K, const FpvBufD& B, uint32_t i, float4 a, const FpvNormalRow* table)
 {
     float ns[4], av[4] = {a.x, a.y, a.z, a.w};
 #pragma unroll
     for (int k = 0; k < 4; ++k) ns[k] = row_at(ROW(B.noise_state, k, B.ld), i);
-    fpv_stick_noise(K.noise, B.step, (uint64_t)i, ns, av);
+    fpv_stick_noise(K.noise, B.step, (uint64_t)i, table, ns, av);
 #pragma unroll
     for (int k = 0; k < 4; ++k) row_at(ROW(B.noise_state, k, B.ld), i) = ns[k];
     const float4 r = make_float4(av[0], av[1], av[2], av[3]);
@@ -285,6 +298,8 @@ template <bool NOISE = false, bool OBJ = false, bool KAHAN = false, bool OVR = f
 __global__ __launch_bounds__(kStepBlock) FPV_EXP_STEP_ATTR void fpv_drone_step_kernel(FPV_STEP_PARAMS)
 {
     FPV_STEP_VIEW;
+    __shared__ FpvNormalRow ntab[NOISE ? FPV_NTAB_ROWS : 1];
+    if (NOISE) stage_normal_table(ntab);
     const uint32_t i = blockIdx.x * (uint32_t)kStepBlock + threadIdx.x;    // n <= 2^28 (fpv_create)
     // lanes past the end leave at once (a ballot over the remaining lanes still yields the right done bits:
     // exited lanes contribute 0, and a wave whose lane 0 is gone is empty)
@@ -294,7 +309,7 @@ __global__ __launch_bounds__(kStepBlock) FPV_EXP_STEP_ATTR void fpv_drone_step_k
     // issue every load of this lane before the first use
     float4 a = (!NOISE || B.action) ? ld_action_any(B.action, B.action_ld, i) : make_float4(0.f, 0.f, 0.f, 0.f);
     ld_drone(B.state, B.ld, i, s);
-    if (NOISE) a = apply_stick_noise(K, B, i, a);
+    if (NOISE) a = apply_stick_noise(K, B, i, a, ntab);
     if (OVR) {
 #pragma unroll
         for (int k = 0; k < 9; ++k) ro[k] = B.rot_over[(int64_t)i * 9 + k];     // 64-bit index: 36 * i can pass 2^32
@@ -378,6 +393,8 @@ template <bool NOISE, bool OBJ, bool KAHAN, bool SQ = false>
 __global__ __launch_bounds__(kStepBlock) FPV_EXP_ROLL_ATTR void fpv_drone_rollout_kernel(const FpvRollArgs A)
 {
     static_assert(!(SQ && OBJ), "the two-height ground flag does not feed the object pass");
+    __shared__ FpvNormalRow ntab[NOISE ? FPV_NTAB_ROWS : 1];
+    if (NOISE) stage_normal_table(ntab);
     const uint32_t i = blockIdx.x * (uint32_t)kStepBlock + threadIdx.x;
     if (i >= A.n) return;
     FpvDroneState s;
@@ -408,11 +425,11 @@ __global__ __launch_bounds__(kStepBlock) FPV_EXP_ROLL_ATTR void fpv_drone_rollou
         av[0] = a_next.x; av[1] = a_next.y; av[2] = a_next.z; av[3] = a_next.w;
         if ((!NOISE || has_action) && (QUIET || prefetch)) a_next = ld_action(reinterpret_cast<const float4*>(ap_next), i);
         if (NOISE) {
-            // the ten Philox round keys are uniform and loop-invariant: left alone the compiler keeps all twenty words
-            // in SGPRs for the whole loop; seen through an opaque copy of the seed they are ten scalar adds per step
+            // the Philox round keys are uniform and loop-invariant: left alone the compiler keeps all fourteen words
+            // in SGPRs for the whole loop; seen through an opaque copy of the seed they are scalar adds per step
             FpvNoiseK N = V.K.noise;
             asm volatile("" : "+s"(N.seed_lo), "+s"(N.seed_hi));
-            fpv_stick_noise(N, V.B.step + (uint64_t)t, (uint64_t)i, ns, av);
+            fpv_stick_noise(N, V.B.step + (uint64_t)t, (uint64_t)i, ntab, ns, av);
         }
         FpvStepOut o = fpv_drone_step_lane<OBJ, !QUIET, SQ && QUIET>(V.K, s, av[0], av[1], av[2], av[3], V.B.wx, V.B.wy, V.B.wz,
                                                                        objs, KAHAN ? kc : nullptr);

@@ -192,15 +192,22 @@ extern "C" int fpvl_stick_noise(const fpv_params_t* P, int64_t n, int steps, flo
         for (int64_t i = 0; i < n; ++i) {
             float s[4], a[4];
             for (int k = 0; k < 4; ++k) { s[k] = ns[k * ld + i]; a[k] = base_actions ? base_actions[((int64_t)t * n + i) * 4 + k] : 0.0f; }
-            fpv_stick_noise(K.noise, step0 + (uint64_t)t, (uint64_t)i, s, a);
+            fpv_stick_noise(K.noise, step0 + (uint64_t)t, (uint64_t)i, fpv_normal_table_host, s, a);
             for (int k = 0; k < 4; ++k) { ns[k * ld + i] = s[k]; if (applied) applied[((int64_t)t * n + i) * 4 + k] = a[k]; }
         }
     return FPV_OK;
 }
 
-extern "C" void fpvl_philox(const uint32_t ctr[4], const uint32_t key[2], uint32_t out[4])
+extern "C" void fpvl_philox(const uint32_t ctr[4], const uint32_t key[2], uint32_t out[4], int rounds)
 {
-    fpv_philox4x32_10(ctr[0], ctr[1], ctr[2], ctr[3], key[0], key[1], out);
+    if (rounds == 7) fpv_philox4x32<7>(ctr[0], ctr[1], ctr[2], ctr[3], key[0], key[1], out);
+    else fpv_philox4x32<10>(ctr[0], ctr[1], ctr[2], ctr[3], key[0], key[1], out);
+}
+extern "C" int fpvl_noise_philox_rounds(void) { return FPV_NOISE_PHILOX_ROUNDS; }
+// the generator's inverse normal CDF on an array of 32-bit words
+extern "C" void fpvl_normal_from_words(const uint32_t* w, float* z, int64_t n)
+{
+    for (int64_t i = 0; i < n; ++i) z[i] = fpv_normal_from_word(w[i], fpv_normal_table_host);
 }
 
 // lane addressing (fpyv_amd/csrc/fpv_addr.h) exposed for the unit test of the 2^28-drone limit
@@ -245,6 +252,3 @@ extern "C" void fpvl_quat_from_rot(const float m[9], float q[4])
     q[0] = r.w; q[1] = r.x; q[2] = r.y; q[3] = r.z;
 }
 
-// the noise generator's own elementary functions (no libm on either side)
-extern "C" void fpvl_sincos_2pi(float u, float* s, float* c) { fpv_sincos_2pi(u, s, c); }
-extern "C" float fpvl_log_normal_arg(float u) { return fpv_log_normal_arg(u); }

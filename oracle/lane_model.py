@@ -266,11 +266,26 @@ def round_seed(base: int, step: int) -> int:
     return int(L.fpvl_round_seed(int(base) & 0xFFFFFFFF, int(step) & (2 ** 64 - 1)))
 
 
-def philox(ctr, key):
+def philox(ctr, key, rounds: int = 10):
+    """Philox4x32 with 10 (the Random123 reference function) or 7 rounds (what the noise generator runs)."""
     L = lib()
     out = (C.c_uint32 * 4)()
-    L.fpvl_philox((C.c_uint32 * 4)(*ctr), (C.c_uint32 * 2)(*key), out)
+    L.fpvl_philox((C.c_uint32 * 4)(*ctr), (C.c_uint32 * 2)(*key), out, int(rounds))
     return [int(x) for x in out]
+
+
+def noise_philox_rounds() -> int:
+    return int(lib().fpvl_noise_philox_rounds())
+
+
+def normal_from_words(w: np.ndarray) -> np.ndarray:
+    """The generator's table-driven inverse normal CDF (fpv_normal_from_word) on an array of 32-bit words."""
+    L = lib()
+    L.fpvl_normal_from_words.argtypes = [C.POINTER(C.c_uint32), C.POINTER(C.c_float), C.c_int64]
+    w = np.ascontiguousarray(w, dtype=np.uint32)
+    z = np.zeros(w.shape, dtype=np.float32)
+    L.fpvl_normal_from_words(w.ctypes.data_as(C.POINTER(C.c_uint32)), z.ctypes.data_as(C.POINTER(C.c_float)), w.size)
+    return z
 
 
 def pid_run(gains, current: np.ndarray, target: np.ndarray):
@@ -299,18 +314,3 @@ def quat_from_rot(R) -> np.ndarray:
     for i in range(R.shape[0]):
         L.fpvl_quat_from_rot(fp(R[i]), fp(q[i]))
     return q
-
-
-def noise_elementary(u: np.ndarray):
-    """(sin(2 pi u), cos(2 pi u), log(u)) in the generator's own fp32 arithmetic for an array of u in (0, 1)."""
-    L = lib()
-    L.fpvl_sincos_2pi.argtypes = [C.c_float, C.POINTER(C.c_float), C.POINTER(C.c_float)]
-    L.fpvl_log_normal_arg.argtypes = [C.c_float]
-    L.fpvl_log_normal_arg.restype = C.c_float
-    u = np.asarray(u, dtype=np.float32)
-    s, c, lg = np.zeros_like(u), np.zeros_like(u), np.zeros_like(u)
-    a, b = C.c_float(), C.c_float()
-    for i, x in enumerate(u):
-        L.fpvl_sincos_2pi(float(x), C.byref(a), C.byref(b))
-        s[i], c[i], lg[i] = a.value, b.value, L.fpvl_log_normal_arg(float(x))
-    return s, c, lg

@@ -1,7 +1,8 @@
-"""In-kernel stick-noise generator: Philox4x32-10 pinned by the Random123
-known-answer vectors, the EMA profile of /root/reference/tests/noise_smooth_test.py:6-12 checked
-against a float64 NumPy restatement (oracle/philox.py), shard / batch invariance, and - on the GPU -
-the kernel against both."""
+"""In-kernel stick-noise generator: Philox4x32 pinned by the Random123 known-answer vectors for
+10 and for 7 rounds (the generator runs 7), the table-driven inverse normal CDF against scipy's, the EMA profile of
+/root/reference/tests/noise_smooth_test.py:6-12 against a float64 NumPy restatement (oracle/philox.py) and against
+its own statistics (mean, stationary sigma, lag-1 autocorrelation, normality), shard / batch invariance, and - on the
+GPU - the kernel against both."""
 import numpy as np
 import pytest
 
@@ -16,11 +17,20 @@ KAT = [  # Random123 kat_vectors, philox4x32-10: counter, key, expected
 ]
 
 
-@pytest.mark.parametrize("ctr,key,want", KAT)
-def test_philox_known_answers(ctr, key, want):
-    got_np = philox.philox4x32_10(np.array([ctr], dtype=np.uint32), np.array([key], dtype=np.uint32))[0]
+KAT7 = [  # Random123 kat_vectors, philox4x32-7 (seven rounds: the "Crush-resistant" minimum of the Random123 paper)
+    ([0, 0, 0, 0], [0, 0], [0x5f6fb709, 0x0d893f64, 0x4f121f81, 0x4f730a48]),
+    ([0xffffffff] * 4, [0xffffffff] * 2, [0x5207ddc2, 0x45165e59, 0x4d8ee751, 0x8c52f662]),
+    ([0x243f6a88, 0x85a308d3, 0x13198a2e, 0x03707344], [0xa4093822, 0x299f31d0],
+     [0x4dfccaba, 0x190a87f0, 0xc47362ba, 0xb6b5242a]),
+]
+
+
+@pytest.mark.parametrize("rounds,ctr,key,want", [(10,) + k for k in KAT] + [(7,) + k for k in KAT7])
+def test_philox_known_answers(rounds, ctr, key, want):
+    got_np = philox.philox4x32(np.array([ctr], dtype=np.uint32), np.array([key], dtype=np.uint32), rounds)[0]
     assert [int(x) for x in got_np] == want
-    assert lane_model.philox(ctr, key) == want          # the header the kernel compiles
+    assert lane_model.philox(ctr, key, rounds) == want          # the header the kernel compiles
+    assert lane_model.noise_philox_rounds() == philox.NOISE_ROUNDS == 7
 
 
 def test_ema_profile_matches_float64_restatement():
@@ -36,21 +46,58 @@ def test_ema_profile_matches_float64_restatement():
     assert np.abs(applied).max() <= 1.0
 
 
-def test_generator_elementary_functions():
-    """The generator's own sin/cos(2 pi u) and log(u) (no libm: the same instructions on the host and on gfx950)
-    against float64 over the whole input set: every exponent of u down to the smallest value the generator
-    produces ((0 + 0.5) 2^-24), the quadrant boundaries, and a dense random sample."""
+def test_inverse_normal_table_against_scipy():
+    """fpv_normal_from_word (one table row + a cubic, no log / sqrt / division) against the exact inverse CDF in float64:
+    every binade of the tail probability down to the smallest one the generator produces, every table-row boundary from
+    both sides, the words that round up to p = 0.5, both signs, and a dense random sample.  Max |error| 3e-6; the
+    generated header records 2.2e-6."""
     rng = np.random.default_rng(0)
-    k = rng.integers(0, 1 << 24, 20000)
-    u = np.concatenate([(k + 0.5) * 2.0 ** -24, (np.array([0, 1, 2, 3, 255, (1 << 24) - 1]) + 0.5) * 2.0 ** -24,
-                        (np.arange(0, 1 << 24, 1 << 22)[1:] + 0.5) * 2.0 ** -24, (np.arange(0, 1 << 24, 1 << 22)[1:] - 0.5) * 2.0 ** -24,
-                        2.0 ** -np.arange(1, 25) * 1.5]).astype(np.float32)
-    s, c, lg = lane_model.noise_elementary(u)
-    u64 = u.astype(np.float64)
-    assert np.abs(s - np.sin(2 * np.pi * u64)).max() < 2.5e-7
-    assert np.abs(c - np.cos(2 * np.pi * u64)).max() < 2.5e-7
-    assert (np.abs(lg - np.log(u64)) / np.maximum(np.abs(np.log(u64)), 1e-3)).max() < 3e-7
-    assert np.abs(lg - np.log(u64)).max() < 2e-6
+    edges = []
+    for e in range(31):
+        for j in range(4):
+            k0 = int((1 << e) * (1 + j / 4))
+            edges += [k0 - 1, k0, k0 + 1, k0 + 2]
+    edges += [0, 1, 2, 3, (1 << 31) - 1, (1 << 31) - 2, (1 << 31) - 64, (1 << 31) - 65, (1 << 31) - 129]
+    k = np.concatenate([np.array([x for x in edges if 0 <= x < (1 << 31)], dtype=np.uint32),
+                        rng.integers(0, 1 << 31, 200000).astype(np.uint32),
+                        (rng.integers(0, 1 << 31, 50000) >> rng.integers(0, 31, 50000)).astype(np.uint32)])     # every binade well populated
+    for sign in (0, 1):
+        w = k | np.uint32(sign << 31)
+        z, ref = lane_model.normal_from_words(w), philox.normal_from_words(w)
+        assert np.abs(z - ref).max() < 3e-6, np.abs(z - ref).max()
+        assert np.all(np.signbit(z) == bool(sign))
+    # symmetric to the bit, monotone in the tail probability, bounded by the smallest p = 2^-32
+    zp, zm = lane_model.normal_from_words(k), lane_model.normal_from_words(k | np.uint32(1 << 31))
+    assert np.array_equal(zp, -zm)
+    ks = np.sort(np.unique(k | np.uint32(1)))
+    zs = lane_model.normal_from_words(ks).astype(np.float64)
+    assert np.all(np.diff(zs) <= 5e-6), "|z| falls as the tail probability grows (up to the table's own error)"
+    assert 6.22 < float(lane_model.normal_from_words(np.array([0], dtype=np.uint32))[0]) < 6.24      # -Phi^-1(2^-32) = 6.2303
+
+
+def test_noise_profile_statistics():
+    """The statistics that define the profile (noise_smooth_test.py:6-12: x ~ N(0, 1), x_s <- 0.9 x_s + 0.1 x): the
+    driving normals are normal (moments and a Kolmogorov-Smirnov test on 4 x 10^5 draws, independent across channels,
+    drones and steps), the smoothed sticks have zero mean, the stationary sigma sqrt(tau / (2 - tau)) = 0.2294 and lag-1
+    autocorrelation 1 - tau = 0.9."""
+    from scipy import stats
+    p = load_params(fps=1000)
+    n, steps = 400, 1000
+    applied, _ = lane_model.stick_noise(p, n, steps, noise_seed=2024, drone_id_offset=12345)
+    x = applied[300:].astype(np.float64)                               # [T, n, 4], stationary part
+    assert abs(x.mean()) < 3e-3
+    assert abs(x.std() - np.sqrt(0.1 / 1.9)) < 3e-3
+    a, b = x[:-1] - x.mean(), x[1:] - x.mean()
+    assert abs((a * b).mean() / x.var() - 0.9) < 5e-3
+    # the driving normals, recovered from the recurrence: z = (x_s(t) - 0.9 x_s(t-1)) / 0.1 (fp32 sticks: ~1e-6 of noise)
+    z = ((applied[1:].astype(np.float64) - 0.9 * applied[:-1].astype(np.float64)) / 0.1)[:250].reshape(-1)
+    assert z.size == 400000 and abs(z.mean()) < 6e-3 and abs(z.std() - 1) < 5e-3
+    assert abs(stats.skew(z)) < 0.02 and abs(stats.kurtosis(z)) < 0.04
+    assert stats.kstest(z, "norm").pvalue > 1e-3
+    # no correlation between channels, neighbouring drones or consecutive steps of the driving noise
+    zz = ((applied[1:].astype(np.float64) - 0.9 * applied[:-1].astype(np.float64)) / 0.1)
+    for u, v in ((zz[..., 0], zz[..., 1]), (zz[:, :-1, 2], zz[:, 1:, 2]), (zz[:-1, :, 3], zz[1:, :, 3])):
+        assert abs(np.corrcoef(u.reshape(-1), v.reshape(-1))[0, 1]) < 6e-3
 
 
 def test_streams_depend_only_on_global_id_and_step():
@@ -67,17 +114,17 @@ def test_streams_depend_only_on_global_id_and_step():
 
 
 def test_step_index_is_64_bit_and_does_not_wrap():
-    """The Philox counter carries the step index in words 2 AND 3 (ABI 4): the stream continues across 2^32 steps
-    (5.5 h at the k-step kernel's rate) instead of repeating, and is unchanged below 2^32 (ABI <= 3 streams)."""
+    """The Philox counter carries the step index in words 2 AND 3 (since ABI 4): the stream continues across 2^32 steps
+    (5.5 h at the k-step kernel's rate) instead of repeating."""
     p = load_params(fps=1000)
     n, seed, off = 96, 0xfeed_f00d_1234, 7
     ids = off + np.arange(n, dtype=np.uint64)
     edge = (1 << 32) - 3
     # the integer generator itself: counter word 3 = high word of the step
     for step in (edge + 2, 1 << 32, (1 << 32) + 5, (123 << 32) | 77):
-        want = philox.philox4x32_10(np.array([[off & 0xFFFFFFFF, off >> 32, step & 0xFFFFFFFF, step >> 32]], dtype=np.uint32),
-                                    np.array([[seed & 0xFFFFFFFF, seed >> 32]], dtype=np.uint32))[0]
-        assert lane_model.philox([off & 0xFFFFFFFF, off >> 32, step & 0xFFFFFFFF, step >> 32], [seed & 0xFFFFFFFF, seed >> 32]) == [int(x) for x in want]
+        want = philox.philox4x32(np.array([[off & 0xFFFFFFFF, off >> 32, step & 0xFFFFFFFF, step >> 32]], dtype=np.uint32),
+                                 np.array([[seed & 0xFFFFFFFF, seed >> 32]], dtype=np.uint32), 7)[0]
+        assert lane_model.philox([off & 0xFFFFFFFF, off >> 32, step & 0xFFFFFFFF, step >> 32], [seed & 0xFFFFFFFF, seed >> 32], 7) == [int(x) for x in want]
     # six steps across the boundary: host build of the kernel's generator vs the float64 restatement with a 64-bit step
     across, ns = lane_model.stick_noise(p, n, 6, noise_seed=seed, drone_id_offset=off, step0=edge)
     ref, ref_s = philox.ema_sticks(seed, ids, 6, step0=edge)
