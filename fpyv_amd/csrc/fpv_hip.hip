@@ -224,13 +224,15 @@ struct RollOut {
         }
         if (bp) bp += bits_stride;
     }
-    __device__ __forceinline__ void finish(uint32_t i)
+    // `Bf`: the buffers through a view taken AFTER the loop - "are episodes tracked" is then a fresh scalar test instead
+    // of a flag carried across the k steps in an SGPR pair
+    __device__ __forceinline__ void finish(uint32_t i, const FpvBufD& Bf)
     {
-        if (track) {
-            B.ep_return[i] = ep_r; B.ep_length[i] = ep_l;
+        if (Bf.ep_return) {
+            Bf.ep_return[i] = ep_r; Bf.ep_length[i] = ep_l;
             if (had_done) {
-                if (B.last_return) B.last_return[i] = last_r;
-                if (B.last_length) B.last_length[i] = last_l;
+                if (Bf.last_return) Bf.last_return[i] = last_r;
+                if (Bf.last_length) Bf.last_length[i] = last_l;
             }
         }
     }
@@ -294,9 +296,26 @@ __device__ __forceinline__ FpvBufD fpv_step_view(const FpvBufD& B_, float* st, i
 }
 #define FPV_STEP_VIEW const FpvBufD B = fpv_step_view(B_, a_state, a_ld, a_action, a_action_ld, a_state_h)
 
+// The kernel-argument segment of a single-step kernel as ONE struct (the parameters of FPV_STEP_PARAMS in order, each at
+// its natural alignment: exactly how the segment is laid out), and a fresh opaque view of it - what fpv_args_again() is
+// for the k-step kernels.  The instantiations that carry more uniforms than the SGPR file holds (in-kernel noise: the
+// Philox keys and the table staging on top of the physics constants and a dozen buffer pointers; object list + guidance
+// override) read their arguments once per SECTION - loads and sticks / physics / stores - instead of keeping every field
+// alive from the first instruction to the last: 12-34 spilled SGPRs (v_readlane / v_writelane per use) in round 3,
+// none now.  The plain kernel keeps the direct form: it never spilled and is the measured optimum as it stands.
+struct FpvStepArgs { float* state; int64_t ld; const float4* action; int64_t action_ld; uint16_t* state_h; int64_t n; FpvK K; FpvBufD B; };
+__device__ __forceinline__ const FpvStepArgs& fpv_step_args_again()
+{
+    typedef const __attribute__((address_space(4))) FpvStepArgs* P4;
+    P4 p = (P4)__builtin_amdgcn_kernarg_segment_ptr();
+    asm volatile("" : "+s"(p));
+    return *(const FpvStepArgs*)p;
+}
+
 template <bool NOISE = false, bool OBJ = false, bool KAHAN = false, bool OVR = false>
 __global__ __launch_bounds__(kStepBlock) FPV_EXP_STEP_ATTR void fpv_drone_step_kernel(FPV_STEP_PARAMS)
 {
+    constexpr bool SECTIONED = NOISE || (OBJ && OVR);
     FPV_STEP_VIEW;
     __shared__ FpvNormalRow ntab[NOISE ? FPV_NTAB_ROWS : 1];
     if (NOISE) stage_normal_table(ntab);
@@ -306,7 +325,7 @@ __global__ __launch_bounds__(kStepBlock) FPV_EXP_STEP_ATTR void fpv_drone_step_k
     if (i >= n) return;
     FpvDroneState s;
     float ro[9] = {1.f, 0.f, 0.f, 0.f, 1.f, 0.f, 0.f, 0.f, 1.f}, to = 0.0f;
-    // issue every load of this lane before the first use
+    // ---- 1. issue every load of this lane before the first use; the sticks
     float4 a = (!NOISE || B.action) ? ld_action_any(B.action, B.action_ld, i) : make_float4(0.f, 0.f, 0.f, 0.f);
     ld_drone(B.state, B.ld, i, s);
     if (NOISE) a = apply_stick_noise(K, B, i, a, ntab);
@@ -319,29 +338,41 @@ __global__ __launch_bounds__(kStepBlock) FPV_EXP_STEP_ATTR void fpv_drone_step_k
     // this fence the compiler parks the last four row loads behind an s_waitcnt on those constants
     // (+1.4 % per launch, A/B in one process)
     __builtin_amdgcn_sched_barrier(0);
+    // ---- 2. the physics, on its own view of the constants when SECTIONED
+    const FpvStepArgs* P = nullptr;
+    if (SECTIONED) P = &fpv_step_args_again();             // (the opaque view is a volatile asm: not even emitted for the plain kernel)
+    const FpvK& Kp = SECTIONED ? P->K : K;
+    const FpvBufD& Bp = SECTIONED ? P->B : B;
     float kc[6];
     if (KAHAN) {
 #pragma unroll
-        for (int k = 0; k < 6; ++k) kc[k] = row_at(ROW(B.pos_comp, k, B.ld), i);
+        for (int k = 0; k < 6; ++k) kc[k] = row_at(ROW(Bp.pos_comp, k, a_ld), i);
     }
-    const FpvStepOut o = fpv_drone_step_lane<OBJ>(K, s, a.x, a.y, a.z, a.w, B.wx, B.wy, B.wz, &B_.objs,   // the table stays in the kernarg segment (a local copy of an indexed array would live in scratch)
+    const FpvStepOut o = fpv_drone_step_lane<OBJ>(Kp, s, a.x, a.y, a.z, a.w, Bp.wx, Bp.wy, Bp.wz, &B_.objs,   // the table stays in the kernarg segment (a local copy of an indexed array would live in scratch)
                                                   KAHAN ? kc : nullptr, OVR ? ro : nullptr, to);
+    // ---- 3. the stores
     // OBJ: the store addresses are formed only now - the 14 row-address pairs the compiler would otherwise carry from
     // the loads to the stores (28 VGPRs) come on top of the object pass's own registers (102 VGPRs, 4 waves per SIMD);
     // the plain kernel is faster WITH the carried addresses (profiles/r02_exp_state_cache_policy.log) and keeps them
     uint32_t j = i;
-    if (OBJ) FPV_KEEP_HERE(j);
+    if (OBJ || SECTIONED) FPV_KEEP_HERE(j);
+    const FpvStepArgs* E = nullptr;
+    if (SECTIONED) E = &fpv_step_args_again();
+    const FpvK& Ke = SECTIONED ? E->K : K;
+    FpvBufD Bs = B;
+    if (SECTIONED) { Bs = E->B; Bs.state = E->state; Bs.ld = E->ld; }
+    const FpvBufD& Be = Bs;
     if (KAHAN) {
-        const bool rst = (K.flags & FPV_FLAG_AUTO_RESET) && o.done;
+        const bool rst = (Ke.flags & FPV_FLAG_AUTO_RESET) && o.done;
 #pragma unroll
-        for (int k = 0; k < 6; ++k) row_at(ROW(B.pos_comp, k, B.ld), j) = rst ? 0.0f : kc[k];
+        for (int k = 0; k < 6; ++k) row_at(ROW(Be.pos_comp, k, Be.ld), j) = rst ? 0.0f : kc[k];
     }
-    if (B.accel) {
-        row_at(ROW(B.accel, 0, B.ld), j) = o.ax; row_at(ROW(B.accel, 1, B.ld), j) = o.ay; row_at(ROW(B.accel, 2, B.ld), j) = o.az;
+    if (Be.accel) {
+        row_at(ROW(Be.accel, 0, Be.ld), j) = o.ax; row_at(ROW(Be.accel, 1, Be.ld), j) = o.ay; row_at(ROW(Be.accel, 2, Be.ld), j) = o.az;
     }
-    if ((K.flags & FPV_FLAG_AUTO_RESET) && o.done) fpv_drone_reset_lane(K, s);
-    st_drone(B.state, B.ld, j, s);
-    emit_outputs(B, j, true, o.reward, o.done);
+    if ((Ke.flags & FPV_FLAG_AUTO_RESET) && o.done) fpv_drone_reset_lane(Ke, s);
+    st_drone(Be.state, Be.ld, j, s);
+    emit_outputs(Be, j, true, o.reward, o.done);
 }
 
 // ---- k-step kernels: ONE kernel parameter, so that offsets into the kernel-argument segment are offsetof() ----
@@ -427,9 +458,12 @@ __global__ __launch_bounds__(kStepBlock) FPV_EXP_ROLL_ATTR void fpv_drone_rollou
         if (NOISE) {
             // the Philox round keys are uniform and loop-invariant: left alone the compiler keeps all fourteen words
             // in SGPRs for the whole loop; seen through an opaque copy of the seed they are scalar adds per step
-            FpvNoiseK N = V.K.noise;
+            // (with an object list the step's own uniforms fill the SGPR file: the generator then reads its few through a
+            // view of its own instead of pushing two of the physics' into VGPR lanes)
+            const FpvRollArgs& NV = OBJ ? fpv_args_again() : V;
+            FpvNoiseK N = NV.K.noise;
             asm volatile("" : "+s"(N.seed_lo), "+s"(N.seed_hi));
-            fpv_stick_noise(N, V.B.step + (uint64_t)t, (uint64_t)i, ntab, ns, av);
+            fpv_stick_noise(N, NV.B.step + (uint64_t)t, (uint64_t)i, ntab, ns, av);
         }
         FpvStepOut o = fpv_drone_step_lane<OBJ, !QUIET, SQ && QUIET>(V.K, s, av[0], av[1], av[2], av[3], V.B.wx, V.B.wy, V.B.wz,
                                                                        objs, KAHAN ? kc : nullptr);
@@ -497,7 +531,7 @@ __global__ __launch_bounds__(kStepBlock) FPV_EXP_ROLL_ATTR void fpv_drone_rollou
             o = one_step(G, &G.B.objs, ap, G.R.action_stride != 0 && t + 1 < kk, t, std::false_type{});
             out.template step<false>(i, t, o.reward, o.done);
         }
-        out.finish(i);
+        out.finish(i, fpv_args_again().B);
     }
     // ---- 3. the stores: row addresses are formed only now (computed before the loops they would sit in ~30 registers
     //         for all k steps)
@@ -671,7 +705,8 @@ __global__ __launch_bounds__(kStepBlock) void fpv_drone_rollout_h_kernel(const F
             const FpvRollArgs& Z = fpv_args_again();
             fpv_drone_reset_lane(Z.K, s);
         }
-        fpv_pack_half(s, fpv_round_seed(V.B.seed, V.B.step + (uint64_t)t), V.K.noise.id_lo + (uint32_t)i, h);   // the HBM round trip of a single step, in registers
+        const FpvRollArgs& PV = fpv_args_again();             // the rounding's three uniforms, read where they are used
+        fpv_pack_half(s, fpv_round_seed(PV.B.seed, PV.B.step + (uint64_t)t), PV.K.noise.id_lo + (uint32_t)i, h);   // the HBM round trip of a single step, in registers
         if (QUIET || widen) fpv_unpack_half(h, s);
         return o;
     };
@@ -707,18 +742,23 @@ __global__ __launch_bounds__(kStepBlock) void fpv_drone_rollout_h_kernel(const F
             o = one_step(G, ap, G.R.action_stride != 0 && t + 1 < kk, t + 1 < kk, t, std::false_type{});
             out.template step<false>(i0, t, o.reward, o.done, live);
         }
-        if (live) out.finish(i0);
+        // "does this lane own a drone" is a compare, not something to carry across the loop in an SGPR pair (the one
+        // value this kernel used to spill): ask again, through an opaque copy of the index
+        uint32_t jf = i0;
+        asm volatile("" : "+v"(jf));
+        if ((int64_t)jf < G.n) out.finish(jf, fpv_args_again().B);
     }
     const FpvRollArgs& E = fpv_args_again();
     uint32_t j = i0;                             // form the store addresses after the loops (VGPR pressure)
     asm volatile("" : "+v"(j));
-    if (live) {
+    const bool live_e = (int64_t)j < E.n;
+    if (live_e) {
         if (E.B.accel) {
             row_at(ROW(E.B.accel, 0, E.B.ld), j) = o.ax; row_at(ROW(E.B.accel, 1, E.B.ld), j) = o.ay; row_at(ROW(E.B.accel, 2, E.B.ld), j) = o.az;
         }
         st_packed_h(E.B, j, s, h);
     }
-    st_thrust_pair_h(E.B, i0, live, h.t);
+    st_thrust_pair_h(E.B, j, live_e, h.t);
 }
 
 template <bool WIDE, bool PIDV>
@@ -802,7 +842,7 @@ __global__ __launch_bounds__(kStepBlock) void fpv_racer_rollout_kernel(const Fpv
         constexpr bool QUIET = decltype(quiet_c)::value;
         const float4 a = a_next;
         if (QUIET || prefetch) a_next = ld_action(reinterpret_cast<const float4*>(ap_next), i);
-        reward = fpv_racer_step_lane<WIDE, PIDV ? 1 : 0, !QUIET>(V.K, s, a.x, a.y, a.z, a.w);
+        reward = fpv_racer_step_lane<WIDE, PIDV ? 1 : 0, !QUIET, WIDE && !QUIET>(V.K, s, a.x, a.y, a.z, a.w);    // per-axis views where outputs compete for SGPRs
         done = !(fabsf(s.pz) <= V.K.ceiling);              // the Racer has no ground; build-defined ceiling only
         if ((V.K.flags & FPV_FLAG_AUTO_RESET) && done) fpv_racer_reset_lane(s);
     };
@@ -834,7 +874,7 @@ __global__ __launch_bounds__(kStepBlock) void fpv_racer_rollout_kernel(const Fpv
             one_step(G, ap, G.R.action_stride != 0 && t + 1 < kk, std::false_type{});
             out.template step<false>(i, t, reward, done);
         }
-        out.finish(i);
+        out.finish(i, fpv_args_again().B);
     }
     const FpvRollArgs& E = fpv_args_again();
     uint32_t j = i;                                  // form the store addresses after the loops (VGPR pressure)

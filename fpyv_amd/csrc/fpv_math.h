@@ -898,7 +898,26 @@ FPV_HD T fpv_pid_axis(const FpvPidK<T>& P, int i, T actual, T desired, bool firs
 // rounding would add up coherently (6e-5 over 1000 steps).  In float64 only the final rounding of q
 // to fp32 remains, which is incoherent: measured 7e-7 on the reference captures G7/G8 over the whole
 // 1000-step trajectory.  The racer_omega_dt variant (angle = omega*dt) is well conditioned in fp32.
-template <bool WIDE, int PIDV = 0, bool OUT = true>
+// A fresh, opaque view of a uniform object that lives in the kernel-argument segment (device only; `r` MUST be a
+// reference into that segment - the k-step kernels' FpvRollArgs - never a by-value kernel parameter, whose address the
+// compiler could only take by copying it to scratch).  What is read through the result is loaded here, not carried
+// from an earlier load of the same field: it bounds how long a group of uniforms stays in SGPRs.
+#if defined(__HIP_DEVICE_COMPILE__)
+template <class T> __device__ __forceinline__ const T& fpv_uniform_again(const T& r)
+{
+    typedef const __attribute__((address_space(4))) T* P4;
+    P4 p = (P4)(&r);
+    asm volatile("" : "+s"(p));
+    return *(const T*)p;
+}
+#else
+template <class T> static inline const T& fpv_uniform_again(const T& r) { return r; }
+#endif
+
+// VIEWS (k-step kernels only, see fpv_uniform_again): the float64 rate loop reads its constants per AXIS - the as-written
+// Racer carries 45 double-precision uniforms (90 SGPRs), which together with the output pointers of a step that stores
+// reward / done did not fit the SGPR file (10-18 spilled in round 3).
+template <bool WIDE, int PIDV = 0, bool OUT = true, bool VIEWS = false>
 FPV_HD float fpv_racer_step_lane(const FpvK& K, FpvRacerState& s, float a0, float a1, float a2, float a3)
 {
     const float act[3] = {a0, a1, a2};
@@ -907,10 +926,11 @@ FPV_HD float fpv_racer_step_lane(const FpvK& K, FpvRacerState& s, float a0, floa
         double ang[3];
 #pragma unroll
         for (int i = 0; i < 3; ++i) {
+            const FpvPidK<double>& Rd = VIEWS ? fpv_uniform_again(K.rd) : K.rd;
             const double w = (double)s.w[i] + (double)s.wlo[i];
             double integ = (double)s.ierr[i] + (double)s.ilo[i], last = (double)s.lerr[i], df = (double)s.dflt[i];
-            const double tq = fpv_pid_axis<double, PIDV>(K.rd, i, w, (double)act[i], first, integ, last, df);
-            const double wn = fma(tq, K.rd.dt_over_I[i], w);                // :98
+            const double tq = fpv_pid_axis<double, PIDV>(Rd, i, w, (double)act[i], first, integ, last, df);
+            const double wn = fma(tq, Rd.dt_over_I[i], w);                  // :98
             s.ierr[i] = (float)integ; s.ilo[i] = (float)(integ - (double)s.ierr[i]);
             s.lerr[i] = (float)last; s.dflt[i] = (float)df;
             s.w[i] = (float)wn; s.wlo[i] = (float)(wn - (double)s.w[i]);
