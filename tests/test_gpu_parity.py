@@ -1685,6 +1685,102 @@ def test_c_abi_allgather_done_over_rccl(params_1k):
     assert L.fpv_comm_create(ident, 2, 5, 0, C.byref(bad)) == -1 and not bad.value
 
 
+def _two_host_threads_two_handles(params, devices, one_world):
+    """Two host threads in ONE process, a handle and a communicator rank per thread, neither thread ever calling
+    hipSetDevice itself.  one_world: both threads join ONE communicator of world size 2 (needs two GPUs); otherwise each
+    thread has its own one-rank communicator (what a one-GPU box can run: the threading of the C ABI - thread-local error
+    strings, RCCL opened under call_once - and the device guard are the same code)."""
+    import ctypes as C
+    import threading
+    L = _lib.lib()
+    idents = []
+    for _ in range(1 if one_world else 2):
+        ident = (C.c_uint8 * _lib.FPV_COMM_ID_BYTES)()
+        _lib.check(L.fpv_comm_unique_id(ident))
+        idents.append(ident)
+    torch.cuda.set_device(0)
+    n, k = 5000, 16
+    words = (n + 63) // 64
+    out, errors = {}, []
+    p = params.replace(ceiling=10.0005)
+    world = 2 if one_world else 1
+
+    def rank_main(r):
+        try:
+            dev = torch.device("cuda", devices[r])
+            seen = [torch.cuda.current_device()]                      # a fresh thread: device 0 is current, also for rank 1
+            from fpyv_amd.env import DroneBatch
+            env = DroneBatch(p, n, device=dev, with_done_bits=True, auto_reset=True, with_accel=False, drone_id_offset=r * n)
+            env.reset()
+            acts = torch.from_numpy(sticks.ema_noise(k, range(r * n, (r + 1) * n), seed=4)).to(dev)
+            acts[..., 3] = 1.0                                          # full throttle: through the ceiling within a few steps
+            if r == 1:
+                acts[:, ::3, 3] = -0.9                                  # every third drone of rank 1 sinks instead: the ranks' masks differ
+            comm = C.c_void_p()
+            _lib.check(L.fpv_comm_create(idents[0 if one_world else r], world, r if one_world else 0, devices[r], C.byref(comm)))   # collective
+            seen.append(torch.cuda.current_device())
+            ws, rk, ver = C.c_int(-1), C.c_int(-1), C.c_int(-1)
+            _lib.check(L.fpv_comm_info(comm, C.byref(ws), C.byref(rk), C.byref(ver)))
+            bucket = torch.zeros((k, words), dtype=torch.int64, device=dev)
+            dones = torch.zeros((k, n), dtype=torch.uint8, device=dev)
+            env.set_done_bits_target(bucket, stride_words=words)
+            env.rollout(acts, dones=dones)                              # ONE launch on this rank's GPU writes all k mask rows
+            seen.append(torch.cuda.current_device())
+            gathered = torch.full((world, k, words), -1, dtype=torch.int64, device=dev)
+            stream = torch.cuda.current_stream(dev).cuda_stream
+            _lib.check(L.fpv_allgather_done(comm, bucket.data_ptr(), gathered.data_ptr(), k * words, stream))
+            seen.append(torch.cuda.current_device())
+            torch.cuda.synchronize(dev)
+            assert L.fpv_allgather_done(comm, None, gathered.data_ptr(), words, stream) == -1
+            assert b"null argument" in L.fpv_last_error()            # this thread's own message (thread-local)
+            out[r] = dict(bucket=bucket.cpu(), gathered=gathered.cpu(), dones=dones.cpu(), seen=seen, info=(ws.value, rk.value, ver.value),
+                          state_device=env.state.device.index)
+            L.fpv_comm_destroy(comm)
+            seen.append(torch.cuda.current_device())
+        except Exception as e:      # noqa: BLE001
+            errors.append((r, repr(e)))
+
+    threads = [threading.Thread(target=rank_main, args=(r,), daemon=True) for r in range(2)]
+    for t in threads:
+        t.start()
+    for t in threads:
+        t.join(timeout=300)
+    assert not any(t.is_alive() for t in threads), "a rank is stuck in RCCL"
+    assert not errors, errors
+    assert torch.cuda.current_device() == 0
+    whole = torch.stack([out[0]["bucket"], out[1]["bucket"]])
+    for r in range(2):
+        o = out[r]
+        assert o["info"][:2] == ((2, r) if one_world else (1, 0)) and o["info"][2] >= 20000
+        assert o["seen"] == [0, 0, 0, 0, 0], f"rank {r}: an fpv_* call left the caller's current device changed: {o['seen']}"
+        assert o["state_device"] == devices[r]
+        assert torch.equal(o["gathered"], whole if one_world else whole[r:r + 1]), f"rank {r}: gathered masks != concatenation of the ranks' buckets"
+        bits = ((o["bucket"].numpy().view(np.uint64)[:, :, None] >> np.arange(64, dtype=np.uint64)) & np.uint64(1)).reshape(k, -1)[:, :n]
+        assert np.array_equal(bits.astype(np.uint8), o["dones"].numpy()) and bits.any()
+    assert not torch.equal(out[0]["bucket"], out[1]["bucket"])
+
+
+@pytest.mark.skipif(torch.cuda.device_count() < 2,
+                    reason=f"needs two GPUs in one process (this box shows {torch.cuda.device_count()}): wakes up on the driver's multi-GPU node")
+@pytest.mark.timeout(600)
+def test_two_gpus_one_process_two_handles_rccl_world_size_2(params_1k):
+    """VERDICT r3 #8 / SURVEY 8b "one process with 8 handles", at the smallest size that exercises it: a handle and a
+    communicator rank per GPU (devices 0 and 1) driven by two host threads of one process.  Every fpv_* call must bind its
+    handle's device for its own launches and put the caller's back (DeviceGuard, fpv_hip.hip: rank 1's thread has device
+    0 current throughout); fpv_comm_create at world size 2 is this project's first RCCL communicator with more than one
+    rank; fpv_allgather_done ships a [k, words] bucket the k-step kernel filled (one mask row per step) and every rank
+    must receive the concatenation of both ranks' buckets."""
+    _two_host_threads_two_handles(params_1k, devices=[0, 1], one_world=True)
+
+
+@pytest.mark.timeout(600)
+def test_two_host_threads_two_handles_on_one_gpu(params_1k):
+    """The same program with both handles on GPU 0 and a one-rank communicator per thread (RCCL refuses two ranks on one
+    device): what of the two-GPU test a one-GPU box can run - concurrent fpv_* calls from two threads, thread-local error
+    strings, RCCL opened once under call_once, the k-step bucket through fpv_allgather_done."""
+    _two_host_threads_two_handles(params_1k, devices=[0, 0], one_world=False)
+
+
 def test_integration_md_stub_runs_and_lands_on_the_reference(params_1k):
     """The binding INTEGRATION.md shows a reference maintainer (src/utils/hip_drone.py) is executed as
     written: Drone(params dict), reset, 1000 x step with the reference's arguments, against capture G2."""
