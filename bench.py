@@ -846,7 +846,8 @@ def main(argv=None):
             "ms_per_step": elapsed * 1e3 / args.steps,
             "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
             "dtype": "f32", "data": "rehearsal (every rank on GPU 0, gloo): not a measurement" if args.rehearse_on_one_gpu else "synthetic",
-            "state_storage": "f16(v,q,rates,thrust)+f32(p)" if args.fp16_state else "f32",
+            "state_storage": ("eleven 16-bit words per drone: f16 v with 5-bit low words, smallest-three 15-bit fixed-point q, f16 rates and thrust; f32 p"
+                              if args.fp16_state else "f32"),
             "config": {"workload": cfg_name
                        + f"{n} drones/GPU, EMA-noise sticks (noise_smooth_test profile), fp32 math, dt=1ms, "
                        + ("no auto-reset" if args.no_auto_reset else f"in-kernel auto-reset on ground contact or |z|>{args.ceiling:g} m"),

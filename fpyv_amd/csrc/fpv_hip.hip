@@ -208,7 +208,11 @@ struct RollOut {
         const bool last = !QUIET && t == last_t;
         if (bp && (bits_stride || last)) {
             const unsigned long long mask = __ballot(live && done);
-            if ((threadIdx.x & 63) == 0 && live) bp[i >> 6] = mask;      // a wave whose lane 0 owns no drone is wholly dead: no word is its own
+            // a wave whose lane 0 owns no drone is wholly dead: no word is its own.  "Am I lane 0" is asked of an opaque copy of
+            // the index on every call: as a loop-invariant lane mask the answer would sit in an SGPR pair across all k steps
+            uint32_t ii = i;
+            asm volatile("" : "+v"(ii));
+            if ((ii & 63u) == 0 && live) bp[ii >> 6] = mask;
         }
         if (!QUIET) {
             if ((out_stride || last) && live) {
@@ -600,10 +604,11 @@ __global__ __launch_bounds__(kStepBlock) void fpv_drone_step_aos_kernel(FPV_STEP
     }
 }
 
-// fp16-storage variant (BASELINE config 4): position rows fp32; the 11 other values of a drone are
-// binary16, stored as FIVE rows of half2 pairs - (vx,vy) (vz,qw) (qx,qy) (qz,rx) (ry,rz) - plus one row
-// of single halves for prev_thrust: 3*4 + 5*4 + 2 = 34 state bytes each way, 89 algorithmic bytes per
-// env-step instead of 133.  One lane = one drone still moves nothing narrower than a dword
+// fp16-storage variant (BASELINE config 4): position rows fp32; the rest of a drone is ELEVEN 16-bit words, stored as
+// FIVE rows of word pairs - (vx,vy) (vz,v_low) (qa,qb) (qc,rx) (ry,rz) - plus one row of single halves for prev_thrust:
+// 3*4 + 5*4 + 2 = 34 state bytes each way, 89 algorithmic bytes per env-step instead of 133.  v, rates and
+// thrust are binary16 (v with a 5-bit low word per component in v_low), q is smallest-three 15-bit fixed point: the
+// encoding is fpv_pack_half / fpv_unpack_half (fpv_math.h).  One lane = one drone still moves nothing narrower than a dword
 // (two-byte accesses waste the memory pipeline: with 11 separate half rows this kernel ran slower than
 // the fp32 one): the even/odd lanes of a drone pair read the SAME dword of the thrust row, and on the
 // way out the even lane fetches its neighbour's half with one DPP quad-permute and stores the dword.
@@ -946,8 +951,9 @@ __global__ __launch_bounds__(kBlock) void fpv_return_triple_kernel(const float* 
 }
 
 // fp16 state storage -> the 14 fp32 rows of the state (fpv_abi.h row numbering) for whoever reads the state on the host
-// side of the boundary (an observation, a log): the position rows copied, every stored half WIDENED AS IT IS (no
-// renormalisation of the quaternion: this is what is stored).  One launch instead of a dozen tensor operations.
+// side of the boundary (an observation, a log): the position rows copied, the eleven 16-bit words decoded exactly as the
+// step kernel decodes them (fpv_unpack_half: v with its low words, q rebuilt from its three stored components).  One
+// launch instead of a dozen tensor operations.
 __global__ __launch_bounds__(kBlock) void fpv_widen_state_kernel(const float* __restrict__ pos, const uint16_t* __restrict__ sh16,
                                                                  const int64_t ld, float* __restrict__ out, const int64_t out_ld,
                                                                  const int64_t n)
@@ -955,15 +961,17 @@ __global__ __launch_bounds__(kBlock) void fpv_widen_state_kernel(const float* __
     const int64_t i = (int64_t)blockIdx.x * kBlock + threadIdx.x;
     if (i >= n) return;
     const uint32_t* __restrict__ sh = reinterpret_cast<const uint32_t*>(sh16);
+    FpvHalfState h;
+#pragma unroll
+    for (int k = 0; k < FPV_HALF_PAIR_ROWS; ++k) h.w[k] = sh[(int64_t)k * ld + i];
+    h.t = sh16[(int64_t)2 * FPV_HALF_PAIR_ROWS * ld + i];
+    FpvDroneState s;
+    fpv_unpack_half(h, s);
 #pragma unroll
     for (int k = 0; k < 3; ++k) out[(int64_t)k * out_ld + i] = pos[(int64_t)k * ld + i];
+    const float v[11] = {s.vx, s.vy, s.vz, s.q.w, s.q.x, s.q.y, s.q.z, s.rx, s.ry, s.rz, s.thrust};
 #pragma unroll
-    for (int k = 0; k < FPV_HALF_PAIR_ROWS; ++k) {
-        const uint32_t w = sh[(int64_t)k * ld + i];
-        out[(int64_t)(3 + 2 * k) * out_ld + i] = fpv_f16_to_f32((uint16_t)w);
-        out[(int64_t)(4 + 2 * k) * out_ld + i] = fpv_f16_to_f32((uint16_t)(w >> 16));
-    }
-    out[(int64_t)FPV_THRUST * out_ld + i] = fpv_f16_to_f32(sh16[(int64_t)2 * FPV_HALF_PAIR_ROWS * ld + i]);
+    for (int k = 0; k < 11; ++k) out[(int64_t)(3 + k) * out_ld + i] = v[k];
 }
 
 // components.PID.__call__ for n drones (components.py:43-54): one lane per drone, four state rows.

@@ -378,38 +378,87 @@ FPV_HD uint32_t fpv_round_seed(uint32_t base, uint64_t step)
     return base + (uint32_t)step + (uint32_t)(step >> 32) * 0x9e3779b1u;
 }
 
-// The 11 binary16 values of one drone in storage order: FIVE half2 words (low half first) - (vx,vy) (vz,qw) (qx,qy)
-// (qz,rx) (ry,rz) - and the prev_thrust half, which lives in a row of single halves (89 state+io bytes per env-step,
-// SURVEY 8d) and is moved separately.
+// The 11 sixteen-bit words of one drone in storage order - FIVE pair words (low word first) and one single word that
+// lives in a row of its own (89 state+io bytes per env-step):
+//   w[0] = (vx, vy)  w[1] = (vz, v_low)  w[2] = (qa, qb)  w[3] = (qc, rx)  w[4] = (ry, rz)   t = prev_thrust
+// Round 4 spends the same 22 bytes better (round 3: eleven binary16 values, |dq| 6e-3 and |dp|/|p| 8e-3 after 1000 steps -
+// both pure random walks of the stochastic rounding of v and q, ulp x sqrt(steps / 6)):
+//   * v: binary16 (round toward zero of the stochastically rounded value) PLUS a 5-bit low word per component - the next
+//     five mantissa bits, three of them packed into v_low: 15 mantissa bits instead of 10, a 32 times finer grid;
+//   * q: SMALLEST THREE.  The component of largest magnitude is dropped (|q| = 1 gives it back, and it is >= 1/2, so the
+//     reconstruction is well conditioned), the other three - each <= 1/sqrt(2) in magnitude - are stored as 15-bit
+//     fixed point (grid 4.3e-5, eleven times finer than binary16 near 0.7), stochastically rounded; the 2-bit index of the
+//     dropped component sits in the spare top bits of qa and qb.  q and -q are the same attitude: the stored sign makes
+//     the dropped component positive.
+//   * rates and thrust are low-pass states: binary16, round to nearest even, as before.
 struct FpvHalfState { uint32_t w[5]; uint16_t t; };
+
+#define FPV_Q3_SCALE 23168.0f            // 15-bit fixed point: 0.70710678 * 23168 = 16382.3 < 2^14
+#define FPV_Q3_INV_SCALE 4.31629834e-05f // 1 / 23168
+
+// floor(x) as int32 (v_cvt_flr_i32_f32 on the device)
+FPV_HD int32_t fpv_floor_i32(float x)
+{
+#if defined(__HIP_DEVICE_COMPILE__)
+    return __float2int_rd(x);
+#else
+    return (int32_t)floorf(x);
+#endif
+}
 
 FPV_HD void fpv_unpack_half(const FpvHalfState& h, FpvDroneState& s)
 {
-    s.vx = fpv_f16_to_f32((uint16_t)h.w[0]); s.vy = fpv_f16_to_f32((uint16_t)(h.w[0] >> 16));
-    s.vz = fpv_f16_to_f32((uint16_t)h.w[1]); s.q.w = fpv_f16_to_f32((uint16_t)(h.w[1] >> 16));
-    s.q.x = fpv_f16_to_f32((uint16_t)h.w[2]); s.q.y = fpv_f16_to_f32((uint16_t)(h.w[2] >> 16));
-    s.q.z = fpv_f16_to_f32((uint16_t)h.w[3]); s.rx = fpv_f16_to_f32((uint16_t)(h.w[3] >> 16));
+    const uint32_t ext = h.w[1] >> 16;                       // three 5-bit low words of v
+    s.vx = fpv_bits_f32(fpv_f32_bits(fpv_f16_to_f32((uint16_t)h.w[0])) | ((ext & 31u) << 8));
+    s.vy = fpv_bits_f32(fpv_f32_bits(fpv_f16_to_f32((uint16_t)(h.w[0] >> 16))) | (((ext >> 5) & 31u) << 8));
+    s.vz = fpv_bits_f32(fpv_f32_bits(fpv_f16_to_f32((uint16_t)h.w[1])) | (((ext >> 10) & 31u) << 8));
+    // 15-bit two's complement fields -> the three stored components
+    const float a = (float)((int32_t)(h.w[2] << 17) >> 17) * FPV_Q3_INV_SCALE;
+    const float b = (float)((int32_t)(h.w[2] << 1) >> 17) * FPV_Q3_INV_SCALE;
+    const float c = (float)((int32_t)(h.w[3] << 17) >> 17) * FPV_Q3_INV_SCALE;
+    const uint32_t idx = ((h.w[2] >> 15) & 1u) | ((h.w[2] >> 30) & 2u);
+    const float d = fpv_sqrt_flushed(fmaxf(fmaf(-a, a, fmaf(-b, b, fmaf(-c, c, 1.0f))), 0.0f));
+    s.q.w = idx == 0u ? d : a;
+    s.q.x = idx == 0u ? a : (idx == 1u ? d : b);
+    s.q.y = idx <= 1u ? b : (idx == 2u ? d : c);
+    s.q.z = idx == 3u ? d : c;
+    s.rx = fpv_f16_to_f32((uint16_t)(h.w[3] >> 16));
     s.ry = fpv_f16_to_f32((uint16_t)h.w[4]); s.rz = fpv_f16_to_f32((uint16_t)(h.w[4] >> 16));
     s.thrust = fpv_f16_to_f32(h.t);
-    // a stored quaternion is unit only to ~1e-3; the fp32 integrator wants |q| = 1.
-    // 1/sqrt(1+e) = 1 - e/2 + 3e^2/8 (the next term, 5e^3/16, is 2.5e-9 at |e| = 2e-3: below fp32 rounding)
-    const float e = fmaf(s.q.w, s.q.w, fmaf(s.q.x, s.q.x, fmaf(s.q.y, s.q.y, fmaf(s.q.z, s.q.z, -1.0f))));
-    const float k = fmaf(0.375f, e, -0.5f) * e;
-    s.q.w = fmaf(k, s.q.w, s.q.w); s.q.x = fmaf(k, s.q.x, s.q.x); s.q.y = fmaf(k, s.q.y, s.q.y); s.q.z = fmaf(k, s.q.z, s.q.z);
+}
+
+// one stored quaternion component: floor(a * 2^8 * scale + 8 random bits) >> 8 = stochastic rounding of a * scale to an integer
+FPV_HD uint32_t fpv_q3_field(float a, uint32_t rnd8)
+{
+    const int32_t n = fpv_floor_i32(fmaf(a, FPV_Q3_SCALE * 256.0f, (float)rnd8)) >> 8;
+    return (uint32_t)n & 0x7fffu;
 }
 
 FPV_HD void fpv_pack_half(const FpvDroneState& s, uint32_t seed, uint32_t drone, FpvHalfState& h)
 {
-    // one full-avalanche hash of (seed, drone); the second and third word by one multiply-xorshift each (bijections of
-    // a uniform word: uniform again) - round 2 ran the full hash three times: six quarter-rate multiplies per lane
+    // one full-avalanche hash of (seed, drone); the second word by one multiply-xorshift (a bijection of a uniform word:
+    // uniform again): 6 x 8 random bits are needed
     const uint32_t r0 = fpv_mix32(seed * 0x9e3779b9u + drone);
     uint32_t r1 = r0 * 0x9e3779b1u; r1 ^= r1 >> 15;
-    uint32_t r2 = r1 * 0x85ebca77u; r2 ^= r2 >> 13;
-    const uint32_t f6 = (((r0 >> 26) | ((r1 >> 20) & 0xfc0u)) << 1) | 1u;         // 12 bits, centred on the 13-bit grid
-    h.w[0] = fpv_pack_pair_rtz(fpv_sr_arg(s.vx, r0 & 0x1fffu), fpv_sr_arg(s.vy, (r0 >> 13) & 0x1fffu));
-    h.w[1] = fpv_pack_pair_rtz(fpv_sr_arg(s.vz, r1 & 0x1fffu), fpv_sr_arg(s.q.w, (r1 >> 13) & 0x1fffu));
-    h.w[2] = fpv_pack_pair_rtz(fpv_sr_arg(s.q.x, r2 & 0x1fffu), fpv_sr_arg(s.q.y, (r2 >> 13) & 0x1fffu));
-    h.w[3] = fpv_pack_pair_rtz(fpv_sr_arg(s.q.z, f6), 0.0f) | ((uint32_t)fpv_f32_to_f16_rn(s.rx) << 16);
+    // v: 8 random bits below the 15 kept mantissa bits, then truncation (round toward zero in both parts)
+    const uint32_t bx = fpv_f32_bits(s.vx) + (r0 & 0xffu), by = fpv_f32_bits(s.vy) + ((r0 >> 8) & 0xffu);
+    const uint32_t bz = fpv_f32_bits(s.vz) + ((r0 >> 16) & 0xffu);
+    const uint32_t ext = ((bx >> 8) & 31u) | (((by >> 8) & 31u) << 5) | (((bz >> 8) & 31u) << 10);
+    h.w[0] = fpv_pack_pair_rtz(fpv_bits_f32(bx), fpv_bits_f32(by));
+    h.w[1] = fpv_pack_pair_rtz(fpv_bits_f32(bz), 0.0f) | (ext << 16);
+    // q: drop the component of largest magnitude, make it positive
+    const float aw = fabsf(s.q.w), ax = fabsf(s.q.x), ay = fabsf(s.q.y), az = fabsf(s.q.z);
+    const bool b01 = ax > aw, b23 = az > ay;
+    const float m01 = b01 ? ax : aw, m23 = b23 ? az : ay;
+    const bool top = m23 > m01;
+    const uint32_t idx = top ? (b23 ? 3u : 2u) : (b01 ? 1u : 0u);
+    const float big = top ? (b23 ? s.q.z : s.q.y) : (b01 ? s.q.x : s.q.w);
+    const uint32_t flip = fpv_f32_bits(big) & 0x80000000u;
+    const float qa = fpv_bits_f32(fpv_f32_bits(idx == 0u ? s.q.x : s.q.w) ^ flip);
+    const float qb = fpv_bits_f32(fpv_f32_bits(idx <= 1u ? s.q.y : s.q.x) ^ flip);
+    const float qc = fpv_bits_f32(fpv_f32_bits(idx <= 2u ? s.q.z : s.q.y) ^ flip);
+    h.w[2] = fpv_q3_field(qa, r0 >> 24) | ((idx & 1u) << 15) | (fpv_q3_field(qb, r1 & 0xffu) << 16) | ((idx & 2u) << 30);
+    h.w[3] = fpv_q3_field(qc, (r1 >> 8) & 0xffu) | ((uint32_t)fpv_f32_to_f16_rn(s.rx) << 16);
     h.w[4] = (uint32_t)fpv_f32_to_f16_rn(s.ry) | ((uint32_t)fpv_f32_to_f16_rn(s.rz) << 16);
     h.t = fpv_f32_to_f16_rn(s.thrust);
 }

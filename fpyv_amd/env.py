@@ -62,8 +62,9 @@ class _Batch:
         _lib.check(self._L.fpv_create(C.byref(self._cparams), self.n, dev_index, C.byref(self._handle)))
         f32 = dict(dtype=torch.float32, device=self.device)
         if self.fp16_state:
-            # BASELINE config 4: position rows fp32; v, q, rates, thrust as binary16: five rows of half2 pairs
-            # (vx,vy) (vz,qw) (qx,qy) (qz,rx) (ry,rz) and one row of thrust halves: 89 B per env-step
+            # BASELINE config 4: position rows fp32; the rest as eleven 16-bit words: five rows of word pairs
+            # (vx,vy) (vz,v_low) (qa,qb) (qc,rx) (ry,rz) and one row of thrust halves: 89 B per env-step
+            # (v, rates, thrust binary16 - v with 5-bit low words -, q smallest-three fixed point: csrc/fpv_math.h)
             self.state = torch.zeros((3, self.ld), **f32)
             self.state_h = torch.zeros(_lib.FPV_HALF_HALVES * self.ld, dtype=torch.float16, device=self.device)
         else:
@@ -131,12 +132,15 @@ class _Batch:
         _lib.check(self._L.fpv_widen_state(self._handle, self._buf_ref, wide.data_ptr(), self.ld, self._stream()))
         return wide[r0:r1, :self.n].t()
 
-    def half_rows(self) -> torch.Tensor:
-        """[11, ld] binary16 values of the fp16 storage, row r-3 = state value r (vx .. thrust): a copy
-        assembled from the five half2 pair rows and the thrust row of `state_h`."""
+    def storage_words(self) -> torch.Tensor:
+        """[11, ld] int16: the eleven 16-bit storage words of every drone of an fp16-state batch in storage order - vx vy vz
+        (binary16), v_low (three 5-bit low words), qa qb qc (smallest-three 15-bit fixed point + index bits), rx ry rz
+        thrust (binary16) - a copy assembled from the five pair rows and the thrust row of `state_h`.  The decoded fp32
+        values are `rows_f32` (one launch of fpv_widen_state)."""
         ld, npair = self.ld, _lib.FPV_HALF_PAIR_ROWS
-        pairs = self.state_h[:2 * npair * ld].view(npair, ld, 2).permute(0, 2, 1).reshape(2 * npair, ld)
-        return torch.cat([pairs, self.state_h[2 * npair * ld:].view(1, ld)], dim=0)
+        raw = self.state_h.view(torch.int16)
+        pairs = raw[:2 * npair * ld].view(npair, ld, 2).permute(0, 2, 1).reshape(2 * npair, ld)
+        return torch.cat([pairs, raw[2 * npair * ld:].view(1, ld)], dim=0)
 
     def algorithmic_bytes(self) -> int:
         return int(self._L.fpv_handle_algorithmic_bytes(self._handle))

@@ -179,6 +179,39 @@ extern "C" void fpvl_pack_state(const float st[14], uint32_t seed, uint32_t dron
     out[5] = h.t;
 }
 
+// a whole [14][ld] fp32 state <-> the storage of the fp16 kernels (pos [3][ld] fp32 + sh: five pair rows of uint32 and the
+// row of thrust halves), drone i packed with rounding seed `seed` and global id id0 + i: what fpv_reset_kernel leaves behind
+extern "C" void fpvl_pack_rows(const float* st, int64_t ld, int64_t n, uint32_t seed, uint32_t id0, float* pos, uint32_t* sh)
+{
+    uint16_t* thrust = reinterpret_cast<uint16_t*>(sh + FPV_HALF_PAIR_ROWS * ld);
+    for (int64_t i = 0; i < n; ++i) {
+        FpvDroneState s;
+        s.px = st[0 * ld + i]; s.py = st[1 * ld + i]; s.pz = st[2 * ld + i]; s.vx = st[3 * ld + i]; s.vy = st[4 * ld + i]; s.vz = st[5 * ld + i];
+        s.q.w = st[6 * ld + i]; s.q.x = st[7 * ld + i]; s.q.y = st[8 * ld + i]; s.q.z = st[9 * ld + i];
+        s.rx = st[10 * ld + i]; s.ry = st[11 * ld + i]; s.rz = st[12 * ld + i]; s.thrust = st[13 * ld + i];
+        FpvHalfState h;
+        fpv_pack_half(s, seed, id0 + (uint32_t)i, h);
+        pos[0 * ld + i] = s.px; pos[1 * ld + i] = s.py; pos[2 * ld + i] = s.pz;
+        for (int k = 0; k < FPV_HALF_PAIR_ROWS; ++k) sh[k * ld + i] = h.w[k];
+        thrust[i] = h.t;
+    }
+}
+extern "C" void fpvl_unpack_rows(const float* pos, const uint32_t* sh, int64_t ld, int64_t n, float* st)
+{
+    const uint16_t* thrust = reinterpret_cast<const uint16_t*>(sh + FPV_HALF_PAIR_ROWS * ld);
+    for (int64_t i = 0; i < n; ++i) {
+        FpvHalfState h;
+        for (int k = 0; k < FPV_HALF_PAIR_ROWS; ++k) h.w[k] = sh[k * ld + i];
+        h.t = thrust[i];
+        FpvDroneState s;
+        fpv_unpack_half(h, s);
+        st[0 * ld + i] = pos[0 * ld + i]; st[1 * ld + i] = pos[1 * ld + i]; st[2 * ld + i] = pos[2 * ld + i];
+        st[3 * ld + i] = s.vx; st[4 * ld + i] = s.vy; st[5 * ld + i] = s.vz;
+        st[6 * ld + i] = s.q.w; st[7 * ld + i] = s.q.x; st[8 * ld + i] = s.q.y; st[9 * ld + i] = s.q.z;
+        st[10 * ld + i] = s.rx; st[11 * ld + i] = s.ry; st[12 * ld + i] = s.rz; st[13 * ld + i] = s.thrust;
+    }
+}
+
 // stick-noise generator on the host: ns [4][ld] EMA state advanced `steps` times from step index
 // step0; applied [steps][n][4] receives clip(base + gain * x_s) (base = 0 when base_actions is NULL)
 extern "C" int fpvl_stick_noise(const fpv_params_t* P, int64_t n, int steps, float* ns, int64_t ld,

@@ -208,22 +208,35 @@ def pack_state(state14, seed: int, drone: int) -> np.ndarray:
     return out
 
 
-def split_half(state: np.ndarray):
-    """[14, ld] fp32 SoA -> (pos [3, ld] fp32, sh [11 * ld] uint16) with round-to-nearest halves (a freshly
-    reset state is exactly representable, so the rounding mode does not matter)."""
-    ld = state.shape[1]
-    h = state[3:14].astype(np.float16)                     # value r-3 = row: vx vy vz qw qx qy qz rx ry rz thrust
-    pairs = np.ascontiguousarray(h[:10].reshape(5, 2, ld).transpose(0, 2, 1))      # [5, ld, 2]
-    sh = np.concatenate([pairs.reshape(-1), h[10]]).view(np.uint16)
-    return np.ascontiguousarray(state[0:3]), np.ascontiguousarray(sh)
+def split_half(state: np.ndarray, seed: int = 0, drone_id_offset: int = 0):
+    """[14, ld] fp32 SoA -> (pos [3, ld] fp32, sh [11 * ld] uint16): the storage of the fp16 kernels (five pair rows, then the
+    thrust row) as fpv_pack_half writes it with rounding seed `seed` and global ids drone_id_offset + i - what
+    fpv_reset_kernel leaves behind for rounding_seed = seed (the reset attitude (1, 0, 0, 0) and a zero velocity are exact
+    in the format; a general reset pose is rounded stochastically, hence the seed)."""
+    L = lib()
+    L.fpvl_pack_rows.argtypes = [C.POINTER(C.c_float), C.c_int64, C.c_int64, C.c_uint32, C.c_uint32, C.POINTER(C.c_float), C.c_void_p]
+    st = np.ascontiguousarray(state, dtype=np.float32)
+    ld = st.shape[1]
+    pos = np.zeros((3, ld), dtype=np.float32)
+    sh = np.zeros(abi.FPV_HALF_HALVES * ld, dtype=np.uint16)
+    fp = lambda a: a.ctypes.data_as(C.POINTER(C.c_float))  # noqa: E731
+    L.fpvl_pack_rows(fp(st), ld, ld, int(seed) & 0xFFFFFFFF, int(drone_id_offset) & 0xFFFFFFFF, fp(pos), sh.ctypes.data)
+    return pos, sh
 
 
 def join_half(pos: np.ndarray, sh: np.ndarray) -> np.ndarray:
-    """inverse of split_half: -> [14, ld] fp32"""
+    """(pos [3, ld], sh [11 * ld] uint16) -> [14, ld] fp32: the state as the fp16 kernels read it (fpv_unpack_half: v with
+    its low words, q rebuilt from its three stored components)."""
+    L = lib()
+    L.fpvl_unpack_rows.argtypes = [C.POINTER(C.c_float), C.c_void_p, C.c_int64, C.c_int64, C.POINTER(C.c_float)]
+    pos = np.ascontiguousarray(pos, dtype=np.float32)
     ld = pos.shape[1]
-    sh = np.asarray(sh).reshape(-1).view(np.float16)
-    pairs = sh[:10 * ld].reshape(5, ld, 2).transpose(0, 2, 1).reshape(10, ld)
-    return np.concatenate([pos, pairs.astype(np.float32), sh[10 * ld:11 * ld].astype(np.float32)[None]], axis=0)
+    sh = np.ascontiguousarray(np.asarray(sh).reshape(-1).view(np.uint16))
+    assert sh.size == abi.FPV_HALF_HALVES * ld
+    st = np.zeros((14, ld), dtype=np.float32)
+    fp = lambda a: a.ctypes.data_as(C.POINTER(C.c_float))  # noqa: E731
+    L.fpvl_unpack_rows(fp(pos), sh.ctypes.data, ld, ld, fp(st))
+    return st
 
 
 def stick_noise(p, n: int, steps: int, noise_seed: int = 0, drone_id_offset: int = 0, base_actions=None,

@@ -155,10 +155,11 @@ def test_return_triple_kernel_equals_host_build_and_torch_form(params_1k):
     assert out[2] is None and out[0].shape == (8, 3, 3)
 
 
-def test_fp16_state_widened_by_one_kernel_equals_the_tensor_form(params_1k):
-    """fpv_widen_state (what rows_f32 / position / velocity / quaternion / FpvVecEnv.obs read for fp16 storage): every
-    stored half widened as it is, position rows copied - bit for bit what half_rows() assembles with tensor operations,
-    at a ragged size, after a flight."""
+def test_fp16_state_widened_by_one_kernel_equals_the_host_decoder(params_1k):
+    """fpv_widen_state (what rows_f32 / position / velocity / quaternion / FpvVecEnv.obs read for fp16 storage): the eleven
+    16-bit words of every drone decoded exactly as the step kernel decodes them - bit for bit the host build of
+    fpv_unpack_half on the same storage words (v with its 5-bit low words, q rebuilt from its three stored components),
+    position rows copied - at a ragged size, after a flight."""
     from fpyv_amd.env import FpvVecEnv
     n = 4099
     env = _drone_batch(params_1k, n, fp16_state=True, with_accel=False)
@@ -166,14 +167,22 @@ def test_fp16_state_widened_by_one_kernel_equals_the_tensor_form(params_1k):
     a = torch.from_numpy(sticks.ema_noise(50, range(n), seed=4)).to(DEV)
     env.rollout(a)
     got = env.rows_f32(0, 14)                                   # [n, 14]
-    want = torch.cat([env.state[:3, :n], env.half_rows()[:, :n].float()], dim=0).t()
-    assert got.shape == (n, 14) and torch.equal(got, want)
-    assert torch.equal(env.quaternion, want[:, 6:10]) and torch.equal(env.position, want[:, 0:3]) and torch.equal(env.prev_thrust, want[:, 13])
+    torch.cuda.synchronize()
+    want = lane_model.join_half(env.state.cpu().numpy(), env.state_h.cpu().numpy().view(np.uint16))[:, :n].T
+    assert got.shape == (n, 14) and np.array_equal(got.cpu().numpy().view(np.uint32), np.ascontiguousarray(want).view(np.uint32))
+    wt = torch.from_numpy(np.ascontiguousarray(want)).to(DEV)
+    assert torch.equal(env.quaternion, wt[:, 6:10]) and torch.equal(env.position, wt[:, 0:3]) and torch.equal(env.prev_thrust, wt[:, 13])
+    assert float((env.quaternion.norm(dim=1) - 1).abs().max()) < 1e-6, "a stored attitude decodes to a unit quaternion"
+    words = env.storage_words()
+    assert words.shape == (11, env.ld) and words.dtype == torch.int16
+    assert torch.equal(words[0, :n].view(torch.float16).float(), (got[:, 3].view(torch.int32) & ~0x1fff).view(torch.float32)), "vx: its binary16 part is the top of the decoded value"
     ve = FpvVecEnv(params_1k, num_envs=64, device=DEV, fp16_state=True)
     o0 = ve.reset()
     o1, r, d, info = ve.step(a[0, :64].contiguous())
     assert o1.shape == (64, 13) and o1.data_ptr() != o0.data_ptr() and bool(torch.isfinite(o1).all())
-    assert torch.equal(o1, torch.cat([ve.batch.state[:3, :64], ve.batch.half_rows()[:10, :64].float()], dim=0).t())
+    torch.cuda.synchronize()
+    w64 = lane_model.join_half(ve.batch.state.cpu().numpy(), ve.batch.state_h.cpu().numpy().view(np.uint16))[:13, :64].T
+    assert np.array_equal(o1.cpu().numpy(), w64)
 
 
 def test_default_fps60(params_60):
@@ -734,11 +743,11 @@ def test_fp16_state_bitwise_vs_lane_model_and_restated_tolerance(params_1k):
     acts = g["actions"]
     T, n = acts.shape[:2]
     env = _drone_batch(params_1k, n, fp16_state=True, rounding_seed=5, with_accel=False)
-    assert env.algorithmic_bytes() == 89 and env.state.shape[0] == 3 and env.state_h.dtype == torch.float16
+    assert env.algorithmic_bytes() == 89 and env.state.shape[0] == 3 and env.state_h.dtype == torch.float16 and env.state_h.numel() == 11 * env.ld
     env.reset()
     env.rollout(torch.from_numpy(acts).to(DEV))
     torch.cuda.synchronize()
-    pos, sh = lane_model.split_half(lane_model.initial_state(params_1k, n))
+    pos, sh = lane_model.split_half(lane_model.initial_state(params_1k, n), seed=5)
     lane_model.run_h(params_1k, pos, sh, acts, seed0=5)
     assert np.array_equal(env.state.cpu().numpy()[:, :n].view(np.uint32), pos[:, :n].view(np.uint32))
     ld, lm = env.ld, pos.shape[1]              # the batch pads its row stride, the lane model does not
@@ -751,7 +760,7 @@ def test_fp16_state_bitwise_vs_lane_model_and_restated_tolerance(params_1k):
     err = soa_vs_oracle(got, ref, n)
     for k, tol in FP16_TOL.items():
         assert err[k] <= tol, (k, err[k])
-    np.testing.assert_allclose(env.velocity.cpu().numpy(), ref[:, 3:6], rtol=5e-2, atol=5e-2)
+    np.testing.assert_allclose(env.velocity.cpu().numpy(), ref[:, 3:6], rtol=3e-2, atol=4e-2)      # per component (attitude error x thrust); the norm-based bound is vel_rel above
 
 
 @pytest.mark.parametrize("n", [1, 63, 333, 4099])
@@ -774,7 +783,7 @@ def test_fp16_state_ragged_sizes_vs_lane_model_and_oracle(params_1k, n, fused):
         for t in range(steps):
             env.step(a[t], return_imu=False)               # fpv_step: fpv_drone_step_h_kernel
     torch.cuda.synchronize()
-    pos, sh = lane_model.split_half(lane_model.initial_state(params_1k, n))
+    pos, sh = lane_model.split_half(lane_model.initial_state(params_1k, n), seed=17)
     done, rew = lane_model.run_h(params_1k, pos, sh, acts, seed0=17)
     ld, lm = env.ld, pos.shape[1]
     got_h = env.state_h.cpu().numpy().view(np.uint16)
@@ -846,7 +855,7 @@ def test_fp16_state_is_shard_invariant(params_1k, fused):
         part = run(lo, hi)
         assert np.array_equal(part[0].view(np.uint32), whole[0][:, lo:hi].view(np.uint32)), (lo, hi)
         assert np.array_equal(part[1], whole[1][:, lo:hi]) and np.array_equal(part[2], whole[2][lo:hi]), (lo, hi)
-    pos, sh = lane_model.split_half(lane_model.initial_state(params_1k, 77))
+    pos, sh = lane_model.split_half(lane_model.initial_state(params_1k, 77), seed=3, drone_id_offset=1000)
     lane_model.run_h(params_1k, pos, sh, acts[:, 1000:1077], seed0=3, drone_id_offset=1000)
     assert np.array_equal(whole[0][:, 1000:1077].view(np.uint32), pos[:, :77].view(np.uint32)), "and the host build agrees on the keyed stream"
 
@@ -866,9 +875,11 @@ def test_fp16_state_full_size_vs_fp32_run():
     dp = (e16.position - e32.position).norm(dim=1) / e32.position.norm(dim=1)
     q16, q32 = e16.quaternion, e32.quaternion
     dq = (q16 * torch.sign((q16 * q32).sum(dim=1, keepdim=True)) - q32).abs().amax(dim=1)
-    assert float(dp.max()) < 2e-2 and float(dp.mean()) < 2e-3, (float(dp.max()), float(dp.mean()))
-    assert float(dq.max()) < 3e-2 and float(dq.mean()) < 3e-3, (float(dq.max()), float(dq.mean()))
-    assert bool(torch.isfinite(e16.state_h.float()).all())
+    # round 3 (eleven binary16 values): max 2e-2 / mean 2e-3 for p, max 3e-2 / mean 3e-3 for q were the asserted bounds; with
+    # 15 mantissa bits for v and the smallest-three quaternion the same 22 bytes hold these, over 2^20 drones
+    assert float(dp.max()) < 5e-3 and float(dp.mean()) < 5e-4, (float(dp.max()), float(dp.mean()))
+    assert float(dq.max()) < 8e-3 and float(dq.mean()) < 8e-4, (float(dq.max()), float(dq.mean()))
+    assert bool(torch.isfinite(e16.rows_f32(0, 14)).all())
 
 
 @pytest.mark.parametrize("n", [1, 63, 1000, 4096 + 5, 1 << 16])
