@@ -250,7 +250,7 @@ def supervise_rank(args, raw_argv):
                     ipc_mode = alt
                 else:
                     plan = ["gloo", "none"]
-    requested = "rccl" if args.collective == "auto" else args.collective
+    requested = "gloo" if args.rehearse_on_one_gpu else ("rccl" if args.collective == "auto" else args.collective)
     for mode in plan:
         port = sup.pick_port()
         cmd = [sys.executable, os.path.abspath(__file__)] + list(raw_argv) + ["--worker", "--collective", mode]
