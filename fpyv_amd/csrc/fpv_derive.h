@@ -56,6 +56,15 @@ static inline int fpv_derive_constants(const fpv_params_t* P, FpvK* K, const cha
     K->d2 = (float)(3 * c3 * h * h * h + c2 * h * h);
     K->d1 = (float)(3 * c3 * h * h * h + 2 * c2 * h * h + c1 * h);
     K->d0 = (float)(c3 * h * h * h + c2 * h * h + c1 * h + c0);
+    {
+        const double kt = P->thrust_transition_rate;
+        K->dk3 = (float)(kt * (c3 * h * h * h));
+        K->dk2 = (float)(kt * (3 * c3 * h * h * h + c2 * h * h));
+        K->dk1 = (float)(kt * (3 * c3 * h * h * h + 2 * c2 * h * h + c1 * h));
+        K->dk0 = (float)(kt * (c3 * h * h * h + c2 * h * h + c1 * h + c0));
+        K->rate_lim = (float)(P->max_rates * P->rates_transition_rate);
+        K->rate_gain = -K->rate_lim;
+    }
     K->inv_mass = (float)(1.0 / P->mass);
     K->g = (float)P->gravity;
     for (int i = 0; i < 3; ++i)

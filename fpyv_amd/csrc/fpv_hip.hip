@@ -499,8 +499,8 @@ __global__ __launch_bounds__(kStepBlock) FPV_EXP_ROLL_ATTR void fpv_drone_rollou
         FpvRollArgs Q;
         Q.K = A.K; Q.B.wx = A.B.wx; Q.B.wy = A.B.wy; Q.B.wz = A.B.wz; Q.B.step = A.B.step;
 #define FPV_VREG(x) do { if (!OBJ && !NOISE) asm volatile("" : "+v"(x)); } while (0)
-        FPV_VREG(Q.K.max_rates); FPV_VREG(Q.K.kr); FPV_VREG(Q.K.omkr); FPV_VREG(Q.K.kt); FPV_VREG(Q.K.omkt);
-        FPV_VREG(Q.K.d3); FPV_VREG(Q.K.d2); FPV_VREG(Q.K.d1); FPV_VREG(Q.K.d0);
+        FPV_VREG(Q.K.rate_gain); FPV_VREG(Q.K.rate_lim); FPV_VREG(Q.K.omkr); FPV_VREG(Q.K.omkt);
+        FPV_VREG(Q.K.dk3); FPV_VREG(Q.K.dk2); FPV_VREG(Q.K.dk1); FPV_VREG(Q.K.dk0);
         FPV_VREG(Q.K.inv_mass); FPV_VREG(Q.K.g); FPV_VREG(Q.K.kdrag_m[0]); FPV_VREG(Q.K.kdrag_m[1]); FPV_VREG(Q.K.kdrag_m[2]);
         FPV_VREG(Q.K.half_k); FPV_VREG(Q.K.dt);
         if (SQ) FPV_VREG(Q.K.motor_c);

@@ -57,6 +57,8 @@ struct FpvK {
     float kr, omkr;         // rates_transition_rate, 1 - it
     float kt, omkt;         // thrust_transition_rate, 1 - it
     float d3, d2, d1, d0;   // thrust [N] as a cubic in the throttle STICK (x = 50a+50 substituted)
+    float dk3, dk2, dk1, dk0;   // the same cubic times thrust_transition_rate: the low-pass is then ONE fma
+    float rate_gain, rate_lim;  // -max_rates * rates_transition_rate and its magnitude: clip and gain of the rate low-pass folded
     float inv_mass;
     float g;
     float kdrag_m[3];       // 0.5*rho*Cd_i*A_i / m
@@ -188,13 +190,16 @@ struct FpvRot { float r00, r01, r02, r10, r11, r12, r20, r21, r22; };
 
 FPV_HD FpvRot fpv_rot(FpvQuat q)
 {
-    const float xx = q.x * q.x, yy = q.y * q.y, zz = q.z * q.z;
-    const float xy = q.x * q.y, xz = q.x * q.z, yz = q.y * q.z;
-    const float wx = q.w * q.x, wy = q.w * q.y, wz = q.w * q.z;
+    // 20 instructions (round 3: 27): the doubled components enter every product once, each off-diagonal pair shares one
+    // product through an fma, the diagonal shares 1 - 2x^2 and 1 - 2y^2
+    const float x2 = q.x + q.x, y2 = q.y + q.y, z2 = q.z + q.z;
+    const float xx = q.x * x2, yy = q.y * y2, zz = q.z * z2;               // 2x^2, 2y^2, 2z^2
+    const float wx = q.w * x2, wy = q.w * y2, wz = q.w * z2;
+    const float ax = 1.0f - xx, ay = 1.0f - yy;
     FpvRot R;
-    R.r00 = fmaf(-2.0f, yy + zz, 1.0f); R.r01 = 2.0f * (xy - wz);           R.r02 = 2.0f * (xz + wy);
-    R.r10 = 2.0f * (xy + wz);           R.r11 = fmaf(-2.0f, xx + zz, 1.0f); R.r12 = 2.0f * (yz - wx);
-    R.r20 = 2.0f * (xz - wy);           R.r21 = 2.0f * (yz + wx);           R.r22 = fmaf(-2.0f, xx + yy, 1.0f);
+    R.r00 = ay - zz;                R.r01 = fmaf(q.x, y2, -wz);     R.r02 = fmaf(q.x, z2, wy);
+    R.r10 = fmaf(q.x, y2, wz);      R.r11 = ax - zz;                R.r12 = fmaf(q.y, z2, -wx);
+    R.r20 = fmaf(q.x, z2, -wy);     R.r21 = fmaf(q.y, z2, wx);      R.r22 = ax - yy;
     return R;
 }
 
@@ -703,15 +708,16 @@ FPV_HD FpvStepOut fpv_drone_step_lane(const FpvK& K, FpvDroneState& s, float a0,
                                       float* kahan = nullptr, const float* rot_over = nullptr, float thrust_over = 0.0f)
 {
     // (1)-(2) stick -> rate command (deg/s), clipped, low-passed          components.py:185-189
-    const float c0 = fpv_clamp(-a0 * K.max_rates, -K.max_rates, K.max_rates);
-    const float c1 = fpv_clamp(-a1 * K.max_rates, -K.max_rates, K.max_rates);
-    const float c2 = fpv_clamp(-a2 * K.max_rates, -K.max_rates, K.max_rates);
-    s.rx = fmaf(c0, K.kr, s.rx * K.omkr);
-    s.ry = fmaf(c1, K.kr, s.ry * K.omkr);
-    s.rz = fmaf(c2, K.kr, s.rz * K.omkr);
-    // (3) thrust cubic (Horner in the stick, no clamp), low-passed          components.py:136,:192-194
-    const float poly = fmaf(fmaf(fmaf(K.d3, a3, K.d2), a3, K.d1), a3, K.d0);
-    s.thrust = fmaf(poly, K.kt, s.thrust * K.omkt);
+    // clip(-a max, +-max) kr = clip(a (-max kr), +-(max kr)): the filter gain folded into the clip's operands (host, in
+    // double), so that an axis is mul + med3 + fma instead of mul + med3 + mul + fma
+    const float c0 = fpv_clamp(a0 * K.rate_gain, -K.rate_lim, K.rate_lim);
+    const float c1 = fpv_clamp(a1 * K.rate_gain, -K.rate_lim, K.rate_lim);
+    const float c2 = fpv_clamp(a2 * K.rate_gain, -K.rate_lim, K.rate_lim);
+    s.rx = fmaf(s.rx, K.omkr, c0);
+    s.ry = fmaf(s.ry, K.omkr, c1);
+    s.rz = fmaf(s.rz, K.omkr, c2);
+    // (3) thrust cubic (Horner in the stick, no clamp), low-passed; the cubic carries the filter gain   components.py:136,:192-194
+    s.thrust = fmaf(s.thrust, K.omkt, fmaf(fmaf(fmaf(K.dk3, a3, K.dk2), a3, K.dk1), a3, K.dk0));
     // guidance override (components.py:230-232): AFTER action2force has advanced prev_rates / prev_thrust the
     // attitude is replaced by the caller's rotation_matrix and the thrust becomes thrust_force * R[:,2]; drag, the
     // motor positions and the attitude increment then start from the new attitude.  A NaN thrust_force leaves
