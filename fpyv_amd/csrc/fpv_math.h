@@ -738,12 +738,12 @@ FPV_HD FpvStepOut fpv_drone_step_lane(const FpvK& K, FpvDroneState& s, float a0,
     const float bz = fmaf(R.r02, ux, fmaf(R.r12, uy, R.r22 * uz));
     const float fx = -K.kdrag_m[0] * bx * speed;
     const float fy = -K.kdrag_m[1] * by * speed;
-    const float fz = -K.kdrag_m[2] * bz * speed;
-    // (4) thrust along body z (third column), gravity; everything already divided by m
-    const float tm = thrust_now * K.inv_mass;
-    float accx = fmaf(R.r00, fx, fmaf(R.r01, fy, fmaf(R.r02, fz, tm * R.r02)));
-    float accy = fmaf(R.r10, fx, fmaf(R.r11, fy, fmaf(R.r12, fz, tm * R.r12)));
-    float accz = fmaf(R.r20, fx, fmaf(R.r21, fy, fmaf(R.r22, fz, fmaf(tm, R.r22, -K.g))));
+    // (4) thrust along body z (third column), gravity; everything already divided by m.  Thrust and the z component of
+    // the drag are both along the body z axis: they are added in the body frame and rotated together
+    const float fz = fmaf(-K.kdrag_m[2] * bz, speed, thrust_now * K.inv_mass);
+    float accx = fmaf(R.r00, fx, fmaf(R.r01, fy, R.r02 * fz));
+    float accy = fmaf(R.r10, fx, fmaf(R.r11, fy, R.r12 * fz));
+    float accz = fmaf(R.r20, fx, fmaf(R.r21, fy, fmaf(R.r22, fz, -K.g)));
 
     // ground flag: any motor below z = 0 on the PRE-update pose             components.py:235-240
     // ground contact (object_list = [Ground]): each motor closer than motor_radius to z = 0 adds a
