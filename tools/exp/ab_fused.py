@@ -30,7 +30,7 @@ ap.add_argument("--rounds", type=int, default=8)
 ap.add_argument("--only", nargs="*", default=None)
 ap.add_argument("--extra", nargs="*", default=[], help="name=flag,flag,... additional variants")
 ap.add_argument("--lib", nargs="*", default=[], help="name=path/to/lib.so: a ready-built library (e.g. an older commit) as a variant")
-ap.add_argument("--geom", default="f32", choices=["f32", "kahan", "racerW", "racerD", "racerWC", "aos"],
+ap.add_argument("--geom", default="f32", choices=["f32", "kahan", "racerW", "racerD", "racerWC", "aos", "noise"],
                 help="which kernel family to time: the plain drone kernel, + Kahan rows, the Racer as written / omega*dt / components.PID, the AoS observation head")
 a = ap.parse_args()
 for e in a.extra:
@@ -69,7 +69,7 @@ if a.geom.startswith("racer"):
     import numpy as np
     p = p.replace(mode=1, racer_pid=np.asarray([[0.004, 0.02, 1e-6], [0.003, 0.01, 2e-6], [0.002, 0.005, 0.0]]),
                   racer_omega_dt=(a.geom == "racerD"), racer_pid_variant=int(a.geom == "racerWC"), ceiling=100.0)
-cp = _lib.pack_params(p, auto_reset=True)
+cp = _lib.pack_params(p, auto_reset=True, stick_noise=(a.geom == "noise"), noise_seed=11)
 n = a.n
 ring = 32 if n <= (1 << 21) else 4
 acts = sticks.ema_noise_device(ring, n, dev)
@@ -98,6 +98,10 @@ extra = None
 if a.geom == "kahan":
     extra = torch.zeros((6, ld), device=dev)
     b.pos_comp = extra.data_ptr()
+elif a.geom == "noise":
+    extra = torch.zeros((4, ld), device=dev)
+    b.noise_state = extra.data_ptr()
+    b.action = None                                  # pure in-kernel noise sticks
 elif a.geom == "aos":
     extra = torch.zeros((n, _lib.FPV_OBS_AOS_DIM), device=dev)
     b.obs_aos = extra.data_ptr()
@@ -121,7 +125,7 @@ for api in (("fpv_rollout",) if a.geom == "aos" else ("fpv_rollout", "fpv_step_n
             torch.cuda.synchronize()
             e0.record()
             for rep in range(reps):
-                rc = fn(H[k], C.byref(b), ring, n * 4, 0, None)
+                rc = fn(H[k], C.byref(b), ring, 0 if a.geom == "noise" else n * 4, 0, None)
                 assert rc == 0, L[k].fpv_last_error()
             e1.record()
             torch.cuda.synchronize()
