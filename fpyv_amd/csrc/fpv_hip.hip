@@ -419,7 +419,7 @@ __device__ __forceinline__ const FpvRollArgs& fpv_args_again()
 #define FPV_EXP_ROLL_ATTR
 #endif
 #ifndef FPV_EXP_QUIET_UNROLL
-#define FPV_EXP_QUIET_UNROLL 1
+#define FPV_EXP_QUIET_UNROLL 2
 #endif
 #ifndef FPV_EXP_VCONST
 #define FPV_EXP_VCONST 0
@@ -509,8 +509,7 @@ __global__ __launch_bounds__(kStepBlock) FPV_EXP_ROLL_ATTR void fpv_drone_rollou
 #else
         const FpvRollArgs& QA = A;
 #endif
-#pragma unroll FPV_EXP_QUIET_UNROLL
-        for (; t < k - 1; ++t) {
+        auto quiet_step = [&]() {
             ap += astride;
             const FpvStepOut o = one_step(QA, &A.B.objs, ap, true, t, std::true_type{});
             if (bp) {
@@ -518,7 +517,16 @@ __global__ __launch_bounds__(kStepBlock) FPV_EXP_ROLL_ATTR void fpv_drone_rollou
                 if ((threadIdx.x & 63) == 0) bp[i >> 6] = mask;
                 bp += bstride;
             }
-        }
+            ++t;
+        };
+#if FPV_EXP_QUIET_UNROLL == 2
+        // two steps per trip, written out (the compiler declines `#pragma unroll` on this loop - it holds ballots and
+        // opaque asm -, which is why round 3's "unrolled by two" measured nothing): the register allocator can then
+        // alternate the loop-carried registers instead of copying five of them back every step (+2 %, one-process A/B)
+        // (not with an object list: its per-object uniforms already fill the SGPR file, two copies of the pass spill)
+        if constexpr (!OBJ) { while (t + 1 < k - 1) { quiet_step(); quiet_step(); } }
+#endif
+        while (t < k - 1) quiet_step();
     }
     // ---- 2. the remaining steps, with every output the caller asked for
     FpvStepOut o;
@@ -721,7 +729,7 @@ __global__ __launch_bounds__(kStepBlock) void fpv_drone_rollout_h_kernel(const F
         const int64_t astride = A.R.action_stride;
         unsigned long long* bp = A.R.bits_stride ? A.B.done_bits : nullptr;
         const int64_t bstride = A.R.bits_stride;
-        for (; t < k - 1; ++t) {
+        auto quiet_step = [&]() {
             ap += astride;
             const FpvStepOut o = one_step(A, ap, true, true, t, std::true_type{});
             if (bp) {
@@ -731,7 +739,12 @@ __global__ __launch_bounds__(kStepBlock) void fpv_drone_rollout_h_kernel(const F
                 if ((threadIdx.x & 63) == 0 && live) bp[i0 >> 6] = mask;
                 bp += bstride;
             }
-        }
+            ++t;
+        };
+#if FPV_EXP_QUIET_UNROLL == 2
+        while (t + 1 < k - 1) { quiet_step(); quiet_step(); }        // two steps per trip (see fpv_drone_rollout_kernel)
+#endif
+        while (t < k - 1) quiet_step();
     }
     FpvStepOut o;
     o.done = false; o.reward = 0.0f; o.ax = o.ay = o.az = 0.0f;
@@ -857,7 +870,7 @@ __global__ __launch_bounds__(kStepBlock) void fpv_racer_rollout_kernel(const Fpv
         const int64_t astride = A.R.action_stride;
         unsigned long long* bp = A.R.bits_stride ? A.B.done_bits : nullptr;
         const int64_t bstride = A.R.bits_stride;
-        for (; t < k - 1; ++t) {
+        auto quiet_step = [&]() {
             ap += astride;
             one_step(A, ap, true, std::true_type{});
             if (bp) {
@@ -865,7 +878,12 @@ __global__ __launch_bounds__(kStepBlock) void fpv_racer_rollout_kernel(const Fpv
                 if ((threadIdx.x & 63) == 0) bp[i >> 6] = mask;
                 bp += bstride;
             }
-        }
+            ++t;
+        };
+#if FPV_EXP_QUIET_UNROLL == 2
+        while (t + 1 < k - 1) { quiet_step(); quiet_step(); }        // two steps per trip (see fpv_drone_rollout_kernel)
+#endif
+        while (t < k - 1) quiet_step();
     }
     {
         const FpvRollArgs& G = fpv_args_again();

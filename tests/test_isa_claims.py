@@ -63,7 +63,7 @@ def test_fp16_and_kstep_kernels_as_design_quotes(isa):
     hk = next(n for n in bodies if "fpv_drone_step_h_kernel" in n)
     kk = next(n for n in bodies if h.HOT["plain k-step kernel fpv_drone_rollout_kernel<false,false,false,true>"] in n)
     assert res[hk]["occ"] == 8 and res[hk]["sspill"] == 0
-    assert (res[kk]["vgpr"], res[kk]["occ"], res[kk]["sspill"]) == (57, 8, 0)
+    assert (res[kk]["vgpr"], res[kk]["occ"], res[kk]["sspill"]) == (56, 8, 0)
     nk = next(n for n in bodies if "fpv_drone_rollout_kernelILb1ELb0ELb0ELb1E" in n)
     cn = h.counts(bodies[nk])
     assert cn["lds"] >= 4 and res[nk]["lds"] == 2048, "the noise kernels read the inverse-CDF table from LDS (one ds_read_b128 per normal)"
