@@ -1038,7 +1038,7 @@ __global__ __launch_bounds__(kBlock) void fpv_diag_copy4_kernel(fpv_v4f* __restr
     if (i < n4) dst[i] = src[i];
 }
 
-// A wave that idles for `ticks` of the 100 MHz constant-rate clock, at most `max_iter` sleeps (an exit every lane reaches
+// A wave that idles for `ticks` of the constant-rate wall clock, at most `max_iter` sleeps (an exit every lane reaches
 // whatever the clock does): a kernel of known duration on one CU (fpv_diag_busy).
 __global__ __launch_bounds__(64) void fpv_diag_busy_kernel(const unsigned long long ticks, const int max_iter)
 {
@@ -1474,7 +1474,11 @@ int fpv_diag_stream_copy_wide(float* dst, const float* src, int64_t n_floats, vo
 int fpv_diag_busy(double microseconds, void* stream)
 {
     if (!(microseconds > 0.0) || microseconds > 1000.0) return fail(FPV_EINVAL, "fpv_diag_busy: 0 < microseconds <= 1000");
-    const unsigned long long ticks = (unsigned long long)(microseconds * 100.0);       // wall_clock64: 100 MHz on gfx950
+    // wall_clock64 ticks at the device's constant wall-clock rate (hipDeviceAttributeWallClockRate, kHz): asked, not assumed
+    int dev = 0, khz = 0;
+    if (hipGetDevice(&dev) != hipSuccess || hipDeviceGetAttribute(&khz, hipDeviceAttributeWallClockRate, dev) != hipSuccess || khz <= 0)
+        khz = 100000;
+    const unsigned long long ticks = (unsigned long long)(microseconds * (double)khz * 1e-3);
     // one s_sleep(32) is 32 x 64 clocks ~ 1 us at 2 GHz: the iteration cap is ~4x the requested time
     hipLaunchKernelGGL(fpv_diag_busy_kernel, dim3(1), dim3(64), 0, (hipStream_t)stream, ticks, (int)(microseconds * 4.0) + 64);
     const hipError_t e = hipGetLastError();

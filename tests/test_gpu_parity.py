@@ -2144,3 +2144,26 @@ def test_sharded_example_under_the_launcher_two_ranks_on_one_gpu():
     assert r.returncode == 0, (r.stdout + r.stderr)[-3000:]
     assert "2 ranks x 32768 drones over gloo, 150 steps" in r.stdout and "(must agree)" in r.stdout
     assert "equals its slice of the unsharded run bit for bit" in r.stdout
+
+
+def test_stream_overlap_probe_and_busy_kernel():
+    """fpyv_amd.streams: the measured choice of the split-phase API's partition streams.  fpv_diag_busy is a kernel of known
+    duration on one CU; two chains of it on ONE stream take twice as long as one chain (ratio ~2), on streams the probe
+    accepted they take as long as one (ratio ~1); the accepted set overlaps pairwise and with the caller's stream."""
+    import time
+    from fpyv_amd.streams import chain_time_ratio, overlapping_streams
+    L = _lib.lib()
+    assert L.fpv_diag_busy(0.0, None) == -1 and L.fpv_diag_busy(2000.0, None) == -1 and b"microseconds" in L.fpv_last_error()
+    s = torch.cuda.Stream(device=DEV)
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(20):
+        _lib.check(L.fpv_diag_busy(200.0, s.cuda_stream))
+    s.synchronize()
+    took = time.perf_counter() - t0
+    assert 20 * 200e-6 * 0.8 < took < 20 * 200e-6 * 2.5, f"20 busy kernels of 200 us took {took * 1e3:.2f} ms"
+    assert chain_time_ratio(s, s) > 1.7, "one stream cannot overlap with itself"
+    cur = torch.cuda.current_stream(DEV)
+    picked, rep = overlapping_streams(DEV, 2, avoid=[cur])
+    assert len(picked) == 2 and rep["verified"] and rep["draws"] >= 2 and picked[0] != picked[1] and cur not in picked
+    assert chain_time_ratio(picked[0], picked[1]) < 1.3 and chain_time_ratio(picked[0], cur) < 1.3
