@@ -1827,8 +1827,9 @@ def test_integration_md_stub_runs_and_lands_on_the_reference(params_1k):
 def test_plain_c_host_through_the_c_abi(params_1k, tmp_path):
     """The boundary is a C ABI: examples/c_host/main.c - plain C, hipMalloc'd buffers, no Python or torch in
     the process - is compiled here with gcc against include/fpv_abi.h and libfpv_hip.so, runs config 2
-    (4096 drones, sinusoidal sticks) as k fpv_step launches and as one fpv_step_n launch, and must
-    reproduce the Python host's result bit for bit."""
+    (4096 drones, sinusoidal sticks) as k fpv_step launches, as one fpv_step_n launch, and as TWO handles over the column
+    halves of the same buffers on two streams (the split-phase layout against the bare C ABI), and must reproduce the
+    Python host's result bit for bit every time."""
     import ctypes as C
     import os
     import subprocess
@@ -1849,10 +1850,10 @@ def test_plain_c_host_through_the_c_abi(params_1k, tmp_path):
     torch.cuda.synchronize()
     want = env.state.cpu().numpy()
     rows, ld = want.shape
-    for mode in ("steps", "fused"):
+    for mode in ("steps", "fused", "split"):
         out = tmp_path / f"state_{mode}.bin"
         r = subprocess.run([exe, str(tmp_path / "params.bin"), str(tmp_path / "actions.bin"), str(n), str(k), str(out)]
-                           + (["fused"] if mode == "fused" else []), capture_output=True, text=True, timeout=300)
+                           + ([mode] if mode != "steps" else []), capture_output=True, text=True, timeout=300)
         assert r.returncode == 0, r.stderr
         raw = np.fromfile(out, dtype=np.uint8)
         got = raw[:rows * ld * 4].view(np.float32).reshape(rows, ld)
