@@ -12,7 +12,7 @@ set whose members all overlap with each other (and with the streams the caller w
 from __future__ import annotations
 
 import time
-from typing import Any, Dict, List, Optional, Sequence, Tuple
+from typing import Any, Dict, List, Sequence, Tuple
 
 import torch
 
