@@ -424,6 +424,9 @@ __device__ __forceinline__ const FpvRollArgs& fpv_args_again()
 #ifndef FPV_EXP_VCONST
 #define FPV_EXP_VCONST 0
 #endif
+#ifndef FPV_EXP_PREFETCH2
+#define FPV_EXP_PREFETCH2 0
+#endif
 template <bool NOISE, bool OBJ, bool KAHAN, bool SQ = false>
 __global__ __launch_bounds__(kStepBlock) FPV_EXP_ROLL_ATTR void fpv_drone_rollout_kernel(const FpvRollArgs A)
 {
@@ -452,12 +455,21 @@ __global__ __launch_bounds__(kStepBlock) FPV_EXP_ROLL_ATTR void fpv_drone_rollou
     if (NOISE) { fpv_settle(ns[0]); fpv_settle(ns[1]); fpv_settle(ns[2]); fpv_settle(ns[3]); }
     if (KAHAN) { for (int c = 0; c < 6; ++c) fpv_settle(kc[c]); }
     float av[4] = {0.f, 0.f, 0.f, 0.f};
+    [[maybe_unused]] float4 a_next2 = a_next;              // (FPV_EXP_PREFETCH2) the action row after the next one
 
     // one step on the view V of the arguments.  QUIET steps take their next action unconditionally (there is always
     // a step t + 1 behind a quiet one; a held action - stride 0 - is simply read again: 16 bytes from the cache)
     auto one_step = [&](const FpvRollArgs& V, const FpvObjects* objs, const float* ap_next, bool prefetch, int t, auto quiet_c) -> FpvStepOut {
         constexpr bool QUIET = decltype(quiet_c)::value;
         av[0] = a_next.x; av[1] = a_next.y; av[2] = a_next.z; av[3] = a_next.w;
+#if FPV_EXP_PREFETCH2
+        // QUIET steps keep TWO action rows in flight: ap_next is the row of step t + 2 (clamped to the last one), the row of
+        // step t + 1 is already here in a_next2.  One row ahead gives a wave ~1.4 us of cover (eight waves share a SIMD, a
+        // step is ~165 instructions each) against an HBM latency of 1-3 us under this load; two rows cover it.
+        if (QUIET) {
+            if (!NOISE || has_action) { a_next = a_next2; a_next2 = ld_action(reinterpret_cast<const float4*>(ap_next), i); }
+        } else
+#endif
         if ((!NOISE || has_action) && (QUIET || prefetch)) a_next = ld_action(reinterpret_cast<const float4*>(ap_next), i);
         if (NOISE) {
             // the Philox round keys are uniform and loop-invariant: left alone the compiler keeps all fourteen words
@@ -509,8 +521,17 @@ __global__ __launch_bounds__(kStepBlock) FPV_EXP_ROLL_ATTR void fpv_drone_rollou
 #else
         const FpvRollArgs& QA = A;
 #endif
+#if FPV_EXP_PREFETCH2
+        const float* const ap_last = ap + (int64_t)(k - 1) * astride;             // row of the last step: nothing is read beyond it
+        if (has_action) a_next2 = ld_action(reinterpret_cast<const float4*>(ap + astride), i);     // row of step 1 (k > 1 here)
+        ap += astride;
+#endif
         auto quiet_step = [&]() {
+#if FPV_EXP_PREFETCH2
+            ap = (t + 2 < k) ? ap + astride : ap_last;                            // row of step t + 2, clamped (uniform)
+#else
             ap += astride;
+#endif
             const FpvStepOut o = one_step(QA, &A.B.objs, ap, true, t, std::true_type{});
             if (bp) {
                 const unsigned long long mask = __ballot(o.done);
