@@ -78,18 +78,25 @@ enum {
     FPV_FLAG_GROUND = 2u,       /* ground plane z = 0 in object_list: per-motor spring contact,
                                    Drone.handle_collisions with a Ground object (components.py:198-214) */
     FPV_FLAG_STICK_NOISE = 8u,  /* drone mode, fp32 state: the kernel advances an EMA-smoothed Gaussian stick noise
-                                   per drone and channel (the profile of tests/noise_smooth_test.py:6-12, Philox4x32-10
+                                   per drone and channel (the profile of tests/noise_smooth_test.py:6-12, Philox4x32-7 + a table-driven inverse normal CDF,
                                    keyed by seed / global drone id / step) and ADDS gain * noise to the action
                                    (clipped to [-1,1]); fpv_buffers_t.action may then be NULL (pure noise sticks) */
-    FPV_FLAG_FP16_STATE = 4u    /* drone mode only: v, q, prev_rates, prev_thrust stored as IEEE binary16 in
+    FPV_FLAG_FP16_STATE = 4u    /* drone mode only: v, q, prev_rates, prev_thrust stored as eleven 16-bit words per drone in
                                    fpv_buffers_t.state_h; fpv_buffers_t.state holds only the 3 position rows in
                                    fp32; arithmetic stays fp32 (BASELINE config 4) */
 };
-/* state_h under FPV_FLAG_FP16_STATE: FPV_HALF_PAIR_ROWS rows of ld half2 pairs (low half first):
- * (vx,vy) (vz,qw) (qx,qy) (qz,rx) (ry,rz) - i.e. value r (FPV_VX..FPV_RZ) of drone i is half ((r-3) & 1) of pair
- * state_h[((r-3) >> 1) * ld + i] - followed by ONE row of ld single halves holding prev_thrust:
- * (FPV_HALF_PAIR_ROWS * 2 + 1) * ld halves in all, 22 bytes per drone.  The kernel never issues a 2-byte access:
- * the two lanes of an even/odd drone pair share the dword of the thrust row and exchange their halves in registers. */
+/* state_h under FPV_FLAG_FP16_STATE: FPV_HALF_PAIR_ROWS rows of ld 32-bit word pairs (low 16 bits first):
+ * (vx,vy) (vz,v_low) (qa,qb) (qc,rx) (ry,rz), followed by ONE row of ld single halves holding prev_thrust:
+ * (FPV_HALF_PAIR_ROWS * 2 + 1) * ld 16-bit words in all, 22 bytes per drone.  Encoding (ABI 5; csrc/fpv_math.h,
+ * fpv_pack_half / fpv_unpack_half; fpv_widen_state decodes a whole batch):
+ *   vx vy vz rx ry rz thrust   IEEE binary16 (v: round toward zero of the stochastically rounded value; rates / thrust: nearest even)
+ *   v_low                      bits 0-4 / 5-9 / 10-14: the next five mantissa bits of vx / vy / vz (v has 15 mantissa bits in all)
+ *   qa qb qc                   "smallest three": bits 0-14 = 15-bit two's-complement fixed point, value / 23168, of the three
+ *                              quaternion components that are NOT the largest in magnitude, in w x y z order; bit 15 of qa and
+ *                              of qb = bits 0 and 1 of the index of the dropped component, which is positive and equals
+ *                              sqrt(1 - qa^2 - qb^2 - qc^2); stochastically rounded.
+ * The kernel never issues a 2-byte access: the two lanes of an even/odd drone pair share the dword of the thrust row and
+ * exchange their halves in registers. */
 #define FPV_HALF_PAIR_ROWS 5
 #define FPV_HALF_ROWS_TOTAL_HALVES 11    /* halves per drone in state_h */
 #define FPV_OBS_AOS_DIM 16
@@ -172,8 +179,8 @@ typedef struct fpv_buffers {
     float wind[3];           /* wind_velocity_vector of this step (kinematics.py:35: ADDED to v) */
     uint32_t rounding_seed;  /* FPV_FLAG_FP16_STATE: mixed with the handle's 64-bit step counter for the stochastic rounding
                                 (step t of the handle rounds with rounding_seed + t, the counter's high word folded in) */
-    uint16_t* state_h;       /* FPV_FLAG_FP16_STATE: [FPV_HALF_PAIR_ROWS][ld] half2 pairs (4 bytes each) + [ld] thrust halves,
-                                8-byte aligned; else unused */
+    uint16_t* state_h;       /* FPV_FLAG_FP16_STATE: [FPV_HALF_PAIR_ROWS][ld] word pairs (4 bytes each) + [ld] thrust halves
+                                (encoding above), 8-byte aligned; else unused */
     float* pos_comp;         /* [6][ld] Kahan compensation of the p and v accumulations, or NULL (plain fp32 sums).
                                 Keeps p, v within ~1 ulp over 10^4+ steps (config 1); +48 B per env-step; drone mode,
                                 fp32 state; combines with stick noise and objects, not with obs_aos */
@@ -257,11 +264,12 @@ int fpv_step_n(fpv_handle_t h, const fpv_buffers_t* b, int k, int64_t action_str
 int fpv_return_triple(fpv_handle_t h, const fpv_buffers_t* b, float* rt, float* gyro, float* acc, void* stream);
 
 /* FPV_FLAG_FP16_STATE handles: the whole state as 14 fp32 rows out[14][out_ld] (same row numbering as the fp32 state) -
- * position rows copied, every stored half widened as it is (no renormalisation: this is the stored state).  For a
- * caller that reads the state each step (an observation); one launch. */
+ * position rows copied, the eleven 16-bit words decoded exactly as the step kernel decodes them (v with its low words, q
+ * rebuilt from its three stored components: a unit quaternion).  For a caller that reads the state each step (an
+ * observation); one launch. */
 int fpv_widen_state(fpv_handle_t h, const fpv_buffers_t* b, float* out, int64_t out_ld, void* stream);
 
-/* The 64-bit step index that keys the stick-noise stream (Philox4x32-10 counter = global drone id, step index; key =
+/* The 64-bit step index that keys the stick-noise stream (Philox4x32-7 counter = global drone id, step index; key =
  * noise_seed) and the stochastic rounding counts the steps a handle has launched, from 0: set it to resume / replay a
  * run, read it to checkpoint one.  2^64 steps do not wrap in practice (2^32 took 5.5 h at the k-step kernel's rate,
  * which is why the 32-bit counter of ABI <= 3 was widened); streams below 2^32 steps are those of ABI <= 3 bit for bit.
