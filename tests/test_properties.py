@@ -101,3 +101,46 @@ def test_rotation_helpers_round_trip_for_any_attitude(q, tiny):
     e = matrix_to_euler_zyx(R)
     if abs(float(R[0, 2, 0])) < 1 - 1e-9:                          # away from gimbal lock the Euler round trip is exact too
         assert float((euler_zyx_matrix(e) - R).abs().max()) < 1e-9
+
+
+@settings(max_examples=150, deadline=None)
+@given(q=st.lists(st.floats(-1, 1, allow_nan=False, width=32), min_size=4, max_size=4),
+       v=st.lists(st.floats(-80, 80, allow_nan=False, width=32), min_size=3, max_size=3),
+       seed=st.integers(0, 2 ** 32 - 1), drone=st.integers(0, 2 ** 32 - 1))
+def test_fp16_storage_round_trip_for_any_attitude_and_velocity(q, v, seed, drone):
+    """The fp16 state's eleven words (fpv_pack_half -> fpv_unpack_half) for ANY unit quaternion and velocity: the decoded
+    attitude is a unit quaternion within the fixed-point grid of the input (as an attitude: q and -q are the same), its
+    largest component is the reconstructed one, the decoded velocity is within one 15-bit-mantissa step."""
+    qn = np.asarray(q, dtype=np.float64)
+    if np.linalg.norm(qn) < 1e-3:
+        qn = np.array([1.0, 0, 0, 0])
+    qn = (qn / np.linalg.norm(qn)).astype(np.float32)
+    st14 = np.zeros((14, 64), dtype=np.float32)
+    st14[3:6, 0], st14[6:10, 0] = v, qn
+    pos, sh = lane_model.split_half(st14, seed=seed, drone_id_offset=drone)
+    back = lane_model.join_half(pos, sh)[:, 0].astype(np.float64)
+    qb = back[6:10]
+    assert abs(np.linalg.norm(qb) - 1) < 2e-6
+    grid = 1.0 / 23168
+    d = min(np.abs(qb - qn).max(), np.abs(qb + qn).max())
+    # three components within one grid step each; the fourth follows from |q| = 1 with a >= 1/2 pivot: <= ~3.5 steps
+    assert d <= 3.6 * grid, (qn, qb, d / grid)
+    k = int(np.argmax(np.abs(qb)))
+    assert abs(qb[k]) >= 0.5 - 1e-6 and qb[k] > 0, "the dropped (reconstructed) component is the largest, stored sign makes it positive"
+    vv = np.asarray(v, dtype=np.float32)
+    step = np.maximum(np.abs(np.spacing(vv.astype(np.float16)).astype(np.float64)) / 32, 2.0 ** -24 * 1.01)
+    assert np.all(np.abs(back[3:6] - vv) <= step * 1.0001 + 1e-12), (vv, back[3:6])
+
+
+@settings(max_examples=200, deadline=None)
+@given(a=st.integers(0, 2 ** 31 - 1), b=st.integers(0, 2 ** 31 - 1), sign=st.integers(0, 1))
+def test_inverse_normal_is_monotone_and_symmetric_for_any_pair_of_words(a, b, sign):
+    """fpv_normal_from_word: a larger tail probability never gives a larger |z| (beyond the table's own 2.2e-6), the sign
+    bit only flips the sign, and the value is the exact inverse CDF to 3e-6."""
+    from oracle import philox
+    lo, hi = sorted((a, b))
+    w = np.array([lo, hi], dtype=np.uint32) | np.uint32(sign << 31)
+    z = lane_model.normal_from_words(w).astype(np.float64)
+    assert abs(z[1]) <= abs(z[0]) + 5e-6
+    assert np.all(np.signbit(z) == bool(sign)) or np.any(z == 0)
+    assert np.abs(z - philox.normal_from_words(w)).max() < 3e-6
