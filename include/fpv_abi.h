@@ -223,7 +223,13 @@ int fpv_handle_algorithmic_bytes(fpv_handle_t h);
 
 /* Replaces Drone.__init__'s physics set-up (components.py:86-142) / Racer.__init__ (:68-83).
  * Validates and narrows the parameters; binds to `device`.  No device allocation.
- * n <= 2^28 drones per handle (32-bit lane byte offsets into 16-byte action rows). */
+ * n <= 2^28 drones per handle (32-bit lane byte offsets into 16-byte action rows).
+ * A handle need not own whole buffers: created with n = hi - lo and params->drone_id_offset + lo, and given every
+ * fpv_buffers_t pointer moved by lo elements (same ld; done_bits by lo / 64 words; lo a multiple of 128; fp32 state), it
+ * steps the COLUMN RANGE [lo, hi) of a larger batch.  Several such handles on streams of their own are independent
+ * kernel chains over one set of tensors - the split-phase layout (fpyv_amd.env.FpvVecEnv(partitions=P),
+ * examples/c_host/main.c `split`): bit-identical to the single batch, and the chains hide part of each other's
+ * per-launch floor. */
 int fpv_create(const fpv_params_t* params, int64_t n, int device, fpv_handle_t* out);
 void fpv_destroy(fpv_handle_t h);
 
