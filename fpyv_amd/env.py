@@ -890,6 +890,13 @@ class FpvVecEnv:
             v = self._part_views[part] = (b.state[:13, P.lo:P.hi].t(), b.reward[P.lo:P.hi], b.done[P.lo:P.hi])
         return v[0], v[1], v[2], self._info(self.batch, P.lo, P.hi)
 
+    def set_done_bits_target(self, target: Any = None) -> None:
+        """Where the kernels write the bit-packed done mask (DroneBatch.set_done_bits_target); with partitions every
+        partition writes its own words of the same row (a partition starts at a multiple of 64 drones)."""
+        self.batch.set_done_bits_target(target)
+        for P in self._parts:
+            P.rebind()
+
     def state_dict(self) -> Dict[str, Any]:
         """The batch's checkpoint; with partitions the step counters of all of them (they key the stick-noise streams)."""
         for k in range(len(self._parts)):

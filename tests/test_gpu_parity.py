@@ -641,8 +641,15 @@ def test_split_phase_partitions_are_bitwise_the_single_batch(params_1k, case):
     one.step(act); split.step(act)
     torch.cuda.synchronize()
     assert torch.equal(a.state, b.state) and torch.equal(a.done_u8, b.done_u8)
+    # the mask redirected to a caller's row (what a collective's bucket is): every partition writes its own words of it
+    row_a, row_b = (torch.full(((n + 63) // 64,), -1, dtype=torch.int64, device=DEV) for _ in range(2))
+    one.batch.set_done_bits_target(row_a); split.set_done_bits_target(row_b)
+    one.step(act); split.step(act)
+    torch.cuda.synchronize()
+    assert torch.equal(row_a, row_b) and torch.equal(a.state, b.state)
+    one.batch.set_done_bits_target(None); split.set_done_bits_target(None)
     ck = split.state_dict()
-    assert ck["partition_step_counters"] == [T + 1] * parts and ck["step_counter"] == T + 1
+    assert ck["partition_step_counters"] == [T + 2] * parts and ck["step_counter"] == T + 2
     third = FpvVecEnv(p, **kw)
     third.reset()
     third.batch.load_state_dict({k: v for k, v in ck.items() if k != "partition_step_counters"})
