@@ -67,6 +67,7 @@ struct FpvBufD {
     uint32_t seed;         // stochastic-rounding base seed (fpv_buffers_t.rounding_seed); step t rounds with fpv_round_seed(seed, step + t)
     const float* rot_over;     // [n][9] guidance override of the attitude (Drone.step rotation_matrix=) or null
     const float* thrust_over;  // [n] thrust_force= of the same call (NaN = this drone is not overridden)
+    uint16_t* thrust_h;        // FPV_FLAG_FP16_STATE: the row of prev_thrust halves (always set by to_device_view)
 };
 
 // k-step launches (fpv_step_n): step t reads its action at + t*action_stride floats and writes
@@ -644,7 +645,7 @@ __global__ __launch_bounds__(kStepBlock) void fpv_drone_step_aos_kernel(FPV_STEP
 // Arithmetic and the lane function are unchanged.
 __device__ __forceinline__ const uint32_t* thrust_row_h(const FpvBufD& B)
 {
-    return reinterpret_cast<const uint32_t*>(B.state_h) + (int64_t)FPV_HALF_PAIR_ROWS * B.ld;
+    return reinterpret_cast<const uint32_t*>(B.thrust_h);      // follows the pair rows unless the caller placed it (a column partition)
 }
 
 __device__ __forceinline__ void ld_drone_h(const FpvBufD& B, uint32_t i, FpvDroneState& s)
@@ -994,8 +995,8 @@ __global__ __launch_bounds__(kBlock) void fpv_return_triple_kernel(const float* 
 // step kernel decodes them (fpv_unpack_half: v with its low words, q rebuilt from its three stored components).  One
 // launch instead of a dozen tensor operations.
 __global__ __launch_bounds__(kBlock) void fpv_widen_state_kernel(const float* __restrict__ pos, const uint16_t* __restrict__ sh16,
-                                                                 const int64_t ld, float* __restrict__ out, const int64_t out_ld,
-                                                                 const int64_t n)
+                                                                 const uint16_t* __restrict__ thrust16, const int64_t ld,
+                                                                 float* __restrict__ out, const int64_t out_ld, const int64_t n)
 {
     const int64_t i = (int64_t)blockIdx.x * kBlock + threadIdx.x;
     if (i >= n) return;
@@ -1003,7 +1004,7 @@ __global__ __launch_bounds__(kBlock) void fpv_widen_state_kernel(const float* __
     FpvHalfState h;
 #pragma unroll
     for (int k = 0; k < FPV_HALF_PAIR_ROWS; ++k) h.w[k] = sh[(int64_t)k * ld + i];
-    h.t = sh16[(int64_t)2 * FPV_HALF_PAIR_ROWS * ld + i];
+    h.t = thrust16[i];
     FpvDroneState s;
     fpv_unpack_half(h, s);
 #pragma unroll
@@ -1150,6 +1151,7 @@ int check_buffers(const fpv_env* h, const fpv_buffers_t* b, bool need_action)  /
     if (h->K.flags & FPV_FLAG_FP16_STATE) {
         if (!b->state_h) return fail(FPV_EINVAL, "FPV_FLAG_FP16_STATE needs fpv_buffers_t.state_h");
         if ((uintptr_t)b->state_h & 7) return fail(FPV_EALIGN, "state_h must be 8-byte aligned");
+        if ((uintptr_t)b->state_h_thrust & 3) return fail(FPV_EALIGN, "state_h_thrust must be 4-byte aligned (a column range starts at an even drone)");
     }
     if ((b->rotation_override == nullptr) != (b->thrust_override == nullptr))
         return fail(FPV_EINVAL, "rotation_override and thrust_override must be given together (Drone.step: thrust_force is only "
@@ -1183,6 +1185,7 @@ FpvBufD to_device_view(const fpv_buffers_t* b, float reach)
     d.noise_state = b->noise_state; d.action_out = reinterpret_cast<float4*>(b->action_out); d.step = 0;
     d.action_ld = b->action_ld;
     d.rot_over = b->rotation_override; d.thrust_over = b->thrust_override;
+    d.thrust_h = b->state_h_thrust ? b->state_h_thrust : (b->state_h ? b->state_h + (int64_t)2 * FPV_HALF_PAIR_ROWS * b->ld : nullptr);
     d.objs.count = 0;
     if (b->objects) {
         d.objs.count = b->objects->count;
@@ -1642,8 +1645,9 @@ int fpv_widen_state(fpv_handle_t h, const fpv_buffers_t* b, float* out, int64_t 
     if (b->ld < h->n || out_ld < h->n) return fail(FPV_EALIGN, "ld / out_ld smaller than the number of drones");
     const DeviceGuard dev(h->device);
     if (dev.rc != FPV_OK) return dev.rc;
+    const uint16_t* thrust = b->state_h_thrust ? b->state_h_thrust : b->state_h + (int64_t)2 * FPV_HALF_PAIR_ROWS * b->ld;
     hipLaunchKernelGGL(fpv_widen_state_kernel, dim3((unsigned)((h->n + kBlock - 1) / kBlock)), dim3(kBlock), 0, (hipStream_t)stream,
-                       b->state, b->state_h, b->ld, out, out_ld, h->n);
+                       b->state, b->state_h, thrust, b->ld, out, out_ld, h->n);
     const hipError_t e = hipGetLastError();
     if (e != hipSuccess) return hip_fail(e, "widen kernel launch");
     return FPV_OK;

@@ -426,8 +426,6 @@ class _Partition:
     floor.  `lo` is a multiple of 128 - whole workgroups, whole done-mask words, 16-byte aligned rows."""
 
     def __init__(self, parent: "_Batch", lo: int, hi: int, stream: Optional[torch.cuda.Stream]):
-        if parent.fp16_state:
-            raise ValueError("partitions need fp32 state (the fp16 thrust row packs TWO drones per word: a column offset is not a pointer offset)")
         if lo % 128 or not lo < hi <= parent.n:
             raise ValueError("a partition starts at a multiple of 128 drones and is not empty")
         self.parent, self.lo, self.hi, self.n = parent, lo, hi, hi - lo
@@ -457,7 +455,14 @@ class _Partition:
         b.last_return, b.last_length = off(pb.last_return, 4), off(pb.last_length, 4)
         b.action_out, b.obs_aos = off(pb.action_out, 4, 4), off(pb.obs_aos, 4, _lib.FPV_OBS_AOS_DIM)
         b.wind[0], b.wind[1], b.wind[2] = pb.wind[0], pb.wind[1], pb.wind[2]
-        b.rounding_seed, b.state_h, b.objects = pb.rounding_seed, None, pb.objects
+        b.rounding_seed, b.objects = pb.rounding_seed, pb.objects
+        if pb.state_h:
+            # fp16 storage: the pair rows move by lo words, the row of thrust halves (two drones per word) by lo halves -
+            # it gets its own pointer (fpv_buffers_t.state_h_thrust)
+            b.state_h = pb.state_h + 4 * lo
+            b.state_h_thrust = pb.state_h + 2 * (2 * _lib.FPV_HALF_PAIR_ROWS * pb.ld + lo)
+        else:
+            b.state_h = b.state_h_thrust = None
         b.done_bits_stride = 0
 
     def action_ptr(self, action: Any) -> Optional[int]:
@@ -884,11 +889,16 @@ class FpvVecEnv:
             cur = torch.cuda.current_stream(self.batch.device)
             if cur != P.stream:
                 cur.wait_stream(P.stream)
+        b = self.batch
+        if b.fp16_state:
+            # fp16 storage: a decoded copy of this partition's columns (one launch of fpv_widen_state on ITS handle), fresh every time
+            wide = torch.empty((_lib.FPV_DRONE_ROWS, _round_up(P.n, 64)), dtype=torch.float32, device=b.device)
+            _lib.check(b._L.fpv_widen_state(P._handle, P._buf_ref, wide.data_ptr(), wide.shape[1], b._stream()))
+            return wide[:13, :P.n].t(), b.reward[P.lo:P.hi], b.done[P.lo:P.hi], self._info(b, P.lo, P.hi)
         v = self._part_views[part]
         if v is None:
-            b = self.batch
             v = self._part_views[part] = (b.state[:13, P.lo:P.hi].t(), b.reward[P.lo:P.hi], b.done[P.lo:P.hi])
-        return v[0], v[1], v[2], self._info(self.batch, P.lo, P.hi)
+        return v[0], v[1], v[2], self._info(b, P.lo, P.hi)
 
     def set_done_bits_target(self, target: Any = None) -> None:
         """Where the kernels write the bit-packed done mask (DroneBatch.set_done_bits_target); with partitions every

@@ -204,6 +204,10 @@ typedef struct fpv_buffers {
                                 caller-supplied sticks; combines with objects / FPV_FLAG_GROUND */
     const float* thrust_override;   /* [n] thrust_force [N] of the same call; required with rotation_override.  A NaN entry
                                 leaves that drone un-overridden (its own attitude and low-passed thrust) */
+    uint16_t* state_h_thrust;/* FPV_FLAG_FP16_STATE: the row of prev_thrust halves when it does NOT follow the pair rows at
+                                state_h + 2 * FPV_HALF_PAIR_ROWS * ld - i.e. for a handle that steps a column range [lo, hi) of a
+                                larger batch (state_h moved by 2 * lo halves, this pointer = the batch's thrust row + lo halves;
+                                4-byte aligned: lo even); NULL = the row follows the pair rows */
 } fpv_buffers_t;
 
 typedef struct fpv_env* fpv_handle_t;
@@ -225,7 +229,8 @@ int fpv_handle_algorithmic_bytes(fpv_handle_t h);
  * Validates and narrows the parameters; binds to `device`.  No device allocation.
  * n <= 2^28 drones per handle (32-bit lane byte offsets into 16-byte action rows).
  * A handle need not own whole buffers: created with n = hi - lo and params->drone_id_offset + lo, and given every
- * fpv_buffers_t pointer moved by lo elements (same ld; done_bits by lo / 64 words; lo a multiple of 128; fp32 state), it
+ * fpv_buffers_t pointer moved by lo elements (same ld; done_bits by lo / 64 words; lo a multiple of 128; fp16 state:
+ * state_h by 2 * lo halves and state_h_thrust = the thrust row + lo halves), it
  * steps the COLUMN RANGE [lo, hi) of a larger batch.  Several such handles on streams of their own are independent
  * kernel chains over one set of tensors - the split-phase layout (fpyv_amd.env.FpvVecEnv(partitions=P),
  * examples/c_host/main.c `split`): bit-identical to the single batch, and the chains hide part of each other's

@@ -586,7 +586,7 @@ def test_vec_env_surface(params_1k):
     assert set(np.unique(raw)) <= {0, 1}
 
 
-@pytest.mark.parametrize("case", ["plain2", "noise3", "racer2", "objects2"])
+@pytest.mark.parametrize("case", ["plain2", "noise3", "racer2", "objects2", "fp16_2"])
 def test_split_phase_partitions_are_bitwise_the_single_batch(params_1k, case):
     """FpvVecEnv(partitions=P): step_async(part, action) / step_wait(part) - each partition its own handle, stream and
     kernel chain over column ranges of the SAME tensors, drones keyed by their global id.  Closed loop (a linear policy
@@ -605,6 +605,8 @@ def test_split_phase_partitions_are_bitwise_the_single_batch(params_1k, case):
         pid = np.array([[0.004, 0.02, 1e-6], [0.003, 0.01, 2e-6], [0.002, 0.005, 0]])
         p = params_1k.replace(mode=1, racer_pid=pid, ceiling=3e-3)
         kw.update(mode="racer")
+    if case == "fp16_2":
+        kw.update(fp16_state=True, rounding_seed=21, drone_id_offset=777)      # the rounding stream is keyed by the global id too
     if case == "objects2":
         p = p.replace(init_position=np.array([0.0, 0.0, 0.12]), init_velocity=np.array([1.0, 0.0, -3.0]), ceiling=3.0)   # diving: the ground ends episodes
         kw.update(object_list=[Ground(), Cylinder(position=[1.5, 0.2, 0.0], radius=0.4, height=1.0)], wind=(0.4, -0.1, 0.0))
@@ -628,19 +630,25 @@ def test_split_phase_partitions_are_bitwise_the_single_batch(params_1k, case):
         o, r, d, info = split.step_wait(k)
         lo, hi = split.partition_range(k)
         assert o.shape == (hi - lo, 13) and r.shape == (hi - lo,) and d.dtype == torch.bool and info["episode_length"].shape == (hi - lo,)
-        assert o.data_ptr() == split.batch.state.data_ptr() + 4 * lo          # a view, not a copy
+        if case == "fp16_2":      # a decoded copy of the partition's columns: equal to the same columns of the whole batch's decoding
+            torch.cuda.synchronize()
+            assert torch.equal(o, split.batch.rows_f32(0, 13)[lo:hi])
+        else:
+            assert o.data_ptr() == split.batch.state.data_ptr() + 4 * lo          # a view, not a copy
     torch.cuda.synchronize()
     a, b = one.batch, split.batch
-    for name in ("state", "reward", "done_u8", "done_bits", "ep_return", "ep_length", "last_return", "last_length", "noise_state", "action_out"):
+    for name in ("state", "state_h", "reward", "done_u8", "done_bits", "ep_return", "ep_length", "last_return", "last_length", "noise_state", "action_out"):
         x, y = getattr(a, name, None), getattr(b, name, None)
         if x is not None:
-            assert torch.equal(x, y), (case, name)
+            assert torch.equal(x.view(torch.int16) if name == "state_h" else x, y.view(torch.int16) if name == "state_h" else y), (case, name)
     assert int(a.last_length.max()) > 0, "auto-reset must have ended episodes"
     # step(): all partitions at once, still the same bits; a checkpoint of the split env continues in an unpartitioned one
     act = (torch.rand((n, 4), device=DEV) * 2 - 1) * (1.0 if case != "racer2" else 4.0)
     one.step(act); split.step(act)
     torch.cuda.synchronize()
     assert torch.equal(a.state, b.state) and torch.equal(a.done_u8, b.done_u8)
+    if case == "fp16_2":
+        assert torch.equal(a.state_h.view(torch.int16), b.state_h.view(torch.int16))
     # the mask redirected to a caller's row (what a collective's bucket is): every partition writes its own words of it
     row_a, row_b = (torch.full(((n + 63) // 64,), -1, dtype=torch.int64, device=DEV) for _ in range(2))
     one.batch.set_done_bits_target(row_a); split.set_done_bits_target(row_b)
@@ -665,8 +673,6 @@ def test_split_phase_api_errors(params_1k):
     env = FpvVecEnv(params_1k, num_envs=1000, device=DEV)
     with pytest.raises(RuntimeError):
         env.step_async(0, torch.zeros((1000, 4), device=DEV))
-    with pytest.raises(ValueError):
-        FpvVecEnv(params_1k, num_envs=1000, device=DEV, partitions=2, fp16_state=True)
     two = FpvVecEnv(params_1k, num_envs=1000, device=DEV, partitions=2)
     two.reset()
     lo, hi = two.partition_range(1)

@@ -30,7 +30,7 @@ ap.add_argument("--rounds", type=int, default=8)
 ap.add_argument("--only", nargs="*", default=None)
 ap.add_argument("--extra", nargs="*", default=[], help="name=flag,flag,... additional variants")
 ap.add_argument("--lib", nargs="*", default=[], help="name=path/to/lib.so: a ready-built library (e.g. an older commit) as a variant")
-ap.add_argument("--geom", default="f32", choices=["f32", "kahan", "racerW", "racerD", "racerWC", "aos", "noise"],
+ap.add_argument("--geom", default="f32", choices=["f32", "kahan", "racerW", "racerD", "racerWC", "aos", "noise", "fp16"],
                 help="which kernel family to time: the plain drone kernel, + Kahan rows, the Racer as written / omega*dt / components.PID, the AoS observation head")
 a = ap.parse_args()
 for e in a.extra:
@@ -69,7 +69,7 @@ if a.geom.startswith("racer"):
     import numpy as np
     p = p.replace(mode=1, racer_pid=np.asarray([[0.004, 0.02, 1e-6], [0.003, 0.01, 2e-6], [0.002, 0.005, 0.0]]),
                   racer_omega_dt=(a.geom == "racerD"), racer_pid_variant=int(a.geom == "racerWC"), ceiling=100.0)
-cp = _lib.pack_params(p, auto_reset=True, stick_noise=(a.geom == "noise"), noise_seed=11)
+cp = _lib.pack_params(p, auto_reset=True, stick_noise=(a.geom == "noise"), noise_seed=11, fp16_state=(a.geom == "fp16"))
 n = a.n
 ring = 32 if n <= (1 << 21) else 4
 acts = sticks.ema_noise_device(ring, n, dev)
@@ -98,6 +98,9 @@ extra = None
 if a.geom == "kahan":
     extra = torch.zeros((6, ld), device=dev)
     b.pos_comp = extra.data_ptr()
+elif a.geom == "fp16":
+    extra = torch.zeros(_lib.FPV_HALF_HALVES * ld, dtype=torch.float16, device=dev)
+    b.state_h, b.rounding_seed = extra.data_ptr(), 5
 elif a.geom == "noise":
     extra = torch.zeros((4, ld), device=dev)
     b.noise_state = extra.data_ptr()
@@ -109,6 +112,8 @@ elif a.geom == "aos":
 
 def reset():
     st.zero_()
+    if a.geom == "fp16":
+        extra.zero_()
     rc = L[names[0]].fpv_reset(H[names[0]], C.byref(b), None, None, None, None, None)
     assert rc == 0, L[names[0]].fpv_last_error()
 
