@@ -386,6 +386,8 @@ def parse_args(argv=None):
                     help="TEST ONLY (with --stub-step): what the preflight children do")
     ap.add_argument("--stub-fail-collective", choices=["", "rccl", "gloo", "all"], default="",
                     help="TEST ONLY (with --stub-step): workers started with this --collective (or all) exit 1 after the rendezvous")
+    ap.add_argument("--stub-hang-collective", choices=["", "rccl", "gloo"], default="",
+                    help="TEST ONLY (with --stub-step): workers started with this --collective never come back (a collective that hangs)")
     ap.add_argument("--stub-fail-rank", type=int, default=-1,
                     help="TEST ONLY (tests/test_bench_spawn.py): this rank exits 1 before it joins the process group")
     ap.add_argument("--stub-step", action="store_true",
@@ -452,6 +454,9 @@ def run_stub(args, world, rank, collective="rccl"):
         if args.stub_fail_collective in (collective, "all"):
             print(f"stub: the {collective} collective of rank {rank} fails", file=sys.stderr)
             raise SystemExit(1)
+        if args.stub_hang_collective == collective and rank == world - 1:
+            print(f"stub: rank {rank} hangs in the {collective} collective", file=sys.stderr)
+            time.sleep(3600)
     words = (args.drones_per_gpu + 63) // 64
     gather = DoneGather((words,), torch.int64, "cpu", block=args.gather_block) if world > 1 and collective != "none" and not args.no_gather else None
     if world > 1:

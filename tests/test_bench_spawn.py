@@ -120,6 +120,28 @@ def test_a_run_that_fails_in_the_collective_is_repeated_with_the_fallback():
     assert "the run with --collective rccl failed" in r.stderr
 
 
+def test_a_run_that_hangs_in_the_collective_is_stopped_and_repeated_with_the_fallback():
+    """The likeliest way for RCCL to fail on an unknown node is not an error but a hang: one rank never comes back from
+    the collective.  Its supervisor stops it at the attempt limit (the peers' workers leave through the process-group
+    timeout or are stopped too), all ranks agree that the attempt failed, and fresh workers run over gloo."""
+    r, lines, took = _run_stub(["--stub-hang-collective", "rccl", "--attempt-timeout-s", "8", "--pg-timeout-s", "6"])
+    assert r.returncode == 0, r.stderr[-3000:]
+    assert len(lines) == 1
+    c = json.loads(lines[0])["collective"]
+    assert [(a["collective"], a["ok"]) for a in c["attempts"]] == [("rccl", False), ("gloo", True)]
+    assert c["used"] == "gloo" and "no result within 8 s" in c["fallback_reason"]
+    assert took < 150, took
+    import time
+    left = []
+    for _ in range(20):                 # a stopped worker may take a moment to be reaped; none may survive
+        left = [ln for ln in subprocess.run(["pgrep", "-af", "stub-hang-collective rccl"], capture_output=True, text=True).stdout.splitlines()
+                if "pgrep" not in ln]
+        if not left:
+            break
+        time.sleep(0.5)
+    assert not left, f"workers left behind: {left}"
+
+
 def test_when_every_fallback_fails_the_job_fails_within_the_limit():
     r, lines, took = _run_stub(["--stub-fail-collective", "all"])
     assert r.returncode != 0 and not lines
