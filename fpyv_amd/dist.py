@@ -342,7 +342,7 @@ class RankSupervisor:
         import sys
         port = self.pick_port()
         cmd = [python or sys.executable, "-m", "fpyv_amd.dist", "--preflight", "--limit-s", str(limit_s)] + (["--stub", stub] if stub else [])
-        r = run_child(cmd, self.child_env(port, ipc_mode), limit_s + 15.0, capture_stdout=True, on_start=self.track)
+        r = run_child(cmd, self.child_env(port, ipc_mode), limit_s + min(15.0, max(2.0, limit_s)), capture_stdout=True, on_start=self.track)   # + start-up of the child
         ok = r["rc"] == 0
         info = None
         if ok:
