@@ -822,9 +822,7 @@ class FpvVecEnv:
         if self._parts:                      # the partitions' chains start after the reset (enqueued on the caller's stream)
             cur = torch.cuda.current_stream(self.batch.device)
             for P in self._parts:
-                P.stream.wait_stream(cur)
-                if mask is None:
-                    P.set_step_counter(self.batch._steps_launched)
+                P.stream.wait_stream(cur)              # (the step counters run on, as the unpartitioned batch's does across a reset)
         return self.obs
 
     def step(self, action) -> Tuple[torch.Tensor, torch.Tensor, torch.Tensor, Dict[str, Any]]:

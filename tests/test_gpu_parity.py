@@ -656,8 +656,17 @@ def test_split_phase_partitions_are_bitwise_the_single_batch(params_1k, case):
     torch.cuda.synchronize()
     assert torch.equal(row_a, row_b) and torch.equal(a.state, b.state)
     one.batch.set_done_bits_target(None); split.set_done_bits_target(None)
+    if case == "noise3":
+        # a reset in the middle of a run: the stick-noise streams are keyed by the step counter, which runs on across a reset
+        # in the single batch - and must in every partition
+        one.reset(); split.reset()
+        for _ in range(3):
+            one.step(act); split.step(act)
+        torch.cuda.synchronize()
+        assert torch.equal(a.state, b.state) and torch.equal(a.noise_state, b.noise_state) and torch.equal(a.action_out, b.action_out)
     ck = split.state_dict()
-    assert ck["partition_step_counters"] == [T + 2] * parts and ck["step_counter"] == T + 2
+    steps_done = T + 2 + (3 if case == "noise3" else 0)
+    assert ck["partition_step_counters"] == [steps_done] * parts and ck["step_counter"] == steps_done
     third = FpvVecEnv(p, **kw)
     third.reset()
     third.batch.load_state_dict({k: v for k, v in ck.items() if k != "partition_step_counters"})
