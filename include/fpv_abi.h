@@ -204,6 +204,11 @@ typedef struct fpv_buffers {
                                 caller-supplied sticks; combines with objects / FPV_FLAG_GROUND */
     const float* thrust_override;   /* [n] thrust_force [N] of the same call; required with rotation_override.  A NaN entry
                                 leaves that drone un-overridden (its own attitude and low-passed thrust) */
+    int32_t action_f16;      /* 0: `action` holds fp32 sticks; 1: IEEE binary16 sticks, rows [n][4] (8 bytes per drone; action_ld must
+                                be 0; fpv_step, fpv_rollout and fpv_rollout_graph only - their strides still count stick VALUES) - what a policy that runs in half
+                                precision produces: consumed as it is (one 8-byte load per drone), widened in registers; the step is
+                                bit for bit that of the same sticks given as fp32 */
+    int32_t reserved0;
     uint16_t* state_h_thrust;/* FPV_FLAG_FP16_STATE: the row of prev_thrust halves when it does NOT follow the pair rows at
                                 state_h + 2 * FPV_HALF_PAIR_ROWS * ld - i.e. for a handle that steps a column range [lo, hi) of a
                                 larger batch (state_h moved by 2 * lo halves, this pointer = the batch's thrust row + lo halves;

@@ -29,7 +29,7 @@ def _design():
 
 def test_no_scratch_no_mfma_no_spill_in_any_kernel(isa):
     h, bodies, res = isa
-    assert len(bodies) == 41 and len(res) >= 41
+    assert len(bodies) == 51 and len(res) >= 51
     for name, body in bodies.items():
         c = h.counts(body)
         assert c["scratch_flat_buffer"] == 0, name
@@ -37,7 +37,7 @@ def test_no_scratch_no_mfma_no_spill_in_any_kernel(isa):
         assert c["sgpr_spill_lane_ops"] == 0, name
     for name, r in res.items():
         assert r.get("scratch", 0) == 0 and r.get("sspill", 0) == 0 and r.get("vspill", 0) == 0, (name, r)
-    assert "41 kernels" in _design()
+    assert "51 kernels" in _design()
 
 
 def test_plain_step_kernel_counts_as_design_quotes(isa):
@@ -46,7 +46,7 @@ def test_plain_step_kernel_counts_as_design_quotes(isa):
     h, bodies, res = isa
     name = next(n for n in bodies if h.HOT["plain single-step kernel fpv_drone_step_kernel<false,false,false,false>"] in n)
     body, c, r = bodies[name], h.counts(bodies[name]), res[name]
-    assert c["global_load"] == 21 and c["global_store"] == 24 and c["v_med3_f32"] == 3 and c["lds"] == 0
+    assert c["global_load"] == 21 and c["global_store"] == 24 and c["v_med3_f32"] == 3 and c["lds"] == 0     # 14 rows + the two fp32 stick layouts (1 + 4) + 2 episode
     block = h.load_block(body)
     state_loads = [ln for ln in block if re.match(r"global_load_dword v\d+, v\[\d+:\d+\], off", ln)]
     assert len(state_loads) == 14, "the 14 fp32 state rows: 64-bit address in a VGPR pair"
@@ -60,6 +60,9 @@ def test_plain_step_kernel_counts_as_design_quotes(isa):
 
 def test_fp16_and_kstep_kernels_as_design_quotes(isa):
     h, bodies, res = isa
+    f16a = next(n for n in bodies if "fpv_drone_step_kernelILb0ELb0ELb0ELb0ELb1EEE" in n)      # the plain kernel for binary16 sticks
+    assert any(re.match(r"global_load_dwordx2 v\[\d+:\d+\], v\d+, s\[\d+:\d+\] nt", ln) for ln in bodies[f16a]), "one 8-byte stick load"
+    assert not any(ln.startswith("global_load_dwordx4") for ln in bodies[f16a])
     hk = next(n for n in bodies if "fpv_drone_step_h_kernel" in n)
     kk = next(n for n in bodies if h.HOT["plain k-step kernel fpv_drone_rollout_kernel<false,false,false,true>"] in n)
     assert res[hk]["occ"] == 8 and res[hk]["sspill"] == 0

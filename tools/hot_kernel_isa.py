@@ -19,7 +19,7 @@ REPO = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, REPO)
 SRC = os.path.join(REPO, "fpyv_amd", "csrc", "fpv_hip.hip")
 HOT = collections.OrderedDict([
-    ("plain single-step kernel fpv_drone_step_kernel<false,false,false,false>", "fpv_drone_step_kernelILb0ELb0ELb0ELb0E"),
+    ("plain single-step kernel fpv_drone_step_kernel<false,false,false,false>", "fpv_drone_step_kernelILb0ELb0ELb0ELb0ELb0EEE"),
     ("fp16-state single-step kernel fpv_drone_step_h_kernel", "fpv_drone_step_h_kernel"),
     ("plain k-step kernel fpv_drone_rollout_kernel<false,false,false,true>", "fpv_drone_rollout_kernelILb0ELb0ELb0ELb1E"),
 ])
@@ -95,16 +95,13 @@ def resources(remarks):
 
 
 def load_block(lines):
-    """the instructions from the first vector load to the first wait for vector memory"""
-    out, started = [], False
-    for ln in lines:
-        if ln.startswith("global_load"):
-            started = True
-        if started:
-            out.append(ln)
-            if ln.startswith("s_waitcnt vmcnt"):
-                break
-    return out
+    """the instructions from the first vector load to the wait that follows the LAST vector load issued before any store (the rare
+    binary16-sticks branch has a wait of its own in the middle: it belongs to the block)"""
+    first = next(k for k, ln in enumerate(lines) if ln.startswith("global_load"))
+    store = next((k for k, ln in enumerate(lines) if ln.startswith("global_store")), len(lines))
+    last = max(k for k, ln in enumerate(lines[:store]) if ln.startswith("global_load"))
+    end = next((k for k in range(last, len(lines)) if lines[k].startswith("s_waitcnt vmcnt")), last)
+    return lines[first:end + 1]
 
 
 def report():
