@@ -2271,3 +2271,36 @@ def test_binary16_sticks_equal_the_same_sticks_as_fp32(params_1k, kind):
     assert L.fpv_step(e._handle, C.byref(b), None) == 0
     assert L.fpv_step_n(e._handle, C.byref(b), 1, 0, 0, None) == -1 and b"fp32 action rows" in L.fpv_last_error()
     torch.cuda.synchronize()
+
+
+@pytest.mark.parametrize("extra", [[], ["--partitions", "2"], ["--api", "rollout"]], ids=["step", "partitions2", "rollout"])
+def test_bench_line_schema_small(extra):
+    """bench.py end to end at a small size: ONE JSON line with the contract's keys, `roofline` (achieved / peak / frac / traffic /
+    sustained leg for the step API) and - N = 1, step API - `cpu_baseline`; the split-phase line says how its streams were chosen;
+    the k-step line without a counted instruction mix for this size keeps bound = "hbm" and says why."""
+    import json
+    import os
+    import subprocess
+    import sys
+    from conftest import REPO
+    r = subprocess.run([sys.executable, os.path.join(REPO, "bench.py"), "--steps", "40", "--warmup", "8", "--drones-per-gpu", str(1 << 16),
+                        "--sustained-steps", "64", "--no-beyond-mall", "--preheat-s", "0.05", "--no-cpu-baseline"] + extra,
+                       capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0, r.stderr[-3000:]
+    lines = [ln for ln in r.stdout.splitlines() if ln.strip()]
+    assert len(lines) == 1, lines
+    d = json.loads(lines[0])
+    for k in ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better", "scaling", "vs_baseline", "dtype", "data", "config", "roofline"):
+        assert k in d, k
+    assert d["n_gpus"] == 1 and d["steps"] == 40 and d["warmup"] == 8 and d["unit"] == "env-steps/s" and d["dtype"] == "f32" and d["vs_baseline"] is None
+    assert d["value"] > 1e8 and abs(d["value"] - (1 << 16) * 40 / (d["ms_per_step"] * 40e-3)) < 1e-3 * d["value"]
+    ro = d["roofline"]
+    assert ro["peak"] == 8000.0 and 0 < ro["frac"] < 1 and abs(ro["frac"] - ro["achieved"] / ro["peak"]) < 1e-9 and ro["traffic"] is None   # traffic is quoted for the headline size only
+    if extra[:1] == ["--api"]:
+        assert ro["bound"] == "hbm" and ro["valu"] is None and "configuration" in ro["valu_unavailable"]
+        assert d["config"]["steps_per_launch"] > 1
+    else:
+        assert ro["bound"] == "hbm" and ro["sustained"]["launches"] == 64 and ro["sustained"]["avg_launch_us"] > 0
+        assert d["config"]["partitions"] == (2 if extra else 1)
+        if extra:
+            assert d["config"]["partition_streams"]["verified"] is True
