@@ -13,7 +13,7 @@ from typing import Optional
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, "libfpv_hip.so")
 
-FPV_ABI_VERSION = 5
+FPV_ABI_VERSION = 6
 FPV_OK = 0
 FPV_MODE_DRONE, FPV_MODE_RACER = 0, 1
 FPV_DRONE_ROWS, FPV_RACER_ROWS = 14, 29
@@ -102,7 +102,7 @@ class FpvBuffers(C.Structure):
         ("wind", C.c_float * 3), ("rounding_seed", C.c_uint32), ("state_h", C.c_void_p),
         ("pos_comp", C.c_void_p), ("noise_state", C.c_void_p), ("action_out", C.c_void_p), ("action_ld", C.c_int64), ("objects", C.c_void_p), ("obs_aos", C.c_void_p),
         ("done_bits_stride", C.c_int64), ("rotation_override", C.c_void_p), ("thrust_override", C.c_void_p),
-        ("action_f16", C.c_int32), ("reserved0", C.c_int32), ("state_h_thrust", C.c_void_p),
+        ("state_h_thrust", C.c_void_p),
     ]
 
 

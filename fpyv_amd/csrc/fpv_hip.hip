@@ -1,7 +1,7 @@
 // fpv_hip.hip - gfx950 kernels + the C ABI of include/fpv_abi.h.
 //
 // One lane = one drone: every wave instruction touches 256 contiguous bytes of one SoA row.  Measured on MI355X
-// (tools/exp, profiles/r01_exp_*.log, r03_exp_wide_rows_beyond_mall.log): 128-thread workgroups beat 64/256/512/1024,
+// (profiles/r01_exp_*.log, r03_exp_wide_rows_beyond_mall.log): 128-thread workgroups beat 64/256/512/1024,
 // one drone per lane beats 2/4 with float2/float4 rows at 2^20 AND at 2^23 drones, persistent/grid-stride/prefetch
 // loops lose to plain oversubscription, non-temporal hints on the once-touched operands (action in, reward/done out)
 // are worth ~0.5 %, and a row stride that is NOT a multiple of 8 KiB is worth 6-9 % (fpv_recommended_ld).  A step is:
@@ -84,7 +84,7 @@ __device__ __forceinline__ T& row_at(T* row_base, uint32_t i)
 }
 #define ROW(st, r, ld) ((st) + (int64_t)(r) * (ld))
 
-// ---- experiment hooks (tools/exp/ab_variants.py builds variants with -DFPV_EXP_*; the shipped values are the defaults)
+// ---- experiment hooks (tools/ab_variants.py builds variants with -DFPV_EXP_*; the shipped values are the defaults)
 #ifndef FPV_EXP_LD_NT
 #define FPV_EXP_LD_NT 0
 #endif
@@ -134,29 +134,8 @@ __device__ __forceinline__ float4 ld_action(const float4* __restrict__ a, uint32
     return make_float4(v.x, v.y, v.z, v.w);
 }
 
-// binary16 sticks [n][4] (a policy that runs in half precision hands its output over as it is): ONE 8-byte load per lane,
-// widened in registers.  Device-side the format rides in action_ld (already a leading, preloaded scalar of the
-// single-step kernels): 0 = fp32 rows, > 0 = fp32 SoA with that row stride, FPV_ACTION_LD_F16 (-1) = binary16 rows.
-#define FPV_ACTION_LD_F16 ((int64_t)-1)
-typedef uint32_t fpv_v2u __attribute__((ext_vector_type(2)));
-__device__ __forceinline__ float4 ld_action_h(const float4* __restrict__ a, uint32_t i)
-{
-    const fpv_v2u v = __builtin_nontemporal_load(&row_at(reinterpret_cast<const fpv_v2u*>(a), i));
-    return make_float4(fpv_f16_to_f32((uint16_t)v.x), fpv_f16_to_f32((uint16_t)(v.x >> 16)),
-                       fpv_f16_to_f32((uint16_t)v.y), fpv_f16_to_f32((uint16_t)(v.y >> 16)));
-}
-
-// rows in either precision (the single-step fp16-state, AoS and Racer kernels: no SoA there; the k-step kernels read fp32 rows
-// only - a format test inside their loop cost 5 % in a one-process A/B, and a pre-computed batch can be cast once)
-__device__ __forceinline__ float4 ld_action_rows(const float4* __restrict__ a, int64_t action_ld, uint32_t i)
-{
-    return action_ld < 0 ? ld_action_h(a, i) : ld_action(a, i);
-}
-
-// either fp32 layout: rows [n][4] (one 16-byte load) or SoA [4][action_ld] (four dword loads) - the latter is what
-// `W[4,13] @ obs[13,n]` produces, so a policy can feed the stepper without a transpose kernel.  (binary16 rows are a
-// template switch of the drone step kernel, F16A: a third arm HERE changed the code generation of the whole plain kernel -
-// its 14 row loads flipped to another addressing form - for a format the headline never sees)
+// either layout: rows [n][4] (one 16-byte load) or SoA [4][action_ld] (four dword loads) - the latter is
+// what `W[4,13] @ obs[13,n]` produces, so a policy can feed the stepper without a transpose kernel
 __device__ __forceinline__ float4 ld_action_any(const float4* __restrict__ a, int64_t action_ld, uint32_t i)
 {
     if (action_ld == 0) return ld_action(a, i);
@@ -297,9 +276,6 @@ __device__ __forceinline__ float4 apply_stick_noise(const FpvK& K, const FpvBufD
 // matrices arrive in the caller's [n][3][3] layout; this is the closed-loop guidance path, not the headline one.
 // One drone per lane, kStepBlock threads per workgroup: 2 / 4 drones per lane and 256-thread workgroups lost every
 // measurement of rounds 1-2 (profiles/r01_exp10_shapes_clean.log, r02_sweep_geometry.log) and were removed in round 3.
-#ifndef FPV_EXP_PLAIN_VIEWS
-#define FPV_EXP_PLAIN_VIEWS 0
-#endif
 #ifdef FPV_EXP_STEP_WAVES
 #define FPV_EXP_STEP_ATTR __attribute__((amdgpu_waves_per_eu(FPV_EXP_STEP_WAVES)))
 #else
@@ -312,7 +288,7 @@ __device__ __forceinline__ float4 apply_stick_noise(const FpvK& K, const FpvBufD
 // kernel-argument segment in SGPRs at wave launch, so a wave issues its 15 vector loads at once instead of first
 // waiting for a scalar load of those pointers - a cold one at every kernel start, because the scalar cache and L2
 // are invalidated at the kernel boundary.  It is the head of the per-launch floor of a chain of dependent step
-// kernels (tools/exp/launch_floor.py).  (Firmware without the feature runs the compiler's compatibility
+// kernels (profiles/r03_exp_launch_floor.log).  (Firmware without the feature runs the compiler's compatibility
 // prologue, which loads the same prefix with s_load: same results either way.)  The structs that follow still carry
 // the same fields; fpv_step_view() overrides them, so their kernarg copies are never loaded.
 #define FPV_STEP_PARAMS float* __restrict__ a_state, const int64_t a_ld, const float4* __restrict__ a_action, \
@@ -341,17 +317,10 @@ __device__ __forceinline__ const FpvStepArgs& fpv_step_args_again()
     return *(const FpvStepArgs*)p;
 }
 
-template <bool NOISE = false, bool OBJ = false, bool KAHAN = false, bool OVR = false, bool F16A = false>
+template <bool NOISE = false, bool OBJ = false, bool KAHAN = false, bool OVR = false>
 __global__ __launch_bounds__(kStepBlock) FPV_EXP_STEP_ATTR void fpv_drone_step_kernel(FPV_STEP_PARAMS)
 {
-    // SECTIONED: the arguments outside the preloaded prefix are re-read per section through an opaque pointer and the store
-    // addresses are formed late - for the instantiations that are short of registers.  NOT for the plain kernel: its
-    // argument loads sit at the kernel entry, ahead of the row loads (with an s_waitcnt lgkmcnt(0) between them, a
-    // write-after-write hazard of two scalar loads), and moving them behind the row loads by the same views was measured
-    // SLOWER (-DFPV_EXP_PLAIN_VIEWS=1: 22.36 against 22.21 us, Kahan rows 29.35 against 28.79; profiles/r04_exp_plain_views_ab.log):
-    // the constants then arrive after the rows instead of with them.
     constexpr bool SECTIONED = NOISE || (OBJ && OVR);
-    constexpr bool VIEWS = SECTIONED || (FPV_EXP_PLAIN_VIEWS != 0);
     FPV_STEP_VIEW;
     __shared__ FpvNormalRow ntab[NOISE ? FPV_NTAB_ROWS : 1];
     if (NOISE) stage_normal_table(ntab);
@@ -362,7 +331,7 @@ __global__ __launch_bounds__(kStepBlock) FPV_EXP_STEP_ATTR void fpv_drone_step_k
     FpvDroneState s;
     float ro[9] = {1.f, 0.f, 0.f, 0.f, 1.f, 0.f, 0.f, 0.f, 1.f}, to = 0.0f;
     // ---- 1. issue every load of this lane before the first use; the sticks
-    float4 a = (!NOISE || B.action) ? (F16A ? ld_action_h(B.action, i) : ld_action_any(B.action, B.action_ld, i)) : make_float4(0.f, 0.f, 0.f, 0.f);
+    float4 a = (!NOISE || B.action) ? ld_action_any(B.action, B.action_ld, i) : make_float4(0.f, 0.f, 0.f, 0.f);
     ld_drone(B.state, B.ld, i, s);
     if (NOISE) a = apply_stick_noise(K, B, i, a, ntab);
     if (OVR) {
@@ -376,9 +345,9 @@ __global__ __launch_bounds__(kStepBlock) FPV_EXP_STEP_ATTR void fpv_drone_step_k
     __builtin_amdgcn_sched_barrier(0);
     // ---- 2. the physics, on its own view of the constants when SECTIONED
     const FpvStepArgs* P = nullptr;
-    if (VIEWS) P = &fpv_step_args_again();
-    const FpvK& Kp = VIEWS ? P->K : K;
-    const FpvBufD& Bp = VIEWS ? P->B : B;
+    if (SECTIONED) P = &fpv_step_args_again();             // (the opaque view is a volatile asm: not even emitted for the plain kernel)
+    const FpvK& Kp = SECTIONED ? P->K : K;
+    const FpvBufD& Bp = SECTIONED ? P->B : B;
     float kc[6];
     if (KAHAN) {
 #pragma unroll
@@ -393,11 +362,10 @@ __global__ __launch_bounds__(kStepBlock) FPV_EXP_STEP_ATTR void fpv_drone_step_k
     uint32_t j = i;
     if (OBJ || SECTIONED) FPV_KEEP_HERE(j);
     const FpvStepArgs* E = nullptr;
-    if (VIEWS) E = &fpv_step_args_again();
-    const FpvK& Ke = VIEWS ? E->K : K;
+    if (SECTIONED) E = &fpv_step_args_again();
+    const FpvK& Ke = SECTIONED ? E->K : K;
     FpvBufD Bs = B;
     if (SECTIONED) { Bs = E->B; Bs.state = E->state; Bs.ld = E->ld; }
-    else if (VIEWS) { Bs = E->B; Bs.state = a_state; Bs.ld = a_ld; }      // the preloaded base and stride: the row addresses of the loads are reused
     const FpvBufD& Be = Bs;
     if (KAHAN) {
         const bool rst = (Ke.flags & FPV_FLAG_AUTO_RESET) && o.done;
@@ -460,7 +428,6 @@ __device__ __forceinline__ const FpvRollArgs& fpv_args_again()
 #ifndef FPV_EXP_PREFETCH2
 #define FPV_EXP_PREFETCH2 0
 #endif
-
 template <bool NOISE, bool OBJ, bool KAHAN, bool SQ = false>
 __global__ __launch_bounds__(kStepBlock) FPV_EXP_ROLL_ATTR void fpv_drone_rollout_kernel(const FpvRollArgs A)
 {
@@ -472,7 +439,7 @@ __global__ __launch_bounds__(kStepBlock) FPV_EXP_ROLL_ATTR void fpv_drone_rollou
     FpvDroneState s;
     const int k = A.R.k;
     const bool has_action = !NOISE || A.B.action;
-    float4 a_next = has_action ? ld_action(A.B.action, i) : make_float4(0.f, 0.f, 0.f, 0.f);     // fp32 rows only (fpv_step_n)
+    float4 a_next = has_action ? ld_action(A.B.action, i) : make_float4(0.f, 0.f, 0.f, 0.f);     // rows only (fpv_step_n)
     ld_drone(A.B.state, A.B.ld, i, s);
     float ns[4] = {0.f, 0.f, 0.f, 0.f}, kc[6] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
     if (NOISE) {
@@ -538,8 +505,8 @@ __global__ __launch_bounds__(kStepBlock) FPV_EXP_ROLL_ATTR void fpv_drone_rollou
         const int64_t bstride = A.R.bits_stride;
 #if FPV_EXP_VCONST
         // The physics constants of the loop as VECTOR registers.  On gfx950 a VALU instruction with an SGPR source
-        // issues in ~4.2 cycles per SIMD against ~2.4 for the same instruction on two VGPRs (tools/exp/issue/
-        // issue_probe.hip, profiles/r03_exp_issue_probe.log), and about a quarter of this loop's instructions read
+        // issues in ~4.2 cycles per SIMD against ~2.4 for the same instruction on two VGPRs (a hand-written issue
+        // probe, profiles/r03_exp_issue_probe.log), and about a quarter of this loop's instructions read
         // one of these uniforms.  A copy of the arguments whose hot fields went through a "+v" constraint keeps them in
         // VGPRs for the k steps (one v_mov each, before the loop).
         FpvRollArgs Q;
@@ -639,7 +606,7 @@ __global__ __launch_bounds__(kStepBlock) void fpv_drone_step_aos_kernel(FPV_STEP
     o.done = false; o.reward = 0.0f; o.ax = o.ay = o.az = 0.0f;
     if (live) {
         FpvDroneState s;
-        const float4 a = ld_action_rows(B.action, B.action_ld, i);
+        const float4 a = ld_action(B.action, i);
         ld_drone(B.state, B.ld, i, s);
         o = fpv_drone_step_lane<false>(K, s, a.x, a.y, a.z, a.w, B.wx, B.wy, B.wz);
         if (B.accel) {
@@ -732,7 +699,7 @@ __global__ __launch_bounds__(kStepBlock) void fpv_drone_step_h_kernel(FPV_STEP_P
     uint32_t th = 0;
     if (live) {
         FpvDroneState s;
-        const float4 a = ld_action_rows(B.action, B.action_ld, i);
+        const float4 a = ld_action(B.action, i);
         ld_drone_h(B, i, s);
         __builtin_amdgcn_sched_barrier(0);       // loads first, constants after (see fpv_drone_step_kernel)
         o = fpv_drone_step_lane<false, true, false, false>(K, s, a.x, a.y, a.z, a.w, B.wx, B.wy, B.wz);
@@ -879,7 +846,7 @@ __global__ __launch_bounds__(kStepBlock) void fpv_racer_step_kernel(FPV_STEP_PAR
     const uint32_t i = blockIdx.x * (uint32_t)kStepBlock + threadIdx.x;
     if (i >= n) return;
     FpvRacerState s;
-    const float4 a = ld_action_rows(B.action, B.action_ld, i);
+    const float4 a = ld_action(B.action, i);
     ld_racer<WIDE, PIDV>(B.state, B.ld, i, s);
     __builtin_amdgcn_sched_barrier(0);
     const float reward = fpv_racer_step_lane<WIDE, PIDV ? 1 : 0>(K, s, a.x, a.y, a.z, a.w);
@@ -1150,8 +1117,6 @@ int check_buffers(const fpv_env* h, const fpv_buffers_t* b, bool need_action)  /
         if (b->obs_aos) return fail(FPV_EINVAL, "obs_aos and FPV_FLAG_STICK_NOISE cannot be combined");
     }
     if ((uintptr_t)b->action_out & 15) return fail(FPV_EALIGN, "action_out must be 16-byte aligned");
-    if (b->action_f16 && b->action_ld) return fail(FPV_EINVAL, "binary16 sticks (action_f16) are rows [n][4]: action_ld must be 0");
-    if (b->action_f16 != 0 && b->action_f16 != 1) return fail(FPV_EINVAL, "action_f16 is 0 (fp32 sticks) or 1 (binary16 sticks)");
     if (b->action_ld) {
         if (b->action_ld < h->n) return fail(FPV_EALIGN, "action_ld must be >= n");   // dword loads: no alignment rule
         if (h->mode != FPV_MODE_DRONE || (h->K.flags & FPV_FLAG_FP16_STATE) || b->obs_aos)
@@ -1159,8 +1124,8 @@ int check_buffers(const fpv_env* h, const fpv_buffers_t* b, bool need_action)  /
     }
     if (b->ld < h->n) return fail(FPV_EALIGN, "fpv_buffers_t.ld is smaller than the number of drones");
     if (b->ld % 4) return fail(FPV_EALIGN, "fpv_buffers_t.ld must be a multiple of 4 floats");
-    if (((uintptr_t)b->state & 15) || ((uintptr_t)b->action & (b->action_f16 ? 7 : 15)))
-        return fail(FPV_EALIGN, "state and action must be 16-byte aligned (binary16 sticks: 8-byte)");
+    if (((uintptr_t)b->state & 15) || ((uintptr_t)b->action & 15))
+        return fail(FPV_EALIGN, "state and action must be 16-byte aligned");
     if ((uintptr_t)b->done_bits & 7) return fail(FPV_EALIGN, "done_bits must be 8-byte aligned");
     if (b->done_bits_stride && (b->done_bits_stride < (h->n + 63) / 64))
         return fail(FPV_EALIGN, "done_bits_stride must be 0 or >= ceil(n / 64) words");
@@ -1218,7 +1183,7 @@ FpvBufD to_device_view(const fpv_buffers_t* b, float reach)
     d.state_h = b->state_h; d.seed = b->rounding_seed; d.obs_aos = b->obs_aos;
     d.pos_comp = b->pos_comp;
     d.noise_state = b->noise_state; d.action_out = reinterpret_cast<float4*>(b->action_out); d.step = 0;
-    d.action_ld = b->action_f16 ? FPV_ACTION_LD_F16 : b->action_ld;       // the device-side encoding of the stick format (ld_action_any)
+    d.action_ld = b->action_ld;
     d.rot_over = b->rotation_override; d.thrust_over = b->thrust_override;
     d.thrust_h = b->state_h_thrust ? b->state_h_thrust : (b->state_h ? b->state_h + (int64_t)2 * FPV_HALF_PAIR_ROWS * b->ld : nullptr);
     d.objs.count = 0;
@@ -1259,27 +1224,20 @@ struct DeviceGuard {
 typedef void (*StepKernel)(float*, const int64_t, const float4*, const int64_t, uint16_t*, const int64_t, const FpvK, const FpvBufD);
 struct KernelChoice { StepKernel func; unsigned grid, block; };
 
-template <bool F16A>
-StepKernel drone_kernel_f(bool noise, bool obj, bool kahan)
+StepKernel drone_kernel(bool noise, bool obj, bool kahan)
 {
     // optional features of the step kernel are independent template switches (in-kernel stick noise x object_list
     // collisions x Kahan rows), each combination its own instantiation, so the plain kernel keeps its register budget
     switch ((noise ? 4 : 0) | (obj ? 2 : 0) | (kahan ? 1 : 0)) {
-        case 0: return fpv_drone_step_kernel<false, false, false, false, F16A>;
-        case 1: return fpv_drone_step_kernel<false, false, true, false, F16A>;
-        case 2: return fpv_drone_step_kernel<false, true, false, false, F16A>;
-        case 3: return fpv_drone_step_kernel<false, true, true, false, F16A>;
-        case 4: return fpv_drone_step_kernel<true, false, false, false, F16A>;
-        case 5: return fpv_drone_step_kernel<true, false, true, false, F16A>;
-        case 6: return fpv_drone_step_kernel<true, true, false, false, F16A>;
-        default: return fpv_drone_step_kernel<true, true, true, false, F16A>;
+        case 0: return fpv_drone_step_kernel<false, false, false>;
+        case 1: return fpv_drone_step_kernel<false, false, true>;
+        case 2: return fpv_drone_step_kernel<false, true, false>;
+        case 3: return fpv_drone_step_kernel<false, true, true>;
+        case 4: return fpv_drone_step_kernel<true, false, false>;
+        case 5: return fpv_drone_step_kernel<true, false, true>;
+        case 6: return fpv_drone_step_kernel<true, true, false>;
+        default: return fpv_drone_step_kernel<true, true, true>;
     }
-}
-
-// f16a: binary16 stick rows (fpv_buffers_t.action_f16): the same kernels with the 8-byte stick load, as instantiations of their own
-StepKernel drone_kernel(bool noise, bool obj, bool kahan, bool f16a)
-{
-    return f16a ? drone_kernel_f<true>(noise, obj, kahan) : drone_kernel_f<false>(noise, obj, kahan);
 }
 
 StepKernel racer_kernel(bool wide, bool pidv)
@@ -1330,12 +1288,10 @@ KernelChoice choose_kernel(const fpv_env* h, const FpvBufD& d)
         c.func = fpv_drone_step_aos_kernel;
     } else {
         const bool noise = (h->K.flags & FPV_FLAG_STICK_NOISE) != 0, obj = d.objs.count > 0, kahan = d.pos_comp != nullptr;
-        const bool f16a = d.action_ld == FPV_ACTION_LD_F16;
         if (d.rot_over)                     // guidance override: plain or object-list kernel (check_buffers)
-            c.func = f16a ? (obj ? fpv_drone_step_kernel<false, true, false, true, true> : fpv_drone_step_kernel<false, false, false, true, true>)
-                          : (obj ? fpv_drone_step_kernel<false, true, false, true> : fpv_drone_step_kernel<false, false, false, true>);
+            c.func = obj ? fpv_drone_step_kernel<false, true, false, true> : fpv_drone_step_kernel<false, false, false, true>;
         else
-            c.func = drone_kernel(noise, obj, kahan, f16a);
+            c.func = drone_kernel(noise, obj, kahan);
     }
     c.grid = (unsigned)((h->n + kStepBlock - 1) / kStepBlock);
     return c;
@@ -1505,8 +1461,7 @@ int fpv_rollout(fpv_handle_t h, const fpv_buffers_t* b, int k, int64_t action_st
     FpvBufD d = to_device_view(b, h->K.contact_reach);
     const float* a0 = b->action;
     for (int t = 0; t < k; ++t) {
-        // action_stride counts stick VALUES (4 per drone): 4 bytes each, or 2 with binary16 sticks
-        d.action = a0 ? reinterpret_cast<const float4*>(reinterpret_cast<const char*>(a0) + (int64_t)t * action_stride * (b->action_f16 ? 2 : 4)) : nullptr;
+        d.action = a0 ? reinterpret_cast<const float4*>(a0 + (int64_t)t * action_stride) : nullptr;
         if (out_stride) {
             if (b->reward) d.reward = b->reward + (int64_t)t * out_stride;
             if (b->done) d.done = b->done + (int64_t)t * out_stride;
@@ -1564,7 +1519,6 @@ int fpv_step_n(fpv_handle_t h, const fpv_buffers_t* b, int k, int64_t action_str
     if (action_stride % 4) return fail(FPV_EALIGN, "action_stride must keep 16-byte alignment");
     if (b->obs_aos) return fail(FPV_EINVAL, "fpv_step_n does not write obs_aos rows (a per-step observation is a closed-loop need: use fpv_step)");
     if (b->action_ld) return fail(FPV_EINVAL, "fpv_step_n reads action rows [n][4] only (SoA sticks are a policy's per-step output, a closed-loop need: use fpv_step or fpv_rollout)");
-    if (b->action_f16) return fail(FPV_EINVAL, "fpv_step_n reads fp32 action rows (binary16 sticks are a half-precision policy's per-step output, a closed-loop need: use fpv_step or fpv_rollout; a pre-computed batch is cast once)");
     if (b->rotation_override) return fail(FPV_EINVAL, "the guidance override is a per-step input: use fpv_step");
     const DeviceGuard dev(h->device);
     if (dev.rc != FPV_OK) return dev.rc;
@@ -1599,7 +1553,7 @@ void drop_graph(fpv_env* h)
 FpvBufD graph_step_view(const fpv_buffers_t* b, const FpvBufD& d0, int t, int64_t action_stride, int64_t out_stride)
 {
     FpvBufD d = d0;
-    d.action = reinterpret_cast<const float4*>(reinterpret_cast<const char*>(b->action) + (int64_t)t * action_stride * (b->action_f16 ? 2 : 4));
+    d.action = reinterpret_cast<const float4*>(b->action + (int64_t)t * action_stride);
     if (out_stride) {
         if (b->reward) d.reward = b->reward + (int64_t)t * out_stride;
         if (b->done) d.done = b->done + (int64_t)t * out_stride;
@@ -1620,8 +1574,7 @@ int fpv_rollout_graph(fpv_handle_t h, const fpv_buffers_t* b, int k, int64_t act
     if (b->rotation_override) return fail(FPV_EINVAL, "the guidance override is a per-step input: use fpv_step");
     // a graph replays frozen kernel arguments, but stick noise and the fp16 rounding are keyed by the per-launch step
     // index: such handles take the k-step kernel instead - the same k steps bit for bit, and cheaper than the replay
-    if (h->K.flags & (FPV_FLAG_STICK_NOISE | FPV_FLAG_FP16_STATE))
-        return b->action_f16 ? fpv_rollout(h, b, k, action_stride, out_stride, stream) : fpv_step_n(h, b, k, action_stride, out_stride, stream);
+    if (h->K.flags & (FPV_FLAG_STICK_NOISE | FPV_FLAG_FP16_STATE)) return fpv_step_n(h, b, k, action_stride, out_stride, stream);
     const DeviceGuard dev(h->device);
     if (dev.rc != FPV_OK) return dev.rc;
     const FpvBufD d0 = to_device_view(b, h->K.contact_reach);

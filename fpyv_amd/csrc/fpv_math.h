@@ -435,7 +435,10 @@ FPV_HD void fpv_unpack_half(const FpvHalfState& h, FpvDroneState& s)
 // one stored quaternion component: floor(a * 2^8 * scale + 8 random bits) >> 8 = stochastic rounding of a * scale to an integer
 FPV_HD uint32_t fpv_q3_field(float a, uint32_t rnd8)
 {
-    const int32_t n = fpv_floor_i32(fmaf(a, FPV_Q3_SCALE * 256.0f, (float)rnd8)) >> 8;
+    // saturated (one v_med3_i32): two tied largest components of a quaternion whose norm drifted above 1 by more than 5e-5
+    // would reach 16384, which the 15-bit field reads back as -16384 - a sign flip of that component
+    int32_t n = fpv_floor_i32(fmaf(a, FPV_Q3_SCALE * 256.0f, (float)rnd8)) >> 8;
+    n = n < -16383 ? -16383 : (n > 16383 ? 16383 : n);
     return (uint32_t)n & 0x7fffu;
 }
 

@@ -164,13 +164,11 @@ class _Batch:
             self._keepalive = action                 # a rollout in between may have replaced what `throttle` reports
             return self._last_action_ptr
         self._last_action = None
-        # hot path: a contiguous float32 - or float16: a half-precision policy's output, consumed as it is - [num_envs, 4]
-        # tensor on the env's device
-        if (type(action) is torch.Tensor and (action.dtype is torch.float32 or action.dtype is torch.float16)
-                and action.shape == self._ashape and action.is_contiguous() and action.device == self.state.device):
+        # hot path: a contiguous float32 [num_envs, 4] tensor on the env's device
+        if (type(action) is torch.Tensor and action.dtype is torch.float32 and action.shape == self._ashape
+                and action.is_contiguous() and action.device == self.state.device):
             self._keepalive = action
             self._buf.action_ld = 0
-            self._buf.action_f16 = 1 if action.dtype is torch.float16 else 0
             self._last_action, self._last_action_ptr = action, action.data_ptr()
             return self._last_action_ptr
         # SoA sticks [4, num_envs] (e.g. the output of `W @ obs_soa`): consumed in place, no transpose
@@ -179,10 +177,8 @@ class _Batch:
                 and action.device == self.state.device):
             self._keepalive = action
             self._buf.action_ld = action.stride(0)
-            self._buf.action_f16 = 0
             return action.data_ptr()
         self._buf.action_ld = 0
-        self._buf.action_f16 = 0
         if not torch.is_tensor(action):
             action = torch.as_tensor(np.asarray(action, dtype=np.float32), device=self.device)
         if action.dim() == 1:
@@ -359,12 +355,11 @@ class _Batch:
             if rewards is None and dones is None and steps is None:
                 raise ValueError("held-action rollouts need rewards/dones [k, num_envs] or steps=k to define k")
             k, stride = (int(steps) if steps is not None else (rewards if rewards is not None else dones).shape[0]), 0
-        if actions is not None and (actions.dtype not in (torch.float32, torch.float16) or not actions.is_contiguous()
+        if actions is not None and (actions.dtype != torch.float32 or not actions.is_contiguous()
                                     or actions.device != self.state.device):
-            raise ValueError("actions must be a contiguous float32 (or float16) tensor on the env's device")
+            raise ValueError("actions must be a contiguous float32 tensor on the env's device")
         b.action = actions.data_ptr() if actions is not None else None
         b.action_ld = 0
-        b.action_f16 = 1 if (actions is not None and actions.dtype is torch.float16) else 0
         if wind is not None:
             b.wind[0], b.wind[1], b.wind[2] = float(wind[0]), float(wind[1]), float(wind[2])
         out_stride = 0
@@ -379,10 +374,6 @@ class _Batch:
         try:
             if graph:
                 fn = self._L.fpv_rollout_graph
-            elif (fused is None or fused) and b.action_f16:
-                if fused:
-                    raise ValueError("the fused k-step kernel reads fp32 action rows; cast a pre-computed batch once (actions.float()) or use fused=False")
-                fn = self._L.fpv_rollout                # float16 sticks: k single-step launches
             elif fused is None or fused:
                 if self.obs_aos is not None:
                     if fused:
@@ -480,12 +471,6 @@ class _Partition:
                 raise ValueError("action=None is only meaningful with stick_noise=True (pure noise sticks)")
             return None
         st = self.parent.state
-        if (type(action) is torch.Tensor and action.dtype is torch.float16 and action.device == st.device
-                and action.shape == self._ashape and action.is_contiguous()):             # binary16 rows: a half-precision policy's output
-            self._buf.action_ld, self._buf.action_f16 = 0, 1
-            self._keep = action
-            return action.data_ptr()
-        self._buf.action_f16 = 0
         if type(action) is torch.Tensor and action.dtype is torch.float32 and action.device == st.device:
             if action.shape == self._ashape and action.is_contiguous():               # [n_p, 4] rows (a row slice of [N, 4] is one)
                 self._buf.action_ld = 0

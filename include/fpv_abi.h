@@ -32,9 +32,12 @@ extern "C" {
  *    256-thread workgroups lost every measurement); fpv_comm_info added; fpv_step_n reads action rows only. */
 /* 5: fpv_diag_busy added (a time-bounded one-wave kernel: lets a host tell whether two streams sit on different
  *    hardware queues - the split-phase API picks its partition streams that way); the in-kernel stick-noise generator
- *    rebuilt for cost (Philox4x32-7, division-free logarithm): streams differ from ABI <= 4 (the reference's profile is
+ *    rebuilt for cost (Philox4x32-7, four normals per call from a table-driven inverse CDF - no logarithm): streams differ from ABI <= 4 (the reference's profile is
  *    unseeded, /root/reference/tests/noise_smooth_test.py:6-12: there never was a stream to stay compatible with). */
-#define FPV_ABI_VERSION 5
+/* 6: fpv_buffers_t.action_f16 / reserved0 (binary16 stick rows, added late in ABI 5) removed: measured at no time gain
+ *    for ten more kernels - a half-precision policy casts its sticks (`.float()`); sizeof(fpv_buffers_t) shrinks by 8.
+ *    fp16 state: the stored quaternion fields saturate at +-16383 instead of wrapping (unit quaternions: unchanged bits). */
+#define FPV_ABI_VERSION 6
 
 enum {
     FPV_OK = 0,
@@ -204,11 +207,6 @@ typedef struct fpv_buffers {
                                 caller-supplied sticks; combines with objects / FPV_FLAG_GROUND */
     const float* thrust_override;   /* [n] thrust_force [N] of the same call; required with rotation_override.  A NaN entry
                                 leaves that drone un-overridden (its own attitude and low-passed thrust) */
-    int32_t action_f16;      /* 0: `action` holds fp32 sticks; 1: IEEE binary16 sticks, rows [n][4] (8 bytes per drone; action_ld must
-                                be 0; fpv_step, fpv_rollout and fpv_rollout_graph only - their strides still count stick VALUES) - what a policy that runs in half
-                                precision produces: consumed as it is (one 8-byte load per drone), widened in registers; the step is
-                                bit for bit that of the same sticks given as fp32 */
-    int32_t reserved0;
     uint16_t* state_h_thrust;/* FPV_FLAG_FP16_STATE: the row of prev_thrust halves when it does NOT follow the pair rows at
                                 state_h + 2 * FPV_HALF_PAIR_ROWS * ld - i.e. for a handle that steps a column range [lo, hi) of a
                                 larger batch (state_h moved by 2 * lo halves, this pointer = the batch's thrust row + lo halves;

@@ -2192,87 +2192,6 @@ def test_stream_overlap_probe_and_busy_kernel():
     assert chain_time_ratio(picked[0], picked[1]) < 1.3 and chain_time_ratio(picked[0], cur) < 1.3
 
 
-@pytest.mark.parametrize("kind", ["f32", "noise", "fp16_state", "racer", "racer_written", "aos", "objects"])
-def test_binary16_sticks_equal_the_same_sticks_as_fp32(params_1k, kind):
-    """fpv_buffers_t.action_f16: a half-precision policy hands its [n, 4] float16 output over as it is - one 8-byte load per
-    drone instead of 16, widened in registers.  The step must be BIT FOR BIT that of the same (already rounded) sticks
-    given as fp32: single-step launches (odd n: a step's rows are only 8-byte aligned), rollouts (float16 sticks take k
-    single-step launches where fp32 sticks take the k-step kernel - the two are bit-identical anyway), per-step outputs,
-    and - where the family has one - the hipGraph replay."""
-    from fpyv_amd.env import DroneBatch, RacerBatch
-    from fpyv_amd.objects import Cylinder, Ground
-    rng = np.random.default_rng(8)
-    for n, k in ((1, 5), (333, 24), (4096 + 2, 16)):
-        if kind in ("racer", "racer_written"):
-            pid = np.array([[0.004, 0.02, 1e-6], [0.003, 0.01, 2e-6], [0.002, 0.005, 0]])
-            p = params_1k.replace(mode=1, racer_pid=pid, racer_omega_dt=(kind == "racer"), ceiling=5e-4)
-            mk = lambda: RacerBatch(p, n, device=DEV, auto_reset=True)   # noqa: E731
-            a32 = np.concatenate([rng.uniform(-6, 6, (k, n, 3)), rng.uniform(0, 8, (k, n, 1))], axis=2).astype(np.float32)
-        else:
-            p = params_1k.replace(ceiling=10.4, init_position=np.array([0.0, 0.0, 10.0 if kind != "objects" else 0.4]))
-            kw = dict(device=DEV, auto_reset=True, with_accel=False)
-            if kind == "noise":
-                kw.update(stick_noise=True, noise_seed=4, with_action_out=True)
-            if kind == "fp16_state":
-                kw.update(fp16_state=True, rounding_seed=3)
-            if kind == "aos":
-                kw.update(with_obs_aos=True)
-            mk = lambda: DroneBatch(p, n, **kw)   # noqa: E731
-            a32 = sticks.ema_noise(k, range(n), seed=12) * np.float32(2.0)
-        h = torch.from_numpy(a32).to(DEV).to(torch.float16)             # what the policy produced
-        f = h.float()                                                     # the same numbers as fp32
-        objs = [Ground(), Cylinder(position=[1.0, 0.2, 0.0], radius=0.4, height=1.0)] if kind == "objects" else ()
-        runs = {}
-        for name, acts in (("f32", f), ("f16", h)):
-            e = mk()
-            e.reset()
-            if objs:
-                e.set_objects(objs)
-            rew = torch.zeros((k, n), device=DEV)
-            for t in range(3):                                            # single steps (fpv_step)
-                if kind.startswith("racer"):
-                    e.step(acts[t])
-                else:
-                    e.step(acts[t], object_list=objs, return_imu=False)
-            if kind != "aos":
-                e.rollout(acts, rewards=rew)                              # the k-step kernel with per-step outputs
-                e.rollout(acts)                                           # ... and quiet
-            e.rollout(acts, fused=False)                                  # k single-step launches from one call (byte strides)
-            if kind in ("f32", "racer"):
-                e.rollout(acts, graph=True)
-            torch.cuda.synchronize()
-            runs[name] = (e.state.clone(), e.reward.clone(), rew, e.state_h.clone().view(torch.int16) if e.state_h is not None else None,
-                          e.obs_aos.clone() if getattr(e, "obs_aos", None) is not None else None,
-                          e.action_out.clone() if getattr(e, "action_out", None) is not None else None)
-        for x, y in zip(runs["f32"], runs["f16"]):
-            if x is not None:
-                assert torch.equal(x, y), (kind, n, k)
-        assert bool(torch.isfinite(runs["f16"][0]).all())
-    # the k-step kernel reads fp32 rows only (a format test inside its loop cost 5 %): float16 sticks take k single-step
-    # launches by default, and asking for the fused kernel explicitly is an error, in Python and in C
-    e = _drone_batch(params_1k, 256)
-    e.reset()
-    h16 = torch.zeros((4, 256, 4), dtype=torch.float16, device=DEV)
-    with pytest.raises(ValueError):
-        e.rollout(h16, fused=True)
-    # what the C ABI refuses: binary16 sticks in the SoA layout, a flag that is neither 0 nor 1
-    import ctypes as C
-    e = _drone_batch(params_1k, 256)
-    e.reset()
-    b = _lib.FpvBuffers()
-    C.memmove(C.byref(b), C.byref(e._buf), C.sizeof(b))
-    hh = torch.zeros((256, 4), dtype=torch.float16, device=DEV)
-    b.action, b.action_f16, b.action_ld = hh.data_ptr(), 1, e.ld
-    L = _lib.lib()
-    assert L.fpv_step(e._handle, C.byref(b), None) == -1 and b"action_ld must be 0" in L.fpv_last_error()
-    b.action_ld, b.action_f16 = 0, 2
-    assert L.fpv_step(e._handle, C.byref(b), None) == -1
-    b.action_f16 = 1
-    assert L.fpv_step(e._handle, C.byref(b), None) == 0
-    assert L.fpv_step_n(e._handle, C.byref(b), 1, 0, 0, None) == -1 and b"fp32 action rows" in L.fpv_last_error()
-    torch.cuda.synchronize()
-
-
 @pytest.mark.parametrize("extra", [[], ["--partitions", "2"], ["--api", "rollout"]], ids=["step", "partitions2", "rollout"])
 def test_bench_line_schema_small(extra):
     """bench.py end to end at a small size: ONE JSON line with the contract's keys, `roofline` (achieved / peak / frac / traffic /

@@ -132,6 +132,27 @@ def test_fp16_storage_round_trip_for_any_attitude_and_velocity(q, v, seed, drone
     assert np.all(np.abs(back[3:6] - vv) <= step * 1.0001 + 1e-12), (vv, back[3:6])
 
 
+@settings(max_examples=150, deadline=None)
+@given(pair=st.sampled_from([(0, 1), (0, 2), (0, 3), (1, 2), (1, 3), (2, 3)]), sa=st.sampled_from([-1.0, 1.0]), sb=st.sampled_from([-1.0, 1.0]),
+       scale=st.floats(1 - 1e-3, 1 + 1e-3), eps=st.floats(0, 1e-4), seed=st.integers(0, 2 ** 32 - 1), drone=st.integers(0, 2 ** 32 - 1))
+def test_fp16_quaternion_fields_saturate_for_tied_components_off_the_unit_sphere(pair, sa, sb, scale, eps, seed, drone):
+    """Two (nearly) tied largest components at +-1/sqrt(2) of a quaternion whose norm is off by up to 1e-3 (a user-written
+    state, fp32 drift): the stored 15-bit field would reach 16384 and read back as -16384 - a sign flip.  The field
+    saturates (fpv_q3_field): the decoded components keep the input's signs (as an attitude: up to q -> -q)."""
+    qn = np.zeros(4)
+    qn[pair[0]], qn[pair[1]] = sa * np.sqrt(0.5) * scale, sb * np.sqrt(0.5) * (scale - eps)
+    qn = qn.astype(np.float32)
+    st14 = np.zeros((14, 64), dtype=np.float32)
+    st14[6:10, 0] = qn
+    pos, sh = lane_model.split_half(st14, seed=seed, drone_id_offset=drone)
+    qb = lane_model.join_half(pos, sh)[6:10, 0].astype(np.float64)
+    if qb[pair[0]] * qn[pair[0]] < 0:
+        qb = -qb
+    assert abs(np.linalg.norm(qb) - 1) < 2e-6
+    assert np.abs(qb - qn).max() < 2e-3 + 3.6 / 23168, (qn, qb)
+    assert qb[pair[0]] * qn[pair[0]] > 0.49 and qb[pair[1]] * qn[pair[1]] > 0.49, (qn, qb)
+
+
 @settings(max_examples=200, deadline=None)
 @given(a=st.integers(0, 2 ** 31 - 1), b=st.integers(0, 2 ** 31 - 1), sign=st.integers(0, 1))
 def test_inverse_normal_is_monotone_and_symmetric_for_any_pair_of_words(a, b, sign):

@@ -3,12 +3,13 @@
 interleaved (cdna_hip_programming.md 5.4 rule 24).  Variants are built here (hipcc cross-compiles) by
 `--build`, timed on the GPU box without flags.
 
-    python tools/exp/ab_variants.py --build            # in the build container
-    python tools/exp/ab_variants.py [--n 1048576]      # on the GPU box
+    python tools/ab_variants.py --build            # in the build container (libraries land in tools/_variants/, git-ignored)
+    python tools/ab_variants.py [--n 1048576]      # on the GPU box
 """
 import argparse, ctypes as C, os, statistics, subprocess, sys
 HERE = os.path.dirname(os.path.abspath(__file__))
-REPO = os.path.dirname(os.path.dirname(HERE))
+REPO = os.path.dirname(HERE)
+OUT = os.path.join(HERE, "_variants")
 sys.path.insert(0, REPO)
 VARIANTS = {
     "base": [],
@@ -27,9 +28,10 @@ a = ap.parse_args()
 names = [k for k in VARIANTS if not a.only or k in a.only]
 if a.build:
     for k in names:
-        out = os.path.join(HERE, f"libfpv_v_{k}.so")
-        subprocess.run(["/opt/rocm/bin/hipcc", "-O3", "--offload-arch=gfx950", "-ffp-contract=off", "-fno-slp-vectorize", "-std=c++17", "-shared", "-fPIC",
-                        *VARIANTS[k], "-o", out, os.path.join(REPO, "fpyv_amd", "csrc", "fpv_hip.hip")], check=True)
+        os.makedirs(OUT, exist_ok=True)
+        out = os.path.join(OUT, f"libfpv_v_{k}.so")
+        from __graft_entry__ import HIPCC_FLAGS
+        subprocess.run(["/opt/rocm/bin/hipcc", *HIPCC_FLAGS, *VARIANTS[k], "-o", out, os.path.join(REPO, "fpyv_amd", "csrc", "fpv_hip.hip")], check=True)
         print("built", out)
     sys.exit(0)
 import torch
@@ -40,7 +42,7 @@ n = a.n; ring = 32 if n <= (1 << 21) else 4
 acts = sticks.ema_noise_device(ring, n, dev)
 L, H = {}, {}
 for k in names:
-    l = C.CDLL(os.path.join(HERE, f"libfpv_v_{k}.so"))
+    l = C.CDLL(os.path.join(OUT, f"libfpv_v_{k}.so"))
     l.fpv_create.argtypes = [C.c_void_p, C.c_int64, C.c_int, C.c_void_p]
     l.fpv_rollout.argtypes = [C.c_void_p, C.c_void_p, C.c_int, C.c_int64, C.c_int64, C.c_void_p]
     l.fpv_recommended_ld.argtypes = [C.c_int64]; l.fpv_recommended_ld.restype = C.c_int64

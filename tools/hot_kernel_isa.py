@@ -5,7 +5,7 @@ VALU, SALU, s_waitcnt, v_med3, LDS, scratch, MFMA) and - from -Rpass-analysis - 
 the plain single-step kernel, the fp16-state single-step kernel and the plain k-step kernel.
 
     python tools/hot_kernel_isa.py                     # prints the report
-    python tools/hot_kernel_isa.py --write r04         # also writes profiles/r04_hot_kernel_isa.txt
+    python tools/hot_kernel_isa.py --write r05         # also writes profiles/r05_hot_kernel_isa.txt
 
 tests/test_isa_claims.py runs the same functions and holds DESIGN.md to the numbers.
 """
@@ -19,7 +19,7 @@ REPO = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, REPO)
 SRC = os.path.join(REPO, "fpyv_amd", "csrc", "fpv_hip.hip")
 HOT = collections.OrderedDict([
-    ("plain single-step kernel fpv_drone_step_kernel<false,false,false,false>", "fpv_drone_step_kernelILb0ELb0ELb0ELb0ELb0EEE"),
+    ("plain single-step kernel fpv_drone_step_kernel<false,false,false,false>", "fpv_drone_step_kernelILb0ELb0ELb0ELb0E"),
     ("fp16-state single-step kernel fpv_drone_step_h_kernel", "fpv_drone_step_h_kernel"),
     ("plain k-step kernel fpv_drone_rollout_kernel<false,false,false,true>", "fpv_drone_rollout_kernelILb0ELb0ELb0ELb1E"),
 ])
@@ -95,13 +95,16 @@ def resources(remarks):
 
 
 def load_block(lines):
-    """the instructions from the first vector load to the wait that follows the LAST vector load issued before any store (the rare
-    binary16-sticks branch has a wait of its own in the middle: it belongs to the block)"""
-    first = next(k for k, ln in enumerate(lines) if ln.startswith("global_load"))
-    store = next((k for k, ln in enumerate(lines) if ln.startswith("global_store")), len(lines))
-    last = max(k for k, ln in enumerate(lines[:store]) if ln.startswith("global_load"))
-    end = next((k for k in range(last, len(lines)) if lines[k].startswith("s_waitcnt vmcnt")), last)
-    return lines[first:end + 1]
+    """the instructions from the first vector load to the first wait for vector memory"""
+    out, started = [], False
+    for ln in lines:
+        if ln.startswith("global_load"):
+            started = True
+        if started:
+            out.append(ln)
+            if ln.startswith("s_waitcnt vmcnt"):
+                break
+    return out
 
 
 def report():
