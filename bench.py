@@ -71,6 +71,39 @@ def kernel_source_hash():
     return h.hexdigest()[:16]
 
 
+def fit_launch_time(points):
+    """Least squares of avg_launch_us(n) = floor_us + algorithmic bytes / streaming rate through `points` =
+    [(drones, bytes_per_launch, avg_launch_us), ...] (three populations inside the Infinity Cache).  The fit is only as good
+    as its points: `valid` is False - with the reason - when a point does not sit on the line (max residual > 0.5 us: a leg
+    measured at idle clocks or bound by the host's launch loop), when the slope says the kernel streams faster than the HBM
+    peak, or when the floor is not positive.  A reader takes floor_us / streaming_GBs from a valid fit only."""
+    import numpy as np
+    A = np.array([[1.0, b / 1e6] for _, b, _ in points])
+    y = np.array([t for _, _, t in points], dtype=np.float64)
+    (t0, slope), *_ = np.linalg.lstsq(A, y, rcond=None)
+    resid = float(np.abs(A @ np.array([t0, slope]) - y).max())
+    rate = float(1e3 / slope) if slope > 0 else float("inf")
+    why = []
+    if not np.isfinite(y).all() or (y <= 0).any():
+        why.append("a point has no positive finite time")
+    if resid > 0.5:
+        why.append(f"max residual {resid:.2f} us > 0.5 us: the points are not on one line (a leg at idle clocks, or bound by the host's launch loop - compare host_enqueue_us with avg_launch_us)")
+    if not slope > 0 or rate > HBM_PEAK_GBS:
+        why.append(f"slope gives a streaming rate of {rate:.0f} GB/s, above the {HBM_PEAK_GBS:.0f} GB/s HBM peak")
+    if not t0 > 0:
+        why.append(f"floor {t0:.2f} us is not positive")
+    return {"model": "avg_launch_us(n) = floor_us + algorithmic bytes / streaming rate (least squares; populations inside the Infinity Cache)",
+            "drones": [int(n_) for n_, _, _ in points], "avg_launch_us": [float(t) for t in y],
+            "floor_us": float(t0), "streaming_GBs": rate, "streaming_frac_of_peak": rate / HBM_PEAK_GBS,
+            "max_residual_us": resid, "valid": not why, "invalid_reason": "; ".join(why) or None}
+
+
+def median(xs):
+    xs = sorted(xs)
+    m = len(xs) // 2
+    return xs[m] if len(xs) % 2 else 0.5 * (xs[m - 1] + xs[m])
+
+
 def usable_cpus():
     """CPUs this process can really run on: min(affinity mask, cgroup v2/v1 CPU quota)."""
     n = len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1)
@@ -328,6 +361,9 @@ def parse_args(argv=None):
     ap.add_argument("--preheat-s", type=float, default=0.5,
                     help="seconds of untimed launches on a SCRATCH batch before the W warm-up steps, so the "
                          "GPU has left its idle clocks (the timed region is only K x ~25 us)")
+    ap.add_argument("--aux-preheat-s", type=float, default=0.25,
+                    help="the same time-based preheat before EACH auxiliary leg (sustained, beyond_mall, launch_time_fit), on that "
+                         "leg's own buffers: each leg starts right after gigabytes were freed and allocated")
     ap.add_argument("--drones-per-gpu", type=int, default=1 << 20)
     ap.add_argument("--ring", type=int, default=32, help="distinct pre-generated action batches")
     ap.add_argument("--api", choices=["rollout", "step", "rollout-launches"], default="step",
@@ -609,6 +645,7 @@ def main(argv=None):
 
     launches = [0]
     part_slices = {}
+    ring_rows = {}
     part_ranges = [venv.partition_range(kk) for kk in range(venv.partitions)] if venv is not None else []
 
     def run_on(e, acts, k, t_base, g):
@@ -628,10 +665,13 @@ def main(argv=None):
                 venv.step_wait(kk)                  # the caller's stream (and its timing events) follow every chain
             return
         if args.api == "step":
+            rows = ring_rows.get(acts.data_ptr())
+            if rows is None:                        # the ring's batches as tensors of their own, made once: what a policy hands over
+                rows = ring_rows[acts.data_ptr()] = [acts[r] for r in range(rlen)]
             for t in range(t_base, t_base + k):
                 if g is not None:
                     e.set_done_bits_target(g.row_ptr(t))
-                e.step(acts[t % rlen], return_imu=False)
+                e.step(rows[t % rlen], return_imu=False)
                 launches[0] += 1
                 if g is not None:
                     g.step_done(t)
@@ -681,6 +721,7 @@ def main(argv=None):
     t0 = time.perf_counter()
     ev0.record()                      # torch's current stream == the stream the kernels are launched on
     run_on(env, actions, args.steps, args.warmup, gather)
+    host_enqueue_s = time.perf_counter() - t0          # the host's side of the K steps: when this is the elapsed time, the host's launch loop is the bound
     ev1.record()
     if gather is not None:
         gather.flush(args.warmup + args.steps - 1)
@@ -711,17 +752,49 @@ def main(argv=None):
             np.save(os.path.join(args.dump_gathered, "gathered_last_bucket.npy"), gather.result(last_t // args.gather_block).cpu().numpy())
         np.save(os.path.join(args.dump_gathered, f"state_rank{rank}.npy"), env.state.cpu().numpy())
 
-    def timed_leg(e, acts, k, t_base):
-        """k more steps of the same kind on the launch stream, HIP-event timed, no exchange: (us per launch, launches)."""
-        a0, a1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-        before = launches[0]
-        a0.record()
-        run_on(e, acts, k, t_base, None)
-        a1.record()
-        torch.cuda.synchronize()
-        nl = launches[0] - before
-        launches[0] = before
-        return a0.elapsed_time(a1) * 1e3 / max(nl, 1), nl
+    def timed_leg(e, acts, k, t_base, repeats=1, c_loop=False):
+        """`repeats` x k more steps of the same kind on the launch stream, each repeat HIP-event timed, no exchange.
+        c_loop: the launches come from one C call per ring span (fpv_rollout - the same single-step kernel, ~1 us of host
+        time per launch) instead of one Python env.step() each, so that a slow host cannot bound the leg.
+        Returns {"avg_launch_us": median over the repeats, "repeats_us", "launches" (per repeat), "host_enqueue_us":
+        median host time per launch spent enqueueing (perf_counter around the launch loop, before the synchronise)}."""
+        us_all, host_all, nl = [], [], 0
+        for rep in range(repeats):
+            a0, a1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            before = launches[0]
+            torch.cuda.synchronize()
+            h0 = time.perf_counter()
+            a0.record()
+            if c_loop:
+                rlen, t = acts.shape[0], t_base + rep * k
+                while t < t_base + (rep + 1) * k:
+                    r0 = t % rlen
+                    span = min(rlen - r0, t_base + (rep + 1) * k - t)
+                    e.rollout(acts[r0:r0 + span], fused=False)
+                    launches[0] += span
+                    t += span
+            else:
+                run_on(e, acts, k, t_base + rep * k, None)
+            h1 = time.perf_counter()
+            a1.record()
+            torch.cuda.synchronize()
+            nl = launches[0] - before
+            launches[0] = before
+            us_all.append(a0.elapsed_time(a1) * 1e3 / max(nl, 1))
+            host_all.append((h1 - h0) * 1e6 / max(nl, 1))
+        us, host = median(us_all), median(host_all)
+        return {"avg_launch_us": us, "repeats_us": us_all, "launches": nl, "host_enqueue_us": host,
+                "host_bound": bool(host > 0.9 * us)}
+
+    def leg_preheat(e, acts):
+        """Time-based, like the headline's --preheat-s, on the leg's OWN buffers (a leg starts right after gigabytes were freed
+        and allocated; 40 launches are 0.5 ms - not enough for the clocks): untimed C-loop launches for --aux-preheat-s."""
+        if args.aux_preheat_s <= 0:
+            return
+        t_end = time.perf_counter() + args.aux_preheat_s
+        while time.perf_counter() < t_end:
+            e.rollout(acts, fused=False)
+            torch.cuda.synchronize()
 
     physics_ms = None
     if multi:
@@ -729,26 +802,28 @@ def main(argv=None):
         # launch must not keep writing rows of a bucket that is no longer being gathered)
         env.set_done_bits_target(None)
         k2 = max(args.gather_block, min(400, max(args.steps, 64)))
-        us, nl = timed_leg(env, actions, k2, args.warmup + args.steps)
-        physics_ms = us * 1e-3 * nl / k2
+        leg = timed_leg(env, actions, k2, args.warmup + args.steps)
+        physics_ms = leg["avg_launch_us"] * 1e-3 * leg["launches"] / k2
         coll = collective_report(dist, world, rank, dev, gather, local_elapsed * 1e3 / args.steps, collective=collective, physics_ms=physics_ms)
 
     # the steady state beside the driver's short shape (20 timed launches are 0.5 ms: the clock also holds the first
     # launch's latency and the closing synchronise): the same env, the same ring, HIP events around `--sustained-steps`
     # further launches at the headline population
     sustained = None
-    if rank == 0 and world == 1 and not multi and args.api == "step" and args.sustained_steps > 0:
-        us, nl = timed_leg(env, actions, args.sustained_steps, args.warmup + args.steps)
+    aux_ok = rank == 0 and world == 1 and not multi and args.api == "step"
+    if aux_ok and args.sustained_steps > 0:
+        leg = timed_leg(env, actions, args.sustained_steps, args.warmup + args.steps)
+        us = leg["avg_launch_us"]
         gbs = env.algorithmic_bytes() * n / (us * 1e-6) / 1e9
-        sustained = {"launches": nl, "avg_launch_us": us, "achieved": gbs, "unit": "GB/s", "frac": gbs / HBM_PEAK_GBS,
-                     "env_steps_per_s": n / (us * 1e-6),
-                     "what": f"{nl} consecutive env.step() launches at {n} drones after the timed region, HIP events on the launch stream"}
+        sustained = {"launches": leg["launches"], "avg_launch_us": us, "host_enqueue_us": leg["host_enqueue_us"], "host_bound": leg["host_bound"],
+                     "achieved": gbs, "unit": "GB/s", "frac": gbs / HBM_PEAK_GBS, "env_steps_per_s": n / (us * 1e-6),
+                     "what": f"{leg['launches']} consecutive env.step() launches at {n} drones after the timed region, HIP events on the launch stream"}
         assert bool(torch.isfinite(env.state).all()), "non-finite state after the sustained leg"
 
     # the same kernel with its state far outside the 256 MiB Infinity Cache (2^23 drones: 470 MB of state):
     # what a GPU-filling population sees; the 2^20-drone state (59 MB) lives in that cache between steps
     beyond = None
-    if rank == 0 and world == 1 and not args.no_beyond_mall and args.api == "step" and venv is None:
+    if aux_ok and not args.no_beyond_mall and venv is None:
         nb = 1 << 23
         big = make_env(nb, False)
         big.reset()
@@ -774,22 +849,18 @@ def main(argv=None):
             torch.cuda.synchronize()
             return 8.0 * cf / (c0.elapsed_time(c1) * 1e-3 / reps) / 1e9      # GB/s, read + write
 
+        leg_preheat(big, acts_b)
         copy_before = time_copy(L.fpv_diag_stream_copy_wide)
-        run_on(big, acts_b, 20, 0, None)
-        torch.cuda.synchronize()
-        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-        kb = 300
-        e0.record()
-        run_on(big, acts_b, kb, 20, None)
-        e1.record()
-        torch.cuda.synchronize()
-        us = e0.elapsed_time(e1) * 1e3 / kb
+        leg = timed_leg(big, acts_b, 100, 0, repeats=3)
+        us = leg["avg_launch_us"]
         copy_after = time_copy(L.fpv_diag_stream_copy_wide)
         copy_dword = time_copy(L.fpv_diag_stream_copy)
         gbs = launch_bytes / (us * 1e-6) / 1e9
         ceiling = max(copy_before, copy_after)
         beyond = {"drones": nb, "state_MB": round(big.state.numel() * 4 / 1e6 + (big.state_h.numel() * 2 / 1e6 if big.state_h is not None else 0)),
-                  "avg_launch_us": us, "achieved": gbs, "frac": gbs / HBM_PEAK_GBS, "env_steps_per_s": nb / (us * 1e-6),
+                  "avg_launch_us": us, "repeats_us": leg["repeats_us"], "launches_per_repeat": leg["launches"],
+                  "host_enqueue_us": leg["host_enqueue_us"], "host_bound": leg["host_bound"],
+                  "achieved": gbs, "frac": gbs / HBM_PEAK_GBS, "env_steps_per_s": nb / (us * 1e-6),
                   "copy_ceiling_GBs": ceiling, "frac_of_copy_ceiling": gbs / ceiling,
                   "copy_GBs": {"float4_before": copy_before, "float4_after": copy_after, "dword": copy_dword,
                                "bytes_per_launch": 8 * cf,
@@ -797,27 +868,24 @@ def main(argv=None):
                                        "step-kernel launch at 2^23 drones, same process, before and after the kernel run"}}
         del big, acts_b, src, dst
 
-    # what a launch costs as a function of the population, on this box, in this process: the same kernel at half and at
-    # twice the headline population (both still inside the Infinity Cache).  With the headline's own time that gives
-    # the straight line t(n) = floor + bytes / rate (from 2^19 drones up the residuals are < 0.4 us):
-    # how much of the headline launch is the per-launch floor of a dependent kernel chain, and what the rest streams at
-    fit = None
-    if rank == 0 and world == 1 and not args.no_beyond_mall and args.api == "step" and n == (1 << 20) and not args.racer and venv is None:
-        pts = []
-        for nn in (n // 2, 2 * n):
+    # what a launch costs as a function of the population, on this box, in this process: the same kernel at half, at one
+    # and at twice the headline population (all inside the Infinity Cache), each leg on fresh buffers after its own
+    # time-based preheat, launched from the C loop (fpv_rollout: the same single-step kernel; one Python call per ring span,
+    # so the host's per-call cost cannot bound a leg), median of three 400-launch repeats.  The straight line
+    # t(n) = floor + bytes / rate says how much of the headline launch is the per-launch floor of a dependent
+    # kernel chain and what the rest streams at - when the points sit on a line; fit_launch_time() says when they do not
+    fit_legs = None
+    if aux_ok and not args.no_beyond_mall and n == (1 << 20) and not args.racer and venv is None:
+        fit_legs = []
+        for nn in (n // 2, n, 2 * n):
             e = make_env(nn, False)
             e.reset()
             aa = sticks.ema_noise_device(8, nn, dev, seed=5)
-            run_on(e, aa, 40, 0, None)
-            torch.cuda.synchronize()
-            f0, f1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-            f0.record()
-            run_on(e, aa, 400, 40, None)
-            f1.record()
-            torch.cuda.synchronize()
-            pts.append((e.algorithmic_bytes() * nn, f0.elapsed_time(f1) * 1e3 / 400))
+            leg_preheat(e, aa)
+            leg = timed_leg(e, aa, 400, 0, repeats=3, c_loop=True)
+            leg.update(drones=nn, bytes_per_launch=e.algorithmic_bytes() * nn)
+            fit_legs.append(leg)
             del e, aa
-        fit = {"points_bytes_us": pts}
 
     if rank == 0:
         state_bytes = env.algorithmic_bytes()                                # 133 B fp32 / 89 B fp16 state
@@ -866,6 +934,8 @@ def main(argv=None):
                          "frac": achieved / HBM_PEAK_GBS, "traffic": traffic, "traffic_source": traffic_src,
                          "kernel": kernel, "algorithmic_bytes_per_env_step": bytes_per_step,
                          "avg_launch_us": kernel_s * 1e6,
+                         "host_enqueue_us": host_enqueue_s * 1e6 / max(n_launches, 1),
+                         "host_bound": bool(host_enqueue_s > 0.9 * dev_ms * 1e-3),
                          "cache_note": "at 2^20 drones the 59 MB state is re-read from the 256 MiB Infinity Cache (MALL) every step; "
                                        "only the action stream and reward/done cross HBM - `beyond_mall` is the same kernel at 2^23 drones",
                          "frac_beyond_mall": beyond["frac"] if beyond else None, "beyond_mall": beyond,
@@ -876,23 +946,16 @@ def main(argv=None):
         if venv is not None:
             out["roofline"]["note"] = (f"split phase: one step = {venv.partitions} launches on {venv.partitions} streams that overlap; avg_launch_us is the "
                                        "time per full-population step, achieved = 133 B x n / that; " + out["roofline"]["note"])
-        if fit is not None:
-            # least squares through (bytes, us) at 2^19, 2^20 and 2^21 drones; the 2^20 point is the sustained leg of this
-            # very env (thousands of launches, like the 400-launch legs of the two other sizes) when there is one, else
-            # the timed region itself
-            import numpy as np
+        if fit_legs is not None:
+            lf = fit_launch_time([(g_["drones"], g_["bytes_per_launch"], g_["avg_launch_us"]) for g_ in fit_legs])
             head_us = sustained["avg_launch_us"] if sustained else kernel_s * 1e6
-            pts = [fit["points_bytes_us"][0], (state_bytes * n, head_us), fit["points_bytes_us"][1]]
-            A = np.array([[1.0, b_ / 1e6] for b_, _ in pts])
-            y = np.array([t_ for _, t_ in pts])
-            (t0, slope), *_ = np.linalg.lstsq(A, y, rcond=None)
-            out["roofline"]["launch_time_fit"] = {
-                "model": "avg_launch_us(n) = floor_us + algorithmic bytes / streaming rate, n = 2^19, 2^20, 2^21 drones (all inside the Infinity Cache)",
-                "drones": [n // 2, n, 2 * n], "avg_launch_us": [float(t_) for _, t_ in pts],
-                "floor_us": float(t0), "streaming_GBs": float(1.0 / slope * 1e3), "streaming_frac_of_peak": float(1.0 / slope * 1e3 / HBM_PEAK_GBS),
-                "headline_point": "roofline.sustained" if sustained else "the timed region",
-                "floor_share_of_headline_launch": float(t0 / head_us),
-                "max_residual_us": float(np.abs(A @ np.array([t0, slope]) - y).max())}
+            lf.update(legs=[{k_: g_[k_] for k_ in ("drones", "avg_launch_us", "repeats_us", "launches", "host_enqueue_us", "host_bound")} for g_ in fit_legs],
+                      launched_by="fpv_rollout (k single-step launches per C call), fresh buffers, time-based preheat per leg, median of 3 x 400 launches",
+                      headline_point="roofline.sustained" if sustained else "the timed region",
+                      floor_share_of_headline_launch=(lf["floor_us"] / head_us) if lf["valid"] else None)
+            if any(g_["host_bound"] for g_ in fit_legs) and lf["valid"]:
+                lf.update(valid=False, invalid_reason="a leg's host enqueue time is within 10 % of its launch time: the host's launch loop, not the GPU, set that point")
+            out["roofline"]["launch_time_fit"] = lf
         if coll is not None:
             out["collective"] = coll
         if args.api == "rollout":

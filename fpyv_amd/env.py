@@ -27,6 +27,11 @@ from . import _lib
 from .params import DroneParams, MODE_DRONE, MODE_RACER, load_params
 
 
+# identifiers stored in checkpoints (state_dict): what the fp16 storage words and the in-kernel stick-noise stream mean
+STATE_H_ENCODING = "abi5: v f16+5-bit low words, q smallest-three 15-bit fixed point, rates/thrust f16"     # csrc/fpv_math.h fpv_pack_half
+NOISE_GENERATOR = "abi5: philox4x32-7, table-driven inverse normal CDF"                                     # csrc/fpv_math.h fpv_stick_noise
+
+
 def _round_up(x: int, m: int) -> int:
     return (x + m - 1) // m * m
 
@@ -179,6 +184,13 @@ class _Batch:
             self._buf.action_ld = action.stride(0)
             return action.data_ptr()
         self._buf.action_ld = 0
+        action = self._coerce_action(action)
+        self._keepalive = action
+        return action.data_ptr()
+
+    def _coerce_action(self, action: Any) -> torch.Tensor:
+        """Whatever the reference's callers pass as sticks - a list, a NumPy array, a [4] broadcast, a tensor of another
+        dtype / device / stride - as a contiguous float32 [num_envs, 4] tensor on the env's device (a copy only if needed)."""
         if not torch.is_tensor(action):
             action = torch.as_tensor(np.asarray(action, dtype=np.float32), device=self.device)
         if action.dim() == 1:
@@ -192,8 +204,7 @@ class _Batch:
             raise ValueError(f"action must have shape ({self.n}, 4), got {tuple(action.shape)}")
         if action.dtype != torch.float32 or action.device != self.state.device or not action.is_contiguous():
             action = action.to(device=self.device, dtype=torch.float32).contiguous()
-        self._keepalive = action
-        return action.data_ptr()
+        return action
 
     def set_step_counter(self, step: int) -> None:
         """64-bit step index keying the stick-noise stream / stochastic rounding (counts the steps launched, from 0)."""
@@ -224,6 +235,12 @@ class _Batch:
         d: Dict[str, Any] = {k: getattr(self, k).clone() for k in self._CKPT_TENSORS if getattr(self, k, None) is not None}
         d["step_counter"] = int(self._steps_launched)
         d["num_envs"], d["mode"] = self.n, self.mode
+        # what the bits mean: the fp16 storage words and the stick-noise streams changed between ABI versions
+        d["abi_version"] = _lib.FPV_ABI_VERSION
+        if self.fp16_state:
+            d["state_h_encoding"] = STATE_H_ENCODING
+        if self.stick_noise:
+            d["noise_generator"] = NOISE_GENERATOR
         return d
 
     def load_state_dict(self, d: Dict[str, Any]) -> None:
@@ -231,6 +248,14 @@ class _Batch:
             raise ValueError("checkpoint was taken from a batch of different size or mode")
         if "done_u8" in d and "done" not in d:        # checkpoints written before the bool view existed
             d = dict(d, done=d["done_u8"].bool())
+        if self.fp16_state and d.get("state_h_encoding") != STATE_H_ENCODING:
+            # an older library's eleven words decode as garbage here (e.g. its qw half would be read as the v_low bits)
+            raise ValueError(f"fp16-state checkpoint with storage encoding {d.get('state_h_encoding')!r} (ABI {d.get('abi_version', '<= 5, unrecorded')}); "
+                             f"this library reads {STATE_H_ENCODING!r} - widen the old state with the library that wrote it and load the fp32 rows")
+        if self.stick_noise and d.get("noise_generator") != NOISE_GENERATOR:
+            import warnings
+            warnings.warn(f"checkpoint was written with stick-noise generator {d.get('noise_generator')!r}, this library runs {NOISE_GENERATOR!r}: "
+                          "the run continues with a different (equally distributed) stick stream, not bit for bit", RuntimeWarning, stacklevel=2)
         for k in self._CKPT_TENSORS:
             if k in d:
                 if getattr(self, k, None) is None:
@@ -495,6 +520,15 @@ class _Partition:
     def set_step_counter(self, step: int) -> None:
         _lib.check(self._L.fpv_set_step_counter(self._handle, int(step)))
         self.steps_launched = int(step)
+
+    def set_params(self) -> None:
+        """Take over the parent's current parameters (FpvVecEnv.set_params), keeping this partition's drone-id offset."""
+        parent = self.parent
+        kw = dict(parent._pack_kw, drone_id_offset=int(parent._pack_kw.get("drone_id_offset", 0)) + self.lo)
+        auto = bool(parent._cparams.flags & _lib.FPV_FLAG_AUTO_RESET)
+        cp = _lib.pack_params(parent.params, auto_reset=auto, **kw)
+        _lib.check(self._L.fpv_set_params(self._handle, C.byref(cp)))
+        self._cparams = cp
 
     def close(self) -> None:
         if getattr(self, "_handle", None) is not None and self._handle.value:
@@ -765,6 +799,9 @@ class FpvVecEnv:
                 obs, reward, done, info = env.step_wait(part)     # views of this partition's drones, after its last step
                 env.step_async(part, policy(obs))                 # returns at once; the other partition's step is in flight
 
+    Calls on the whole population (reset, load_state_dict, state_dict, set_done_bits_target, close) are ordered after
+    every partition's enqueued steps on the device - a reset right after a step_async does not race it.
+
     While the policy looks at partition A, partition B steps, and the two kernel chains overlap on the GPU - each hides a
     part of the other's per-launch floor (17 % of a 2^20-drone launch).  Drones keep their GLOBAL ids, so
     every buffer is bit-identical to the unpartitioned env's after the same number of steps, whatever P is.  `step()`
@@ -817,17 +854,42 @@ class FpvVecEnv:
             self._obs_view = v               # fp32 storage: a view of the state tensor, which never moves
         return self._obs_view
 
+    # -- ordering between the caller's stream and the partitions' chains --------------------------------------------------
+    # Every call that touches the WHOLE population on the caller's stream (reset, load_state_dict, state_dict, close) first
+    # makes that stream wait for every partition's chain - a step_async that nobody has step_wait-ed for yet is complete
+    # before the reset kernel / the copies run - and afterwards makes every partition's stream wait for the caller's, so
+    # the next step_async sees the result.  (gym's vector envs raise on a reset while a step is pending; here the streams
+    # order it: `step_async(k, a); reset(mask)` is exactly `step(a); reset(mask)` of the single batch, bit for bit.)  The
+    # waits are device-side (two event records and waits per partition, no host synchronisation).
+    def _caller_waits_for_partitions(self) -> "torch.cuda.Stream":
+        cur = torch.cuda.current_stream(self.batch.device)
+        for P in self._parts:
+            if cur != P.stream:
+                cur.wait_stream(P.stream)
+        return cur
+
+    def _partitions_wait_for(self, cur: "torch.cuda.Stream") -> None:
+        for P in self._parts:
+            if cur != P.stream:
+                P.stream.wait_stream(cur)
+
     def reset(self, mask=None) -> torch.Tensor:
-        self.batch.reset(mask=mask)
-        if self._parts:                      # the partitions' chains start after the reset (enqueued on the caller's stream)
-            cur = torch.cuda.current_stream(self.batch.device)
-            for P in self._parts:
-                P.stream.wait_stream(cur)              # (the step counters run on, as the unpartitioned batch's does across a reset)
+        if not self._parts:
+            self.batch.reset(mask=mask)
+            return self.obs
+        cur = self._caller_waits_for_partitions()      # steps still in flight on the partitions' streams finish first
+        self.batch.reset(mask=mask)                    # (the step counters run on, as the unpartitioned batch's does across a reset)
+        self._partitions_wait_for(cur)
         return self.obs
 
     def step(self, action) -> Tuple[torch.Tensor, torch.Tensor, torch.Tensor, Dict[str, Any]]:
         if self._parts:
-            soa = action is not None and action.dim() == 2 and action.shape[0] == 4 and action.shape[1] == self.num_envs != 4
+            soa = False
+            if action is not None:
+                soa = (type(action) is torch.Tensor and action.dim() == 2 and action.shape[0] == 4 and action.shape[1] == self.num_envs != 4
+                       and action.dtype is torch.float32 and action.stride(1) == 1 and action.device == self.batch.state.device)
+                if not soa:
+                    action = self.batch._coerce_action(action)       # lists, arrays, [4] broadcasts, other dtypes: as the single batch takes them
             for k, P in enumerate(self._parts):
                 self.step_async(k, None if action is None else action[:, P.lo:P.hi] if soa else action[P.lo:P.hi])
             for k in range(len(self._parts)):
@@ -876,6 +938,8 @@ class FpvVecEnv:
         if self.object_list or self.batch._buf.objects:
             self.batch._set_objects(self.object_list)
             P._buf.objects = self.batch._buf.objects
+        w = self.wind                                   # read on every step, like the single batch's step(action, self.wind)
+        P._buf.wind[0], P._buf.wind[1], P._buf.wind[2] = w[0], w[1], w[2]
         P.launch(action)
 
     def step_wait(self, part: int, sync: bool = True) -> Tuple[torch.Tensor, torch.Tensor, torch.Tensor, Dict[str, Any]]:
@@ -900,15 +964,26 @@ class FpvVecEnv:
 
     def set_done_bits_target(self, target: Any = None) -> None:
         """Where the kernels write the bit-packed done mask (DroneBatch.set_done_bits_target); with partitions every
-        partition writes its own words of the same row (a partition starts at a multiple of 64 drones)."""
+        partition writes its own words of the same row (a partition starts at a multiple of 64 drones).  Host-side only: a
+        launch carries its target in its kernel arguments, so steps already enqueued still write the OLD target; the caller's
+        stream is ordered after them, so what it reads from the old target next is complete."""
+        self._caller_waits_for_partitions()
         self.batch.set_done_bits_target(target)
         for P in self._parts:
             P.rebind()
 
+    def set_params(self, params: DroneParams, auto_reset: Optional[bool] = None) -> None:
+        """New physics constants for the steps enqueued from now on - the batch's handle AND every partition's (each keeps
+        its own global drone ids).  Host-side only: a launch carries its constants in its kernel arguments, steps already
+        enqueued keep the ones they were launched with, exactly as on the single batch."""
+        self.batch.set_params(params, auto_reset)
+        for P in self._parts:
+            P.set_params()
+
     def state_dict(self) -> Dict[str, Any]:
-        """The batch's checkpoint; with partitions the step counters of all of them (they key the stick-noise streams)."""
-        for k in range(len(self._parts)):
-            self.step_wait(k)
+        """The batch's checkpoint; with partitions the step counters of all of them (they key the stick-noise streams).
+        The clones are ordered after every partition's last enqueued step."""
+        self._caller_waits_for_partitions()
         d = self.batch.state_dict()
         if self._parts:
             d["partition_step_counters"] = [P.steps_launched for P in self._parts]
@@ -916,17 +991,21 @@ class FpvVecEnv:
         return d
 
     def load_state_dict(self, d: Dict[str, Any]) -> None:
+        if not self._parts:
+            self.batch.load_state_dict(d)
+            return
+        ctr = d.get("partition_step_counters") or [d["step_counter"]] * len(self._parts)
+        if len(ctr) != len(self._parts):
+            raise ValueError("checkpoint was taken with a different number of partitions")
+        cur = self._caller_waits_for_partitions()      # a step still in flight must not land on top of the loaded state
         self.batch.load_state_dict(d)
-        if self._parts:
-            ctr = d.get("partition_step_counters") or [d["step_counter"]] * len(self._parts)
-            if len(ctr) != len(self._parts):
-                raise ValueError("checkpoint was taken with a different number of partitions")
-            cur = torch.cuda.current_stream(self.batch.device)
-            for P, c in zip(self._parts, ctr):
-                P.set_step_counter(c)
-                P.stream.wait_stream(cur)
+        for P, c in zip(self._parts, ctr):
+            P.set_step_counter(c)
+        self._partitions_wait_for(cur)
 
     def close(self) -> None:
-        for P in self._parts:
+        for P in self._parts:                          # a handle is destroyed only after its chain has drained
+            if getattr(P, "_handle", None) is not None and P._handle.value:
+                P.stream.synchronize()
             P.close()
         self.batch.close()
