@@ -27,6 +27,7 @@ import subprocess
 import sys
 import time
 
+T_PROCESS_START = time.monotonic()       # the job deadline of an N-rank run counts from here (supervise_rank)
 REPO = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, REPO)
 
@@ -243,27 +244,58 @@ def spawn_ranks(n_ranks, argv, port=None, python=sys.executable, wall_limit_s=15
     return 0
 
 
+def stage_limit(configured_s, time_left_s, later_attempts, reserve_s, margin_s=10.0):
+    """Wall limit of the next stage (a preflight or an attempt) of an N-rank job under ONE deadline: the configured limit,
+    cut to the time left minus what the stages after it must keep - `reserve_s` per attempt still in the plan, so that the
+    last resort (gloo, then no exchange at all) can still start, run and print - and minus `margin_s` for stopping a child
+    that hangs (terminate, grace, kill).  Returns 0.0 when less than 5 s would remain: the stage is skipped."""
+    lim = min(float(configured_s), float(time_left_s) - later_attempts * float(reserve_s) - margin_s)
+    return lim if lim >= 5.0 else 0.0
+
+
 def supervise_rank(args, raw_argv):
     """One rank of an N-rank job as the launcher started it - by torchrun (the driver's way) or by spawn_ranks.  This
     process stays GPU-FREE: it agrees with its peers over gloo on CPU tensors (fpyv_amd.dist.RankSupervisor) and runs
     everything that touches the GPU in fresh child processes it can stop by their PID, so the job cannot come back
-    empty-handed because RCCL would not start on this node:
+    empty-handed because RCCL would not start on this node - or because something hangs:
       1. RCCL preflight in fresh children (init + one all-gather of the rank ids, wall limit) with the caller's
          HSA_ENABLE_IPC_MODE_LEGACY; when that fails, once more with the other value;
       2. the worker (`--worker --collective rccl`) per rank; if the preflight failed, or the workers fail or hang, fresh
          workers once more with the done mask over gloo (host-staged), and as the last resort with no exchange;
       3. rank 0 prints the accepted worker's JSON line, with what happened in collective.{requested, backend, ipc_mode,
-         fallback_reason, preflight, attempts}.  Non-zero exit only when every attempt failed.
-    Loop being sharded: /root/reference/src/core/simulator.py:83-156."""
+         fallback_reason, preflight, attempts, budget}.  Non-zero exit only when every attempt failed.
+    ONE deadline bounds the sum (`--job-deadline-s`, counted from this process's start): every stage's limit is
+    min(its configured limit, time left - `--attempt-reserve-s` per attempt still in the plan - a stop margin), agreed
+    across the ranks (the minimum), recorded as `limit_s`; a stage with less than 5 s left is skipped, and past the
+    deadline the job ends with a non-zero code.  Children are always fresh processes - never an exec of one that has
+    touched the GPU.  Loop being sharded: /root/reference/src/core/simulator.py:83-156."""
     from fpyv_amd import dist as fd
     watch_parent()
+    deadline = T_PROCESS_START + args.job_deadline_s
     with stdout_to_stderr():                     # gloo announces itself on stdout
-        sup = fd.RankSupervisor()
+        sup = fd.RankSupervisor(timeout_s=args.job_deadline_s + 120.0)
     rank = sup.rank
     ipc_caller = os.environ.get(fd.IPC_ENV)
     ipc_mode = ipc_caller
     stub_pf = args.stub_preflight if args.stub_step else None
     preflights, attempts, final = [], [], None
+    reserve = args.attempt_reserve_s
+
+    def limit_for(configured, later_attempts):
+        # every rank's own clock, then the minimum over the ranks: all of them stop their children together
+        return sup.agree_min(stage_limit(configured, deadline - time.monotonic(), later_attempts, reserve))
+
+    def preflight(mode, later_attempts):
+        conf = args.preflight_timeout_s
+        allow = min(15.0, max(2.0, conf))                  # start-up of the child on top of the bring-up limit it is given
+        lim = limit_for(conf + allow, later_attempts)      # the child's wall limit
+        if lim <= 0:
+            return {"ok": False, "ipc_mode": mode, "seconds": 0.0, "limit_s": 0.0, "reasons": ["skipped: no time left under the job deadline"], "library_version": None}
+        inner = conf if lim >= conf + allow else max(2.0, lim - min(allow, 0.3 * lim))
+        res = sup.preflight(mode, inner, stub_pf, wall_s=lim)
+        res["limit_s"] = round(lim, 1)
+        return res
+
     if args.rehearse_on_one_gpu:
         plan = ["gloo"]                          # RCCL refuses two ranks on one device
     elif args.collective != "auto":
@@ -271,23 +303,28 @@ def supervise_rank(args, raw_argv):
     else:
         plan = ["rccl", "gloo", "none"]
         if not args.no_preflight:
-            res = sup.preflight(ipc_caller, args.preflight_timeout_s, stub_pf)
+            res = preflight(ipc_caller, later_attempts=3)          # (a second preflight comes out of the rccl attempt's share)
             preflights.append(res)
             if not res["ok"]:
                 alt = fd.other_ipc_mode(ipc_caller)
                 if rank == 0:
                     print(f"bench.py: RCCL preflight failed with {fd.IPC_ENV}={ipc_caller!r} ({'; '.join(res['reasons'])[:300]}); trying {alt!r}", file=sys.stderr)
-                res = sup.preflight(alt, args.preflight_timeout_s, stub_pf)
+                res = preflight(alt, later_attempts=2)              # RCCL will only be tried if this one passes: keep gloo's and none's shares
                 preflights.append(res)
                 if res["ok"]:
                     ipc_mode = alt
                 else:
                     plan = ["gloo", "none"]
     requested = "gloo" if args.rehearse_on_one_gpu else ("rccl" if args.collective == "auto" else args.collective)
-    for mode in plan:
+    for k, mode in enumerate(plan):
+        lim = limit_for(args.attempt_timeout_s, later_attempts=len(plan) - 1 - k)
+        if lim <= 0:
+            attempts.append({"collective": mode, "ipc_mode": ipc_mode, "ok": False, "seconds": 0.0, "limit_s": 0.0,
+                             "reasons": ["skipped: no time left under the job deadline"]})
+            continue
         port = sup.pick_port()
         cmd = [sys.executable, os.path.abspath(__file__)] + list(raw_argv) + ["--worker", "--collective", mode]
-        r = fd.run_child(cmd, sup.child_env(port, ipc_mode), args.attempt_timeout_s, capture_stdout=(rank == 0), on_start=sup.track)
+        r = fd.run_child(cmd, sup.child_env(port, ipc_mode), lim, capture_stdout=(rank == 0), on_start=sup.track)
         line, ok_local = None, r["rc"] == 0
         if rank == 0 and ok_local:
             cand = [ln for ln in r["stdout"].splitlines() if ln.lstrip().startswith("{")]
@@ -295,10 +332,10 @@ def supervise_rank(args, raw_argv):
                 line = json.loads(cand[-1])
             except (IndexError, ValueError):
                 ok_local = False
-        why = None if ok_local else (f"no result within {args.attempt_timeout_s:.0f} s" if r["timed_out"] else f"exit code {r['rc']}: {r['stderr_tail']}")
+        why = None if ok_local else (f"no result within {lim:.0f} s" if r["timed_out"] else f"exit code {r['rc']}: {r['stderr_tail']}")
         ok = sup.all_ok(ok_local)
         reasons = sup.gather_reasons(why)
-        attempts.append({"collective": mode, "ipc_mode": ipc_mode, "ok": ok, "seconds": round(r["seconds"], 2), "reasons": reasons})
+        attempts.append({"collective": mode, "ipc_mode": ipc_mode, "ok": ok, "seconds": round(r["seconds"], 2), "limit_s": round(lim, 1), "reasons": reasons})
         if ok:
             final = line
             break
@@ -306,6 +343,10 @@ def supervise_rank(args, raw_argv):
             print(f"bench.py: the run with --collective {mode} failed ({'; '.join(reasons)[:400]})"
                   + ("; starting fresh workers with the next fallback" if mode != plan[-1] else "; no fallback left"), file=sys.stderr)
     done = bool(attempts) and attempts[-1]["ok"]
+    used_s = time.monotonic() - T_PROCESS_START
+    if rank == 0 and not done:
+        print(f"bench.py: no attempt of the {sup.world}-rank job succeeded within the job deadline of {args.job_deadline_s:.0f} s ({used_s:.0f} s used): "
+              + "; ".join(f"{x['collective']}: {'; '.join(x['reasons'])[:200]}" for x in attempts), file=sys.stderr)
     if rank == 0 and done:
         c = final.setdefault("collective", {})
         used = attempts[-1]["collective"]
@@ -317,7 +358,9 @@ def supervise_rank(args, raw_argv):
                    else "run failed: " + "; ".join(failed_at[0]["reasons"]) if failed_at else "unknown")[:600]
         c.update(requested=requested, used=used, ipc_mode=ipc_mode, ipc_mode_of_caller=ipc_caller,
                  ipc_mode_source=os.environ.get("FPV_BENCH_IPC_MODE_SOURCE"), fallback_reason=why,
-                 preflight=preflights, attempts=attempts)
+                 preflight=preflights, attempts=attempts,
+                 budget={"job_deadline_s": args.job_deadline_s, "used_s": round(used_s, 1), "reserve_per_later_attempt_s": reserve,
+                         "rule": "limit of a stage = min(configured, time left - reserve x attempts still in the plan - 10 s), minimum over ranks"})
         print(json.dumps(final), flush=True)
     sup.close()
     return 0 if done else 1
@@ -400,8 +443,9 @@ def parse_args(argv=None):
     ap.add_argument("--dump-gathered", default=None,
                     help="with --rehearse-on-one-gpu: rank 0 saves the gathered done masks of the last bucket and every rank its "
                          "own final state to this directory (the test compares them with a single-process run)")
-    ap.add_argument("--spawn-timeout-s", type=float, default=1500.0,
-                    help="self-launched ranks (--gpus N outside a launcher): wall-clock limit of the whole job")
+    ap.add_argument("--spawn-timeout-s", type=float, default=0.0,
+                    help="self-launched ranks (--gpus N outside a launcher): wall-clock limit of the whole job; 0 (default) = the job "
+                         "deadline + 60 s (the supervisors end the job themselves at the deadline; this is the launcher's backstop)")
     ap.add_argument("--collective", choices=["auto", "rccl", "gloo", "none"], default="auto",
                     help="N > 1: what carries the done mask and the job's barriers.  auto (default): RCCL if a preflight in fresh "
                          "child processes brings it up (with the caller's HSA_ENABLE_IPC_MODE_LEGACY, then once with the other value), "
@@ -413,7 +457,13 @@ def parse_args(argv=None):
     ap.add_argument("--preflight-timeout-s", type=float, default=90.0,
                     help="wall limit of one RCCL preflight (init + one all-gather in fresh children; torch is already in the page "
                          "cache by then, so this is GPU + RCCL bring-up time only)")
-    ap.add_argument("--attempt-timeout-s", type=float, default=600.0, help="wall limit of one attempt of the N-rank run")
+    ap.add_argument("--attempt-timeout-s", type=float, default=600.0, help="wall limit of one attempt of the N-rank run (cut to what the job deadline leaves)")
+    ap.add_argument("--job-deadline-s", type=float, default=480.0,
+                    help="N > 1: ONE wall-clock deadline for the whole supervised job, counted from the start of the rank's process: "
+                         "every preflight and attempt gets min(its own limit, the time left minus --attempt-reserve-s per attempt still "
+                         "in the plan), so that a hang anywhere still leaves the last fallback time to print its line")
+    ap.add_argument("--attempt-reserve-s", type=float, default=75.0,
+                    help="N > 1: what every attempt still in the plan keeps for itself (process start, import, rendezvous, the short run)")
     ap.add_argument("--pg-timeout-s", type=float, default=180.0, help="process-group timeout inside a worker: a rank whose peer died leaves its collective after this long")
     ap.add_argument("--sustained-steps", type=int, default=2000,
                     help="N = 1, --api step: after the contract's K timed steps, this many more launches at the headline size, HIP-event "
@@ -424,6 +474,9 @@ def parse_args(argv=None):
                     help="TEST ONLY (with --stub-step): workers started with this --collective (or all) exit 1 after the rendezvous")
     ap.add_argument("--stub-hang-collective", choices=["", "rccl", "gloo"], default="",
                     help="TEST ONLY (with --stub-step): workers started with this --collective never come back (a collective that hangs)")
+    ap.add_argument("--stub-hang-before-init", choices=["", "rccl", "gloo", "all"], default="",
+                    help="TEST ONLY (with --stub-step): workers started with this --collective (or all) hang OUTSIDE any collective - before "
+                         "they join the process group, the way a GPU or library bring-up that never returns would")
     ap.add_argument("--stub-fail-rank", type=int, default=-1,
                     help="TEST ONLY (tests/test_bench_spawn.py): this rank exits 1 before it joins the process group")
     ap.add_argument("--stub-step", action="store_true",
@@ -546,7 +599,7 @@ def main(argv=None):
             if have < args.gpus:
                 raise SystemExit(f"bench.py --gpus {args.gpus} needs {args.gpus} GPUs on this node, found {have}; "
                                  f"run with --gpus {max(have, 1)} (or --force-dist to rehearse the collective path on one GPU)")
-        raise SystemExit(spawn_ranks(args.gpus, raw_argv, wall_limit_s=args.spawn_timeout_s))
+        raise SystemExit(spawn_ranks(args.gpus, raw_argv, wall_limit_s=args.spawn_timeout_s if args.spawn_timeout_s > 0 else args.job_deadline_s + 60.0))
 
     if args.gather_block <= 0:
         args.gather_block = 64 if args.steps + args.warmup >= 256 else 16
@@ -563,6 +616,9 @@ def main(argv=None):
         watch_parent()
     collective = "gloo" if args.rehearse_on_one_gpu else ("rccl" if args.collective == "auto" else args.collective)
     if args.stub_step:
+        if args.worker and args.stub_hang_before_init in (collective, "all"):
+            print(f"stub: the {collective} worker of rank {rank} hangs before it joins the process group", file=sys.stderr)
+            time.sleep(3600)
         raise SystemExit(run_stub(args, world, rank, collective))
 
     import torch
@@ -862,6 +918,8 @@ def main(argv=None):
                   "host_enqueue_us": leg["host_enqueue_us"], "host_bound": leg["host_bound"],
                   "achieved": gbs, "frac": gbs / HBM_PEAK_GBS, "env_steps_per_s": nb / (us * 1e-6),
                   "copy_ceiling_GBs": ceiling, "frac_of_copy_ceiling": gbs / ceiling,
+                  "addresses": {"state": hex(big.state.data_ptr()), "ld": big.ld, "action": hex(acts_b.data_ptr()),
+                                "reward": hex(big.reward.data_ptr()), "done": hex(big.done.data_ptr())},
                   "copy_GBs": {"float4_before": copy_before, "float4_after": copy_after, "dword": copy_dword,
                                "bytes_per_launch": 8 * cf,
                                "what": "fpv_diag_stream_copy_wide / fpv_diag_stream_copy: dst[i] = src[i], read + write bytes equal to one "

@@ -310,6 +310,12 @@ class RankSupervisor:
         self.dist.broadcast_object_list(box, src=0)
         return int(box[0])
 
+    def agree_min(self, value: float) -> float:
+        """The smallest of the ranks' values (a wall limit every rank derived from its own clock)."""
+        t = torch.tensor([float(value)], dtype=torch.float64)
+        self.dist.all_reduce(t, op=self.dist.ReduceOp.MIN)
+        return float(t.item())
+
     def all_ok(self, ok: bool) -> bool:
         t = torch.tensor([1 if ok else 0], dtype=torch.int64)
         self.dist.all_reduce(t, op=self.dist.ReduceOp.MIN)
@@ -336,13 +342,17 @@ class RankSupervisor:
             env[IPC_ENV] = ipc_mode
         return env
 
-    def preflight(self, ipc_mode: Optional[str], limit_s: float, stub: Optional[str] = None, python: Optional[str] = None) -> dict:
-        """One RCCL preflight across all ranks in fresh children; returns {"ok", "ipc_mode", "seconds", "reasons", "info"}."""
+    def preflight(self, ipc_mode: Optional[str], limit_s: float, stub: Optional[str] = None, python: Optional[str] = None,
+                  wall_s: Optional[float] = None) -> dict:
+        """One RCCL preflight across all ranks in fresh children; returns {"ok", "ipc_mode", "seconds", "reasons", "info"}.
+        `limit_s` is the bring-up limit the child gives its process group; `wall_s` the wall limit of the child itself
+        (default: limit_s plus a start-up allowance of up to 15 s) - a caller under a deadline passes what it has left."""
         import json
         import sys
         port = self.pick_port()
         cmd = [python or sys.executable, "-m", "fpyv_amd.dist", "--preflight", "--limit-s", str(limit_s)] + (["--stub", stub] if stub else [])
-        r = run_child(cmd, self.child_env(port, ipc_mode), limit_s + min(15.0, max(2.0, limit_s)), capture_stdout=True, on_start=self.track)   # + start-up of the child
+        wall = float(wall_s) if wall_s is not None else limit_s + min(15.0, max(2.0, limit_s))      # + start-up of the child
+        r = run_child(cmd, self.child_env(port, ipc_mode), wall, capture_stdout=True, on_start=self.track)
         ok = r["rc"] == 0
         info = None
         if ok:

@@ -142,6 +142,56 @@ def test_a_run_that_hangs_in_the_collective_is_stopped_and_repeated_with_the_fal
     assert not left, f"workers left behind: {left}"
 
 
+def test_stage_limits_share_one_deadline():
+    """bench.stage_limit: a stage gets min(its configured limit, time left - reserve x attempts still in the plan - margin);
+    under 5 s it is skipped.  The defaults (480 s deadline, 75 s reserve): a hanging preflight pair and a hanging RCCL run
+    still leave gloo and the exchange-free run their shares."""
+    sys.path.insert(0, REPO)
+    import bench
+    assert bench.stage_limit(600, 480, 2, 75) == 480 - 150 - 10           # the rccl attempt cannot eat the fallbacks' time
+    assert bench.stage_limit(90, 480, 3, 75) == 90                          # plenty left: the configured limit stands
+    assert bench.stage_limit(600, 100, 1, 75) == 15 and bench.stage_limit(600, 89, 1, 75) == 0.0     # < 5 s: skipped
+    left, spent = 480.0, []
+    for conf, later in ((105, 3), (105, 2), (600, 1), (600, 0)):            # everything hangs: pf, pf, gloo, none
+        lim = bench.stage_limit(conf, left, later, 75)
+        assert lim > 0
+        spent.append(lim); left -= lim + 10                                 # a stopped stage costs its limit + the stop margin
+    assert left >= 0 and spent[-1] >= 75 - 10 - 1, (left, spent)
+
+
+def test_a_worker_that_hangs_outside_the_collective_still_leaves_time_for_the_fallback():
+    """a worker that hangs where no process-group timeout can reach it (GPU or library bring-up).  With ONE
+    job deadline the RCCL attempt's limit is what the deadline leaves after the fallbacks' shares - not its own 600 s - so
+    the gloo attempt still runs and its line is printed before the deadline; every stage records its limit."""
+    r, lines, took = _run_stub(["--stub-hang-before-init", "rccl", "--job-deadline-s", "70", "--attempt-reserve-s", "14"])
+    assert r.returncode == 0, r.stderr[-3000:]
+    assert len(lines) == 1 and took < 70, took
+    c = json.loads(lines[0])["collective"]
+    assert [(a["collective"], a["ok"]) for a in c["attempts"]] == [("rccl", False), ("gloo", True)]
+    assert c["attempts"][0]["limit_s"] < 70 - 2 * 14 and "no result within" in c["attempts"][0]["reasons"][0]
+    assert c["attempts"][1]["limit_s"] <= 70 - 14 and c["preflight"][0]["limit_s"] > 0
+    assert c["budget"]["job_deadline_s"] == 70 and c["budget"]["used_s"] < 70 and c["used"] == "gloo"
+
+
+def test_when_everything_hangs_the_job_ends_non_zero_at_the_deadline():
+    """Preflights hang, then every worker hangs before it joins a process group: each stage is stopped at its share and the
+    job returns a non-zero code within the deadline (plus the stop margin), with no line and no process left behind."""
+    r, lines, took = _run_stub(["--stub-preflight", "hang", "--stub-hang-before-init", "all", "--job-deadline-s", "60",
+                                "--attempt-reserve-s", "8", "--preflight-timeout-s", "6"])
+    assert r.returncode != 0 and not lines, (r.returncode, lines)
+    assert took < 60 + 15, took
+    assert "within the job deadline of 60 s" in r.stderr and "gloo: " in r.stderr and "none: " in r.stderr
+    import time
+    left = []
+    for _ in range(20):
+        left = [ln for ln in subprocess.run(["pgrep", "-af", "stub-hang-before-init all"], capture_output=True, text=True).stdout.splitlines()
+                if "pgrep" not in ln]
+        if not left:
+            break
+        time.sleep(0.5)
+    assert not left, f"processes left behind: {left}"
+
+
 def test_when_every_fallback_fails_the_job_fails_within_the_limit():
     r, lines, took = _run_stub(["--stub-fail-collective", "all"])
     assert r.returncode != 0 and not lines
