@@ -91,19 +91,29 @@ __device__ __forceinline__ T& row_at(T* row_base, uint32_t i)
 #ifndef FPV_EXP_ST_NT
 #define FPV_EXP_ST_NT 0
 #endif
-#if FPV_EXP_LD_NT
-#define LDROW(st, r, ld, i) __builtin_nontemporal_load(&row_at(ROW(st, r, ld), i))
+#ifndef FPV_EXP_ROWSKEW
+#define FPV_EXP_ROWSKEW 0
+#endif
+#if FPV_EXP_ROWSKEW      // experiment (tools/rowskew_search.py): every state row moved by its own offset (floats), set from the host
+__constant__ int64_t fpv_exp_skew[16];
+extern "C" int fpv_exp_set_skew(const int64_t* skew) { return (int)hipMemcpyToSymbol(HIP_SYMBOL(fpv_exp_skew), skew, sizeof(int64_t) * 16); }
+#define SROW(st, r, ld) ((st) + (int64_t)(r) * (ld) + fpv_exp_skew[(r)])
 #else
-#define LDROW(st, r, ld, i) row_at(ROW(st, r, ld), i)
+#define SROW(st, r, ld) ROW(st, r, ld)
+#endif
+#if FPV_EXP_LD_NT
+#define LDROW(st, r, ld, i) __builtin_nontemporal_load(&row_at(SROW(st, r, ld), i))
+#else
+#define LDROW(st, r, ld, i) row_at(SROW(st, r, ld), i)
 #endif
 #if FPV_EXP_ST_NT == 2       // write-through and drop from L2: global_store ... sc0 sc1
-#define STROW(st, r, ld, i, v) __hip_atomic_store(&row_at(ROW(st, r, ld), i), (v), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM)
+#define STROW(st, r, ld, i, v) __hip_atomic_store(&row_at(SROW(st, r, ld), i), (v), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM)
 #elif FPV_EXP_ST_NT == 3     // agent scope: sc1
-#define STROW(st, r, ld, i, v) __hip_atomic_store(&row_at(ROW(st, r, ld), i), (v), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)
+#define STROW(st, r, ld, i, v) __hip_atomic_store(&row_at(SROW(st, r, ld), i), (v), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)
 #elif FPV_EXP_ST_NT
-#define STROW(st, r, ld, i, v) __builtin_nontemporal_store((v), &row_at(ROW(st, r, ld), i))
+#define STROW(st, r, ld, i, v) __builtin_nontemporal_store((v), &row_at(SROW(st, r, ld), i))
 #else
-#define STROW(st, r, ld, i, v) (row_at(ROW(st, r, ld), i) = (v))
+#define STROW(st, r, ld, i, v) (row_at(SROW(st, r, ld), i) = (v))
 #endif
 
 __device__ __forceinline__ void ld_drone(const float* __restrict__ st, int64_t ld, uint32_t i, FpvDroneState& s)

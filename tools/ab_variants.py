@@ -18,6 +18,7 @@ VARIANTS = {
     "ld_st_nt": ["-DFPV_EXP_LD_NT=1", "-DFPV_EXP_ST_NT=1"],
     "st_sys": ["-DFPV_EXP_ST_NT=2"],          # state stores write through and leave L2 (sc0 sc1)
     "st_agent": ["-DFPV_EXP_ST_NT=3"],        # agent-scope stores (sc1)
+    "rowskew": ["-DFPV_EXP_ROWSKEW=1"],       # per-row offsets of the state matrix from a __constant__ table (tools/rowskew_search.py)
 }
 ap = argparse.ArgumentParser()
 ap.add_argument("--build", action="store_true")

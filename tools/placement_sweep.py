@@ -12,6 +12,7 @@ launches) while one placement parameter moves at a time:
   action  the action ring's offset relative to a 2 MiB boundary
   reward  the reward row's offset;   done  the done row's offset
   gap     distance between the state matrix and the action ring (MiB)
+  stream  the stream the launches go to (null stream, fresh streams, high-priority streams), same buffers
 
     python tools/placement_sweep.py [--n 8388608] [--sweeps shift ld action reward done gap]
 """
@@ -41,7 +42,11 @@ env = DroneBatch(params, n, device=dev, auto_reset=True, with_accel=False)
 ld0 = env.ld
 keep = (env.state, env.reward, env.done)           # the batch's own tensors stay alive (and unused)
 ring_src = sticks.ema_noise_device(ring, n, dev, seed=99)
-arena_bytes = 14 * (n + (1 << 18)) * 4 + ring * n * 16 + n * 5 + 512 * MiB
+BIG_PADS = [256, (1 << 16) + 256, (1 << 18) + 256, (1 << 19) + 256, (1 << 20) + 256, 3 * (1 << 19) + 256, (1 << 21) + 256, 3 * (1 << 20) + 256,
+            (1 << 22) + 256, 5 * (1 << 20) + 256, 6 * (1 << 20) + 256, 7 * (1 << 20) + 256, (1 << 23) + 256, 3 * (1 << 22) + 256,
+            (1 << 20) + (1 << 16) + 256, (1 << 21) + (1 << 19) + (1 << 17) + 256, 1234567 // 64 * 64 + 256, 2718281 // 64 * 64 + 256, 5555555 // 64 * 64 + 256]
+max_pad = max(BIG_PADS) if "ldbig" in a.sweeps else (1 << 18)
+arena_bytes = 14 * (n + max_pad) * 4 + ring * n * 16 + n * 5 + 512 * MiB
 arena = torch.empty(arena_bytes, dtype=torch.uint8, device=dev)
 base = (arena.data_ptr() + 2 * MiB - 1) // (2 * MiB) * (2 * MiB) - arena.data_ptr()       # first 2 MiB boundary inside the arena
 print(f"n = {n}, recommended ld = {ld0} (n + {ld0 - n}), arena at 0x{arena.data_ptr():x}, 2 MiB-aligned origin at +{base}", flush=True)
@@ -101,11 +106,28 @@ for _ in range(30):
     env.rollout(acts, fused=False)
 torch.cuda.synchronize()
 KiB = 1024
+if "stream" in a.sweeps:
+    # the same buffers, the same kernel, another stream: torch's null stream, fresh streams (each may sit on another hardware
+    # queue), high-priority streams
+    print("--- the stream the launches go to (same buffers)", flush=True)
+    acts = place()
+    cand = [("null stream", torch.cuda.default_stream(dev))] + [(f"new stream {k}", torch.cuda.Stream(device=dev)) for k in range(10)] \
+        + [(f"high-priority stream {k}", torch.cuda.Stream(device=dev, priority=-1)) for k in range(3)]
+    res = {name: [] for name, _ in cand}
+    for r in range(a.rounds):
+        for name, st in cand:
+            with torch.cuda.stream(st):
+                res[name].append(timed(acts))
+    for name, st in cand:
+        med = statistics.median(res[name])
+        print(f"  {name:>24s} (0x{st.cuda_stream:x}): median {med:8.2f} us  min {min(res[name]):8.2f}  {133 * n / med / 1e3:7.0f} GB/s", flush=True)
 if "shift" in a.sweeps:
     sweep("everything shifted together (bytes)", "shift", [0, 256, 4 * KiB, 64 * KiB, 1 * MiB, 2 * MiB, 34 * MiB, 254 * MiB], lambda v: f"{v}")
 if "ld" in a.sweeps:
     pads = [64, 256, 320, 512, 768, 1024, 1536, 2048 + 256, 2048 + 1024, 4096 + 256, 4096 + 2048, 8192 + 256, 16384 + 512, 32768 + 1024, 65536 + 256, 131072 + 512, 131072 + 65536]
     sweep("row stride of the state matrix: ld = n + pad (floats)", "ld", [n + p for p in pads], lambda v: f"n+{v - n}")
+if "ldbig" in a.sweeps:
+    sweep("row stride, large pads: ld = n + pad (floats)", "ld", [n + p for p in BIG_PADS], lambda v: f"n+{v - n}")
 if "action" in a.sweeps:
     sweep("action ring offset from its 2 MiB boundary (bytes)", "a_off", [0, 256, 1 * KiB, 4 * KiB, 16 * KiB, 64 * KiB, 256 * KiB, 1 * MiB], lambda v: f"{v}")
 if "reward" in a.sweeps:
