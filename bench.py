@@ -164,6 +164,41 @@ def cpu_baseline(params, seconds_budget=12.0):
         oracle.drone_run(params, st1, a1, threads=1, native=True)
     one_core = n1 * a1.shape[0] * reps / (time.perf_counter() - t0)
     del L
+    # the host's best: the same float64 arithmetic with the DRONES as the vector axis (oracle/fpv_oracle_simd.c: SoA tiles of
+    # 256 drones, `omp simd` over the tile, libmvec sin / cos, -O3 -march=native), all usable cores, time-outer per tile;
+    # checked to 1e-12 against the scalar oracle in tests/test_numpy_port.py.  ~5 s
+    simd = None
+    try:
+        sts = oracle.drone_initial_state(n, params.init_position, params.init_velocity, params.init_orientation_deg)
+        oracle.drone_run_simd(params, sts, acts[:2], threads=threads, native=True)
+        s_steps, t0 = 0, time.perf_counter()
+        while True:
+            oracle.drone_run_simd(params, sts, acts, threads=threads, native=True)
+            s_steps += acts.shape[0]
+            s_el = time.perf_counter() - t0
+            if s_el > 5.0:
+                break
+        simd_all = n * s_steps / s_el
+        sts1 = oracle.drone_initial_state(n1, params.init_position, params.init_velocity, params.init_orientation_deg)
+        oracle.drone_run_simd(params, sts1, a1[:2], threads=1, native=True)
+        t0 = time.perf_counter()
+        for _ in range(reps):
+            oracle.drone_run_simd(params, sts1, a1, threads=1, native=True)
+        simd_one = n1 * a1.shape[0] * reps / (time.perf_counter() - t0)
+        isa = "unknown"
+        try:
+            fl = open("/proc/cpuinfo").read()
+            isa = "AVX-512" if " avx512f" in fl else "AVX2" if " avx2" in fl else "AVX" if " avx " in fl else "SSE2"
+        except OSError:
+            pass
+        simd = {"value": simd_all, "unit": "env-steps/s", "kind": "port", "cores": threads, "one_thread_value": simd_one, "vector_isa_of_host": isa,
+                "over_scalar_port": simd_all / all_cores,
+                "sample": f"{n} drones x {s_steps} steps of the same sticks, oracle/fpv_oracle_simd.c: float64, structure-of-arrays tiles of 256 drones, "
+                          f"`#pragma omp simd` over the drones of a tile (gcc -O3 -march=native -ffp-contract=off, libmvec sin / cos), OpenMP over tiles with "
+                          f"{threads} threads, time-outer inside a tile; same arithmetic as the scalar port (1e-12, tests/test_numpy_port.py)"
+                          + ("" if simd_all >= all_cores else "; SLOWER than the scalar port on this host - kept as evidence")}
+    except Exception as e:                      # noqa: BLE001  (a missing libmvec / compiler on some host must not cost the line)
+        simd = {"value": None, "error": f"{type(e).__name__}: {e}"[:300]}
     # the "idiomatic Python" baseline - the same step written with NumPy over a drone axis
     # (oracle/numpy_port.py, checked against the C oracle in tests/test_numpy_port.py); ~3 s of it
     from oracle import numpy_port
@@ -176,13 +211,21 @@ def cpu_baseline(params, seconds_budget=12.0):
         numpy_port.step(params, Sn, an[np_steps % an.shape[0]])
         np_steps += 1
     numpy_rate = nn * np_steps / (time.perf_counter() - t0)
-    return {"value": all_cores, "unit": "env-steps/s", "cores": threads, "kind": "port",
-            "sample": f"{n} drones x {steps_done} steps of EMA-noise sticks, float64 C restatement of Drone.step "
-                      f"(oracle/fpv_oracle.c, gcc -O3 -march=native -fno-tree-vectorize), OpenMP: {threads} threads each walking a contiguous "
-                      f"drone tile time-outer; 1-thread rate {one_core:.3e} env-steps/s (speed-up {all_cores / one_core:.1f}x with "
-                      f"{usable} usable of {os.cpu_count()} logical CPUs: nproc / cgroup quota); reference's own Python Drone.step, timed in the build container only "
-                      f"(it cannot travel): 2.7e3-4.0e3 env-steps/s on one core (profiles/r01_reference_python_timing.json)",
-            "one_thread_value": one_core, "host_cpus": os.cpu_count(), "usable_cpus": usable, "threads_used": threads,
+    scalar = {"value": all_cores, "unit": "env-steps/s", "cores": threads, "kind": "port", "one_thread_value": one_core,
+              "sample": f"{n} drones x {steps_done} steps of EMA-noise sticks, float64 C restatement of Drone.step "
+                        f"(oracle/fpv_oracle.c, gcc -O3 -march=native -fno-tree-vectorize: one drone at a time), OpenMP: {threads} threads each walking a "
+                        f"contiguous drone tile time-outer; 1-thread rate {one_core:.3e} env-steps/s (speed-up {all_cores / one_core:.1f}x)"}
+    best_is_simd = bool(simd.get("value")) and simd["value"] > all_cores
+    best = simd if best_is_simd else scalar
+    # the reported baseline is the host's BEST leg (a scalar per-drone port flatters the GPU); both legs and the
+    # NumPy one stay on the line
+    return {"value": best["value"], "unit": "env-steps/s", "cores": threads, "kind": "port",
+            "leg": "simd_across_drones" if best_is_simd else "scalar_per_drone",
+            "sample": best["sample"] + f"; {usable} usable of {os.cpu_count()} logical CPUs (nproc / cgroup quota); reference's own Python Drone.step, timed in the "
+                      f"build container only (it cannot travel): 2.7e3-4.0e3 env-steps/s on one core (profiles/r01_reference_python_timing.json)",
+            "one_thread_value": best["one_thread_value"], "host_cpus": os.cpu_count(), "usable_cpus": usable, "threads_used": threads,
+            "scalar_per_drone": scalar,
+            "simd_across_drones": simd,
             "numpy_vectorised": {"value": numpy_rate, "unit": "env-steps/s", "kind": "port",
                                  "sample": f"{nn} drones x {np_steps} steps, oracle/numpy_port.py (float64 NumPy over a drone axis: the idiomatic-Python "
                                            f"batching of Drone.step, SURVEY 8d iii), NumPy {np.__version__} as it threads itself on this host"},
@@ -711,7 +754,9 @@ def main(argv=None):
         if venv is not None and e is env:
             # split phase: every partition's chain gets its step t; nothing joins the chains between steps (a policy
             # would sit between step_wait(part) and step_async(part) of ONE partition while the other one steps)
-            sl = part_slices.setdefault(acts.data_ptr(), [[acts[r][lo:hi] for lo, hi in part_ranges] for r in range(rlen)])
+            sl = part_slices.get(acts.data_ptr())
+            if sl is None:                          # built once per ring (a setdefault would build the 2 x ring slices on every call)
+                sl = part_slices[acts.data_ptr()] = [[acts[r][lo:hi] for lo, hi in part_ranges] for r in range(rlen)]
             for t in range(t_base, t_base + k):
                 row = sl[t % rlen]
                 for kk in range(venv.partitions):

@@ -182,6 +182,47 @@ def drone_run(p, state: np.ndarray, actions: np.ndarray, steps: Optional[int] = 
     return state, accel, done
 
 
+def simd_lib(native: bool = False) -> C.CDLL:
+    """fpv_oracle_simd.c (Drone.step with the drones as the vector axis): the portable build for the tests, or the
+    -march=native build on the host that runs bench.py's cpu_baseline.simd_across_drones leg."""
+    name = "libfpv_oracle_simd_native.so" if native else "libfpv_oracle_simd.so"
+    if name not in _libs:
+        if native:
+            subprocess.run(["make", "-C", _HERE, "-B", os.path.join("_build", name)], check=True, stdout=subprocess.DEVNULL)
+        elif not os.path.isfile(os.path.join(_BUILD, name)):
+            subprocess.run(["make", "-C", _HERE], check=True, stdout=subprocess.DEVNULL)
+        L = C.CDLL(os.path.join(_BUILD, name))
+        dp, u8p = C.POINTER(C.c_double), C.POINTER(C.c_uint8)
+        L.fpvs_drone_step_batch.argtypes = [C.POINTER(OracleParams), C.c_int64, C.c_int, dp, dp, C.c_int, dp, dp, u8p, C.c_int]
+        L.fpvs_drone_step_batch.restype = C.c_int
+        _libs[name] = L
+    return _libs[name]
+
+
+def drone_run_simd(p, state: np.ndarray, actions: np.ndarray, steps: Optional[int] = None,
+                   wind=(0.0, 0.0, 0.0), threads: int = 1, native: bool = False
+                   ) -> Tuple[np.ndarray, np.ndarray, np.ndarray]:
+    """drone_run through the SIMD-across-drones build (same arguments, same results to rounding level)."""
+    n = state.shape[0]
+    assert state.shape == (n, DRONE_STATE) and state.dtype == np.float64 and state.flags.c_contiguous
+    actions = np.ascontiguousarray(actions, dtype=np.float64)
+    per_step = actions.ndim == 3
+    if per_step:
+        steps = actions.shape[0] if steps is None else steps
+        assert actions.shape == (steps, n, 4)
+    else:
+        assert steps is not None and actions.shape == (n, 4)
+    accel = np.zeros((n, 3))
+    done = np.zeros(n, dtype=np.uint8)
+    w = np.asarray(wind, dtype=np.float64)
+    op = pack_params(p)
+    rc = simd_lib(native).fpvs_drone_step_batch(C.byref(op), n, steps, _dp(state), _dp(actions), int(per_step), _dp(w),
+                                                _dp(accel), done.ctypes.data_as(C.POINTER(C.c_uint8)), threads)
+    if rc != 0:
+        raise ValueError("the SIMD-across-drones build covers object_list = [] or [Ground] only")
+    return state, accel, done
+
+
 def drone_run_guided(p, state: np.ndarray, actions: np.ndarray, rotations, thrust_forces, wind=(0.0, 0.0, 0.0)
                      ) -> Tuple[np.ndarray, np.ndarray, np.ndarray]:
     """One drone (state [19]), T steps with the guidance arguments of Drone.step (components.py:230-232):
