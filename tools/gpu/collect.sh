@@ -1,0 +1,51 @@
+# copies what tools/gpu/measure.sh <round> left under gpurun_out/<round>/ into profiles/ (the tracked, judged copies)
+set -e
+R=${1:-r05}
+STAGE=${2:-all}
+cd "$(dirname "$0")/../.."
+O=gpurun_out/$R; P=profiles
+last() { tail -n 1 "$1" > "$2"; }
+if [ "$STAGE" != bench ]; then
+cp $O/pmc_traffic.json $O/pmc_valu.json $O/${R}_pmc_summary.md $O/${R}_kernel_stats.csv $O/${R}_beyond_mall_counters.md $P/
+cp $O/valu_counts.log      $P/${R}_pmc_valu_counts.log
+cp $O/gpu_tests.log        $P/${R}_gpu_tests.log
+f=$(ls -t $O/prof_kt_variants/*/*_kernel_stats.csv | head -1); cp "$f" $P/${R}_kernel_stats_variants.csv
+fi
+if [ "$STAGE" = counters ]; then exit 0; fi
+last $O/bench_step.json              $P/${R}_bench_n1_step.json
+last $O/bench_step_20.json           $P/${R}_bench_n1_step_20steps.json
+last $O/bench_partitions2.json       $P/${R}_bench_n1_step_partitions2.json
+last $O/bench_rollout.json           $P/${R}_bench_n1_rollout.json
+last $O/bench_fp16.json              $P/${R}_bench_n1_fp16.json
+last $O/bench_fp16_rollout.json      $P/${R}_bench_n1_fp16_rollout.json
+last $O/bench_racerW.json            $P/${R}_bench_n1_racerW.json
+last $O/bench_racerD.json            $P/${R}_bench_n1_racerD.json
+last $O/bench_forcedist.json         $P/${R}_bench_n1_forcedist.json
+last $O/bench_forcedist_20.json      $P/${R}_bench_n1_forcedist_20steps.json
+last $O/bench_rehearsal_2ranks.json  $P/${R}_bench_rehearsal_2ranks_on_one_gpu.json
+python3 - $O $P/${R}_ab_partitions_20steps.json <<'PY'
+import json, sys
+out = {}
+for k in ("p1", "p2"):
+    rows = []
+    for i in (1, 2, 3):
+        d = json.loads(open(f"{sys.argv[1]}/bench_{k}_20_{i}.json").read().strip().splitlines()[-1]); r = d["roofline"]
+        rows.append({"ms_per_step": d["ms_per_step"], "event_us_per_step": r["avg_launch_us"], "host_enqueue_us_per_step": r["host_enqueue_us"]})
+    out["partitions=2" if k == "p2" else "single chain"] = rows
+json.dump(out, open(sys.argv[2], "w"), indent=1)
+PY
+cp $O/closed_loop.log      $P/${R}_exp_closed_loop_split_phase.log
+cp $O/sweep.json           $P/${R}_sweep_variants.json
+cp $O/sweep.log            $P/${R}_sweep_variants.log
+cp $O/sweep_4096.log       $P/${R}_sweep_4096_drones.log
+grep -v amdgpu.ids $O/beyond_combos.log > $P/${R}_exp_beyond_combos_state_x_action.log
+grep -v amdgpu.ids $O/beyond_sizes.log  > $P/${R}_exp_beyond_sizes.log
+python3 - <<'PY'
+import json, sys
+sys.path.insert(0, ".")
+import bench
+h = bench.kernel_source_hash()
+for f in ("profiles/pmc_traffic.json", "profiles/pmc_valu.json"):
+    j = json.load(open(f))
+    print(f, j["kernel_source_sha256_16"], "ok" if j["kernel_source_sha256_16"] == h else f"STALE (sources {h})")
+PY
