@@ -147,10 +147,10 @@ template <int D> static int launch_d(const SrvArgs& A, hipStream_t stream, int* 
     int dev = 0, cus = 0, blocks = 0;
     if (hipGetDevice(&dev) != hipSuccess || hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess) SRV_FAIL("device query failed");
     if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&blocks, fpv_env_server_kernel<D>, 64, 0) != hipSuccess) SRV_FAIL("occupancy query failed");
-    // all waves must be resident at once (a wave that is not can never arrive at the step barrier); the occupancy
-    // API can be one block per CU high (microarchitecture guide), and the policy's kernels need slots of their own: ask for
-    // no more than (blocks - 1) per CU
-    const int limit = (blocks - 1) * cus;
+    // all waves must be resident at once (a wave that is not can never arrive at the step barrier).  These kernels are
+    // VGPR-bound at 1 - 4 waves per SIMD (the occupancy query's known one-block overshoot concerns SGPR-bound kernels); if
+    // the query is wrong anyway, the step barrier never completes, every wait runs into its cap and the kernel leaves
+    const int limit = blocks * cus;
     *waves_per_cu = (int)((A.waves + cus - 1) / cus); *resident_limit = limit;
     if ((int64_t)A.waves > (int64_t)limit) SRV_FAIL("grid of %u waves cannot be fully resident with a margin (%d blocks per CU x %d CUs by the occupancy query): use more drones per lane or fewer drones", A.waves, blocks, cus);
     hipLaunchKernelGGL(fpv_env_server_kernel<D>, dim3(A.waves), dim3(64), 0, stream, A);
