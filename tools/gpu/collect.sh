@@ -38,8 +38,8 @@ cp $O/closed_loop.log      $P/${R}_exp_closed_loop_split_phase.log
 cp $O/sweep.json           $P/${R}_sweep_variants.json
 cp $O/sweep.log            $P/${R}_sweep_variants.log
 cp $O/sweep_4096.log       $P/${R}_sweep_4096_drones.log
-grep -v amdgpu.ids $O/beyond_combos.log > $P/${R}_exp_beyond_combos_state_x_action.log
-grep -v amdgpu.ids $O/beyond_sizes.log  > $P/${R}_exp_beyond_sizes.log
+grep -v amdgpu.ids $O/beyond_combos.log > $P/${R}_exp_beyond_combos_state_x_action_run2.log
+grep -v amdgpu.ids $O/beyond_sizes.log  > $P/${R}_exp_beyond_sizes_run2.log
 python3 - <<'PY'
 import json, sys
 sys.path.insert(0, ".")
