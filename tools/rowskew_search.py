@@ -95,6 +95,10 @@ else:
     todo = [(list(range(R)), [r * 256 for r in range(R)])]                    # the shipped layout's analogue: consecutive, 1 KiB apart
     for _ in range(configs):
         slots = rng.sample(range(nslots), R) if mode == 0 else [s + rng.randrange(nslots - R) * 0 for s in range(R)]
+        if mode == 4:                            # all 14 rows inside the arena's first 1 GiB (31 slots of 33 MiB), irregular spacing
+            slots = rng.sample(range(31), R)
+        if mode == 5:                            # rows in the LAST 14 + k slots of the arena
+            slots = rng.sample(range(nslots - 20, nslots), R)
         if mode == 1:
             first = rng.randrange(nslots - R)
             slots = [first + r for r in range(R)]
