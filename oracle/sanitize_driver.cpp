@@ -1,4 +1,4 @@
-// sanitize_driver.cpp - runs every entry point of the two CPU builds (the float64 oracle and the
+// sanitize_driver.cpp - runs every entry point of the CPU builds (the float64 oracle, its SIMD-across-drones form and the
 // host build of the kernel's lane arithmetic) under AddressSanitizer + UndefinedBehaviorSanitizer.
 //
 // TEST INFRASTRUCTURE ONLY (`make -C oracle asan`, run by tests/test_sanitizers.py).  Inputs are
@@ -15,6 +15,8 @@
 #include "fpv_oracle.h"
 
 extern "C" {
+int fpvs_drone_step_batch(const fpvo_params* P, int64_t n, int steps, double* state, const double* actions, int action_per_step,
+                          const double wind[3], double* accel, uint8_t* done, int threads);
 int fpvl_run(const fpv_params_t* P, int64_t n, int steps, float* st, int64_t ld, const float* actions, int per_step,
              const float wind[3], float* accel, uint8_t* done, float* reward);
 int fpvl_run_h(const fpv_params_t* P, int64_t n, int steps, float* pos, uint32_t* sh, int64_t ld, const float* actions,
@@ -179,6 +181,13 @@ int main()
             for (int64_t i = 0; i < n; ++i) { double* s = &st[(size_t)i * FPVO_DRONE_STATE]; s[2] = 0.4 + 0.3 * urand(); s[3] = 1.0; s[6] = s[10] = s[14] = 1.0; }
             fpvo_drone_step_batch(&P, n, steps, st.data(), actsd.data(), 1, windd, acc.data(), done.data(), 1);
             fpvo_drone_step_batch(&P, n, 3, st.data(), actsd.data(), 0, windd, nullptr, nullptr, 0);
+            // the SIMD-across-drones form of the same step (fpv_oracle_simd.c): ragged tiles, per-step and held sticks; a
+            // general object list must be refused
+            std::vector<double> sv((size_t)n * FPVO_DRONE_STATE, 0.0);
+            for (int64_t i = 0; i < n; ++i) { double* s = &sv[(size_t)i * FPVO_DRONE_STATE]; s[2] = 0.4 + 0.3 * urand(); s[3] = 1.0; s[6] = s[10] = s[14] = 1.0; }
+            const int rc1 = fpvs_drone_step_batch(&P, n, steps, sv.data(), actsd.data(), 1, windd, acc.data(), done.data(), 1);
+            const int rc2 = fpvs_drone_step_batch(&P, n, 3, sv.data(), actsd.data(), 0, windd, nullptr, nullptr, 0);
+            if ((variant == 2) != (rc1 != 0) || rc1 != rc2) { fprintf(stderr, "fpvs_drone_step_batch: unexpected return codes %d %d\n", rc1, rc2); return 5; }
         }
         for (int variant = 0; variant < 4; ++variant) {
             const fpv_params_t A = abi_params(FPV_MODE_RACER, 0);
