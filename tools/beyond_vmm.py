@@ -50,6 +50,17 @@ orders = ((0, "in order"), (1, "reverse"), (2, "random a"), (2, "random b"), (0,
 if len(sys.argv) > 2 and sys.argv[2] == "small":
     chunks = (("64 KiB", 64 * KiB), ("256 KiB", 256 * KiB), ("1 MiB", MiB), ("2 MiB", 2 * MiB), ("4 MiB", 4 * MiB), ("8 MiB", 8 * MiB), ("16 MiB", 16 * MiB), ("whole", total))
     orders = ((0, "in order"), (2, "random a"), (0, "in order + spacers"))
+if len(sys.argv) > 2 and sys.argv[2] == "brief":
+    # one line per process: the shipped allocation against 2 / 4 / 8 MiB chunks and one whole chunk - run it in many processes
+    row = [f"torch {base_t:7.2f}"]
+    for name, chunk, order in (("2MiB", 2 * MiB, 0), ("2MiB-rnd", 2 * MiB, 2), ("4MiB", 4 * MiB, 0), ("8MiB", 8 * MiB, 0), ("whole", total, 0), ("2MiB-again", 2 * MiB, 0)):
+        va, hd = C.c_void_p(), C.c_void_p()
+        assert V.vmm_alloc(0, total, chunk, order, 11, 0, C.byref(va), C.byref(hd)) == 0
+        env._fill_buffers(); env._buf.state = va.value; env.reset()
+        row.append(f"{name} {timed():7.2f}")
+        torch.cuda.synchronize(); V.vmm_free(hd)
+    print(f"pid {os.getpid()}: " + "  ".join(row), flush=True)
+    sys.exit(0)
 if len(sys.argv) > 2 and sys.argv[2] == "spacers":
     # one physical chunk per ROW, a spacer allocation of X MiB made before each chunk and held until all rows exist (then freed):
     # does it take a different physical REGION per row to be fast, and how far apart?
