@@ -128,7 +128,8 @@ def test_fp16_storage_round_trip_for_any_attitude_and_velocity(q, v, seed, drone
     k = int(np.argmax(np.abs(qb)))
     assert abs(qb[k]) >= 0.5 - 1e-6 and qb[k] > 0, "the dropped (reconstructed) component is the largest, stored sign makes it positive"
     vv = np.asarray(v, dtype=np.float32)
-    step = np.maximum(np.abs(np.spacing(vv.astype(np.float16)).astype(np.float64)) / 32, 2.0 ** -24 * 1.01)
+    # (spacing of |v|: numpy's spacing of a NEGATIVE power of two is the step of the binade below it)
+    step = np.maximum(np.spacing(np.abs(vv).astype(np.float16)).astype(np.float64) / 32, 2.0 ** -24 * 1.01)
     assert np.all(np.abs(back[3:6] - vv) <= step * 1.0001 + 1e-12), (vv, back[3:6])
 
 

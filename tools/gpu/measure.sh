@@ -43,8 +43,8 @@ run bench_forcedist python bench.py --force-dist --no-cpu-baseline --steps 5000
 run bench_forcedist_20 python bench.py --force-dist --no-cpu-baseline --steps 20 --warmup 5
 T=400 run bench_rehearsal_2ranks python bench.py --gpus 2 --rehearse-on-one-gpu --steps 2000 --warmup 100 --no-cpu-baseline --drones-per-gpu 524288
 # where the state matrix lands decides the launch time beyond the Infinity Cache: the spread inside one process
-timeout -k 10 300 python tools/beyond_combos.py 4 > $O/beyond_combos.log 2>&1; echo "combos rc=$?"
-timeout -k 10 300 python tools/beyond_sizes.py 5 > $O/beyond_sizes.log 2>&1; echo "sizes rc=$?"
+timeout -k 10 300 python tools/beyond_placement.py combos 4 > $O/beyond_combos.log 2>&1; echo "combos rc=$?"
+timeout -k 10 300 python tools/beyond_placement.py sizes 5 > $O/beyond_sizes.log 2>&1; echo "sizes rc=$?"
 timeout -k 10 300 python examples/closed_loop_policy.py --hidden 0 > $O/closed_loop.log 2>&1; timeout -k 10 300 python examples/closed_loop_policy.py --hidden 64 >> $O/closed_loop.log 2>&1; echo "closed loop rc=$?"
 timeout -k 10 600 python tools/kernel_sweep.py --fp16 --noise --extras --racer --fused --ovr --aos --rounds 5 --out $O/sweep.json > $O/sweep.log 2>&1; echo "sweep rc=$?"
 timeout -k 10 300 python tools/kernel_sweep.py --n 4096 --fused --graph --launches 256 --rounds 5 > $O/sweep_4096.log 2>&1; echo "sweep4096 rc=$?"
