@@ -18,6 +18,7 @@ VARIANTS = {
     "ld_st_nt": ["-DFPV_EXP_LD_NT=1", "-DFPV_EXP_ST_NT=1"],
     "st_sys": ["-DFPV_EXP_ST_NT=2"],          # state stores write through and leave L2 (sc0 sc1)
     "st_agent": ["-DFPV_EXP_ST_NT=3"],        # agent-scope stores (sc1)
+    "w4": ["-DFPV_EXP_STEP_WAVES=4"], "w5": ["-DFPV_EXP_STEP_WAVES=5"], "w7": ["-DFPV_EXP_STEP_WAVES=7"], "w8": ["-DFPV_EXP_STEP_WAVES=8"],   # occupancy of the step kernel
     "rowskew": ["-DFPV_EXP_ROWSKEW=1"],       # per-row offsets of the state matrix from a __constant__ table (tools/rowskew_search.py)
 }
 ap = argparse.ArgumentParser()
