@@ -106,6 +106,26 @@ def median(xs):
     return xs[m] if len(xs) % 2 else 0.5 * (xs[m - 1] + xs[m])
 
 
+def library_hash():
+    """sha256 (16 hex digits) of the built library, fpyv_amd/libfpv_hip.so: the kernels a counter pass ran ARE these bytes.  hipcc is
+    deterministic (a forced rebuild of the same sources gives the same file), and code that is compiled out - an experiment hook
+    behind an `#if` that is off - does not change it, so a measurement stays valid for exactly as long as the machine code does."""
+    h = hashlib.sha256()
+    with open(os.path.join(REPO, "fpyv_amd", "libfpv_hip.so"), "rb") as f:
+        for chunk in iter(lambda: f.read(1 << 20), b""):
+            h.update(chunk)
+    return h.hexdigest()[:16]
+
+
+def measurement_is_current(j):
+    """A committed counter file (profiles/pmc_traffic.json, pmc_valu.json) belongs to the kernels of this tree when the library
+    it was measured on is byte for byte the one that is built now; files from before the library hash existed fall back to the hash
+    of the kernel sources' code."""
+    if j.get("library_sha256_16"):
+        return j["library_sha256_16"] == library_hash()
+    return j.get("kernel_source_sha256_16") == kernel_source_hash()
+
+
 def usable_cpus():
     """CPUs this process can really run on: min(affinity mask, cgroup v2/v1 CPU quota)."""
     n = len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1)
@@ -1016,10 +1036,10 @@ def main(argv=None):
         tp = os.path.join(REPO, "profiles", "pmc_traffic.json")
         if os.path.isfile(tp) and not args.fp16_state and not args.racer and args.api == "step" and n == (1 << 20):
             tj = json.load(open(tp))
-            if tj.get("kernel_source_sha256_16") == kernel_source_hash():
+            if measurement_is_current(tj):
                 traffic, traffic_src = tj.get("hbm_bytes_per_launch"), tj.get("source")
             else:
-                traffic_src = "stale: profiles/pmc_traffic.json was measured on different kernel sources (re-run tools/pmc_probe.py)"
+                traffic_src = "stale: profiles/pmc_traffic.json was measured on another build of the kernels (re-run tools/pmc_probe.py)"
         kernel = ("fpv_racer_step_kernel" if args.racer else "fpv_drone_step_h_kernel" if args.fp16_state else "fpv_drone_step_kernel")
         if args.api == "rollout":
             kernel = kernel.replace("_step_", "_rollout_")
@@ -1087,8 +1107,8 @@ def main(argv=None):
             else:
                 vj = json.load(open(vp))
                 ent = vj.get("kernels", {}).get(fam)
-                if vj.get("kernel_source_sha256_16") != kernel_source_hash():
-                    why = "stale: profiles/pmc_valu.json was measured on different kernel sources (re-run tools/pmc_valu.py)"
+                if not measurement_is_current(vj):
+                    why = "stale: profiles/pmc_valu.json was measured on another build of the kernels (re-run tools/pmc_valu.py)"
                 elif ent is None or gather is not None or abs(steps_per_launch - ent["steps_per_launch"]) > 0.5 or n != vj.get("drones"):
                     # (a timed region that starts in the middle of the action ring has one or two shorter launches: the
                     # average steps per launch may sit a fraction below the ring span the count was taken at)

@@ -101,19 +101,29 @@ extern "C" int fpv_exp_set_skew(const int64_t* skew) { return (int)hipMemcpyToSy
 #else
 #define SROW(st, r, ld) ROW(st, r, ld)
 #endif
-#if FPV_EXP_LD_NT
-#define LDROW(st, r, ld, i) __builtin_nontemporal_load(&row_at(SROW(st, r, ld), i))
+#ifndef FPV_EXP_TILE
+#define FPV_EXP_TILE 0
+#endif
+#if FPV_EXP_TILE      // experiment (tools/ab_variants.py): the fp32 drone state as tiles [n / T][14][T] instead of rows [14][ld] - a wave's
+#undef SROW           // 14 rows sit within 14 * T * 4 contiguous bytes (n * 14 * 4 < 2^32: n <= 2^26)
+#define SROW(st, r, ld) ((st) + (int64_t)(r) * FPV_EXP_TILE)
+#define TIDX(i) ((((i) / (uint32_t)FPV_EXP_TILE) * (14u * (uint32_t)FPV_EXP_TILE)) + ((i) % (uint32_t)FPV_EXP_TILE))
 #else
-#define LDROW(st, r, ld, i) row_at(SROW(st, r, ld), i)
+#define TIDX(i) (i)
+#endif
+#if FPV_EXP_LD_NT
+#define LDROW(st, r, ld, i) __builtin_nontemporal_load(&row_at(SROW(st, r, ld), TIDX(i)))
+#else
+#define LDROW(st, r, ld, i) row_at(SROW(st, r, ld), TIDX(i))
 #endif
 #if FPV_EXP_ST_NT == 2       // write-through and drop from L2: global_store ... sc0 sc1
-#define STROW(st, r, ld, i, v) __hip_atomic_store(&row_at(SROW(st, r, ld), i), (v), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM)
+#define STROW(st, r, ld, i, v) __hip_atomic_store(&row_at(SROW(st, r, ld), TIDX(i)), (v), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM)
 #elif FPV_EXP_ST_NT == 3     // agent scope: sc1
-#define STROW(st, r, ld, i, v) __hip_atomic_store(&row_at(SROW(st, r, ld), i), (v), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)
+#define STROW(st, r, ld, i, v) __hip_atomic_store(&row_at(SROW(st, r, ld), TIDX(i)), (v), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)
 #elif FPV_EXP_ST_NT
-#define STROW(st, r, ld, i, v) __builtin_nontemporal_store((v), &row_at(SROW(st, r, ld), i))
+#define STROW(st, r, ld, i, v) __builtin_nontemporal_store((v), &row_at(SROW(st, r, ld), TIDX(i)))
 #else
-#define STROW(st, r, ld, i, v) (row_at(SROW(st, r, ld), i) = (v))
+#define STROW(st, r, ld, i, v) (row_at(SROW(st, r, ld), TIDX(i)) = (v))
 #endif
 
 __device__ __forceinline__ void ld_drone(const float* __restrict__ st, int64_t ld, uint32_t i, FpvDroneState& s)

@@ -1009,3 +1009,12 @@ class FpvVecEnv:
                 P.stream.synchronize()
             P.close()
         self.batch.close()
+
+    def __del__(self):
+        # an env dropped without close(): its tensors go back to the allocator, which knows only the stream they were
+        # allocated on - a partition's chain still running on ITS stream must be through before that memory can be handed out again
+        try:
+            for P in getattr(self, "_parts", []):
+                P.stream.synchronize()
+        except Exception:
+            pass

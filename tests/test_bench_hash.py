@@ -30,3 +30,14 @@ def test_committed_pmc_files_carry_a_source_hash():
     for name in ("pmc_traffic.json", "pmc_valu.json"):
         d = json.load(open(os.path.join(REPO, "profiles", name)))
         assert len(d["kernel_source_sha256_16"]) == 16 and d["source"].startswith("profiles/r0")
+
+
+def test_a_measurement_is_tied_to_the_built_library(tmp_path, monkeypatch):
+    """The counter files belong to the machine code: the hash of fpyv_amd/libfpv_hip.so decides (a compiled-out experiment hook
+    changes the sources but not the library); a file from before that hash existed falls back to the source hash."""
+    lib = bench.library_hash()
+    assert len(lib) == 16 and lib == bench.library_hash()
+    assert bench.measurement_is_current({"library_sha256_16": lib, "kernel_source_sha256_16": "0" * 16})
+    assert not bench.measurement_is_current({"library_sha256_16": "0" * 16, "kernel_source_sha256_16": bench.kernel_source_hash()})
+    assert bench.measurement_is_current({"kernel_source_sha256_16": bench.kernel_source_hash()})
+    assert not bench.measurement_is_current({"kernel_source_sha256_16": "0" * 16})

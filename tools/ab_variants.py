@@ -19,6 +19,7 @@ VARIANTS = {
     "st_sys": ["-DFPV_EXP_ST_NT=2"],          # state stores write through and leave L2 (sc0 sc1)
     "st_agent": ["-DFPV_EXP_ST_NT=3"],        # agent-scope stores (sc1)
     "w4": ["-DFPV_EXP_STEP_WAVES=4"], "w5": ["-DFPV_EXP_STEP_WAVES=5"], "w7": ["-DFPV_EXP_STEP_WAVES=7"], "w8": ["-DFPV_EXP_STEP_WAVES=8"],   # occupancy of the step kernel
+    "tile256": ["-DFPV_EXP_TILE=256"], "tile512": ["-DFPV_EXP_TILE=512"], "tile1k": ["-DFPV_EXP_TILE=1024"], "tile4k": ["-DFPV_EXP_TILE=4096"], "tile16k": ["-DFPV_EXP_TILE=16384"],   # [n/T][14][T] state (results are the same numbers in another order)
     "rowskew": ["-DFPV_EXP_ROWSKEW=1"],       # per-row offsets of the state matrix from a __constant__ table (tools/rowskew_search.py)
 }
 ap = argparse.ArgumentParser()
@@ -26,6 +27,7 @@ ap.add_argument("--build", action="store_true")
 ap.add_argument("--n", type=int, default=1 << 20)
 ap.add_argument("--rounds", type=int, default=8)
 ap.add_argument("--only", nargs="*", default=None)
+ap.add_argument("--states", type=int, default=1, help="time every variant on this many separately allocated state matrices (placement matters beyond the cache)")
 a = ap.parse_args()
 names = [k for k in VARIANTS if not a.only or k in a.only]
 if a.build:
@@ -52,21 +54,64 @@ for k in names:
     h = C.c_void_p(); rc = l.fpv_create(C.byref(cp), n, 0, C.byref(h)); assert rc == 0, l.fpv_last_error()
     L[k], H[k] = l, h
 ld = int(L[names[0]].fpv_recommended_ld(n))
-st = torch.zeros((14, ld), device=dev); rew = torch.zeros(n, device=dev); done = torch.zeros(n, dtype=torch.uint8, device=dev)
+rew = torch.zeros(n, device=dev); done = torch.zeros(n, dtype=torch.uint8, device=dev)
+if a.states > 1:
+    # the same variants on several state matrices of this process, freed and allocated again in between: one line per matrix
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    keep = []
+    for j in range(a.states):
+        if j % 2 == 1:
+            torch.cuda.empty_cache()
+        keep.append(torch.empty((5 + 13 * j) << 20, dtype=torch.uint8, device=dev))
+        st = torch.zeros((14, ld), device=dev)
+        b = _lib.FpvBuffers(); b.state, b.ld, b.reward, b.done, b.action = st.data_ptr(), ld, rew.data_ptr(), done.data_ptr(), acts.data_ptr()
+        row = []
+        for k in names:
+            ts = []
+            for r in range(3):
+                st.zero_()
+                if k.startswith("tile"):
+                    T = int(VARIANTS[k][0].split("=")[1]); v = st.reshape(-1)[:(n // T) * 14 * T].view(n // T, 14, T); v[:, 2] = 10; v[:, 3] = 1; v[:, 6] = 1
+                else:
+                    st[2] = 10; st[3] = 1; st[6] = 1
+                assert L[k].fpv_rollout(H[k], C.byref(b), ring, n * 4, 0, None) == 0
+                torch.cuda.synchronize(); e0.record()
+                for rep in range(6):
+                    assert L[k].fpv_rollout(H[k], C.byref(b), ring, n * 4, 0, None) == 0
+                e1.record(); torch.cuda.synchronize()
+                ts.append(e0.elapsed_time(e1) * 1e3 / (6 * ring))
+            row.append(f"{k} {statistics.median(ts):7.2f}")
+        print(f"state 0x{st.data_ptr():x}: " + "  ".join(row), flush=True)
+        if j % 3 != 2:
+            keep.append(st)
+        del st
+    sys.exit(0)
+st = torch.zeros((14, ld), device=dev)
 b = _lib.FpvBuffers(); b.state, b.ld, b.reward, b.done = st.data_ptr(), ld, rew.data_ptr(), done.data_ptr()
 b.action = acts.data_ptr()
-def reset(): st.zero_(); st[2] = 10; st[3] = 1; st[6] = 1
+def reset(k="base"):
+    st.zero_()
+    if k.startswith("tile"):
+        T = int(VARIANTS[k][0].split("=")[1])
+        v = st.reshape(-1)[:(n // T) * 14 * T].view(n // T, 14, T)
+        v[:, 2] = 10; v[:, 3] = 1; v[:, 6] = 1
+    else:
+        st[2] = 10; st[3] = 1; st[6] = 1
 res = {k: [] for k in names}; fin = {}
 e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
 reps = 8 if n <= (1 << 21) else 16
 for r in range(a.rounds):
     for k in names:
-        reset(); torch.cuda.synchronize(); e0.record()
+        reset(k); torch.cuda.synchronize(); e0.record()
         for rep in range(reps):
             rc = L[k].fpv_rollout(H[k], C.byref(b), ring, n * 4, 0, None); assert rc == 0, L[k].fpv_last_error()
         e1.record(); torch.cuda.synchronize()
         if r: res[k].append(e0.elapsed_time(e1) * 1e3 / (reps * ring))
         fin[k] = st.clone()
+        if k.startswith("tile"):        # back to rows [14][n] for the comparison with the row layout
+            T = int(VARIANTS[k][0].split("=")[1])
+            flat = st.reshape(-1)[:(n // T) * 14 * T].view(n // T, 14, T).permute(1, 0, 2).reshape(14, n)
+            fin[k] = torch.zeros_like(st); fin[k][:, :n] = flat
 for k in names:
     med = statistics.median(res[k])
-    print(f"n={n} {k:12s}: median {med:8.3f} us  min {min(res[k]):8.3f} us   {133 * n / med / 1e3:8.1f} GB/s   bitwise==base {bool(torch.equal(fin[k], fin[names[0]]))}", flush=True)
+    print(f"n={n} {k:12s}: median {med:8.3f} us  min {min(res[k]):8.3f} us   {133 * n / med / 1e3:8.1f} GB/s   bitwise==base {bool(torch.equal(fin[k][:, :n], fin[names[0]][:, :n]))}", flush=True)

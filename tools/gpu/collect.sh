@@ -44,8 +44,7 @@ python3 - <<'PY'
 import json, sys
 sys.path.insert(0, ".")
 import bench
-h = bench.kernel_source_hash()
 for f in ("profiles/pmc_traffic.json", "profiles/pmc_valu.json"):
     j = json.load(open(f))
-    print(f, j["kernel_source_sha256_16"], "ok" if j["kernel_source_sha256_16"] == h else f"STALE (sources {h})")
+    print(f, j.get("library_sha256_16"), j["kernel_source_sha256_16"], "ok" if bench.measurement_is_current(j) else f"STALE (library now {bench.library_hash()})")
 PY

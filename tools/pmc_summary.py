@@ -69,6 +69,7 @@ def main():
         "kernel": "fpv_drone_step_kernel<false, false, false, false> (NOISE, OBJ, KAHAN, OVR off; 128 threads, 1 drone per lane)", "drones": a.n,
         # bench.py reports this traffic only while the kernel sources still hash to this value
         "kernel_source_sha256_16": __import__("bench").kernel_source_hash(),
+        "library_sha256_16": __import__("bench").library_hash(),
         "fetch_raw_kib": mean(fe[("step", "FETCH_SIZE")]), "write_raw_kib": mean(wr[("step", "WRITE_SIZE")]),
         "fetch_scale": f_scale, "write_scale": w_scale,
         "read_bytes_per_launch": fetch_kib * 1024, "write_bytes_per_launch": write_kib * 1024,

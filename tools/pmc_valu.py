@@ -53,7 +53,7 @@ def main():
            "fp16": pick(lambda k: k.startswith("fpv_drone_rollout_h_kernel")),
            "racer": pick(lambda k: k.startswith("fpv_racer_rollout_kernel<true, false"))}
     out = {"source": f"profiles/{a.round}_pmc_valu_counts.log (rocprofv3 --pmc SQ_INSTS_VALU SQ_INSTS_SALU SQ_WAVES, counters only; tools/pmc_valu.py)",
-           "kernel_source_sha256_16": kernel_source_hash(), "drones": a.drones,
+           "kernel_source_sha256_16": kernel_source_hash(), "library_sha256_16": __import__("bench").library_hash(), "drones": a.drones,
            "kernels": {k: v for k, v in fam.items() if v}, "all": rows}
     json.dump(out, open(os.path.join(REPO, "profiles", "pmc_valu.json"), "w"), indent=1)
     print("wrote profiles/pmc_valu.json for sources", out["kernel_source_sha256_16"])
