@@ -2296,3 +2296,36 @@ def test_bench_line_schema_small(extra):
         assert d["config"]["partitions"] == (2 if extra else 1)
         if extra:
             assert d["config"]["partition_streams"]["verified"] is True
+
+
+def test_bench_line_auxiliary_legs_at_the_headline_size():
+    """The legs only the full-size line has: `beyond_mall` at 2^23 drones with its three repeats, host enqueue
+    time and buffer addresses, and `launch_time_fit` over 2^19 / 2^20 / 2^21 drones with per-leg repeats, host enqueue time
+    and a verdict on its own validity - on a warm GPU the fit must be valid with a floor of a few microseconds."""
+    import json
+    import os
+    import subprocess
+    import sys
+    from conftest import REPO
+    r = subprocess.run([sys.executable, os.path.join(REPO, "bench.py"), "--steps", "20", "--warmup", "5", "--sustained-steps", "200", "--no-cpu-baseline"],
+                       capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0, r.stderr[-3000:]
+    lines = [ln for ln in r.stdout.splitlines() if ln.strip()]
+    assert len(lines) == 1, lines
+    ro = json.loads(lines[0])["roofline"]
+    assert ro["host_enqueue_us"] > 0 and ro["host_bound"] is False and ro["sustained"]["host_enqueue_us"] > 0
+    b = ro["beyond_mall"]
+    assert b["drones"] == 1 << 23 and len(b["repeats_us"]) == 3 and b["launches_per_repeat"] == 100 and b["host_enqueue_us"] > 0
+    assert max(b["repeats_us"]) < 1.10 * min(b["repeats_us"]), b["repeats_us"]
+    assert 0.4 < b["frac"] < 0.95 and 0.7 < b["frac_of_copy_ceiling"] < 1.15 and set(b["addresses"]) == {"state", "ld", "action", "reward", "done"}
+    lf = ro["launch_time_fit"]
+    assert lf["drones"] == [1 << 19, 1 << 20, 1 << 21] and len(lf["legs"]) == 3
+    for leg in lf["legs"]:
+        assert len(leg["repeats_us"]) == 3 and leg["launches"] == 400 and 0 < leg["host_enqueue_us"] < leg["avg_launch_us"]
+    # the fit judges itself: on a warm, quiet GPU it is valid (floor of a few microseconds); a box on which a leg is off the line
+    # must say so instead of printing a floor - either way the line is consistent with its own verdict
+    if lf["valid"]:
+        assert lf["invalid_reason"] is None and 2.0 < lf["floor_us"] < 7.0 and lf["max_residual_us"] <= 0.5 and 0.7 < lf["streaming_frac_of_peak"] <= 1.0
+        assert abs(lf["floor_share_of_headline_launch"] - lf["floor_us"] / ro["sustained"]["avg_launch_us"]) < 1e-9
+    else:
+        assert lf["invalid_reason"] and lf["floor_share_of_headline_launch"] is None
