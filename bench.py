@@ -119,10 +119,12 @@ def library_hash():
 
 def measurement_is_current(j):
     """A committed counter file (profiles/pmc_traffic.json, pmc_valu.json) belongs to the kernels of this tree when the library
-    it was measured on is byte for byte the one that is built now; files from before the library hash existed fall back to the hash
-    of the kernel sources' code."""
-    if j.get("library_sha256_16"):
-        return j["library_sha256_16"] == library_hash()
+    it was measured on is byte for byte the one that is built now, or when the kernel sources' code (comments stripped, with
+    the compiler flags) still hashes to the value recorded with it."""
+    # (hipcc derives its compilation-unit id from the output path, so the same sources built elsewhere give other bytes: the
+    # source hash stays as the second key)
+    if j.get("library_sha256_16") and j["library_sha256_16"] == library_hash():
+        return True
     return j.get("kernel_source_sha256_16") == kernel_source_hash()
 
 

@@ -38,6 +38,7 @@ def test_a_measurement_is_tied_to_the_built_library(tmp_path, monkeypatch):
     lib = bench.library_hash()
     assert len(lib) == 16 and lib == bench.library_hash()
     assert bench.measurement_is_current({"library_sha256_16": lib, "kernel_source_sha256_16": "0" * 16})
-    assert not bench.measurement_is_current({"library_sha256_16": "0" * 16, "kernel_source_sha256_16": bench.kernel_source_hash()})
+    assert bench.measurement_is_current({"library_sha256_16": "0" * 16, "kernel_source_sha256_16": bench.kernel_source_hash()}), "built elsewhere: the source hash decides"
+    assert not bench.measurement_is_current({"library_sha256_16": "0" * 16, "kernel_source_sha256_16": "0" * 16})
     assert bench.measurement_is_current({"kernel_source_sha256_16": bench.kernel_source_hash()})
     assert not bench.measurement_is_current({"kernel_source_sha256_16": "0" * 16})
