@@ -13,7 +13,7 @@ from typing import Optional
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, "libfpv_hip.so")
 
-FPV_ABI_VERSION = 6
+FPV_ABI_VERSION = 7
 FPV_OK = 0
 FPV_MODE_DRONE, FPV_MODE_RACER = 0, 1
 FPV_DRONE_ROWS, FPV_RACER_ROWS = 14, 29
@@ -31,7 +31,7 @@ R_OMEGA, R_IERR, R_LERR, R_FIRST, R_OMEGA_LO, R_IERR_LO, R_DFILT = 10, 13, 16, 1
 
 # every symbol include/fpv_abi.h declares
 EXPORTS = ("fpv_abi_version", "fpv_sizeof", "fpv_state_rows", "fpv_algorithmic_bytes", "fpv_handle_algorithmic_bytes", "fpv_create", "fpv_destroy",
-           "fpv_reset", "fpv_step", "fpv_rollout", "fpv_step_n", "fpv_rollout_graph", "fpv_return_triple", "fpv_widen_state", "fpv_set_params", "fpv_set_step_counter", "fpv_get_step_counter", "fpv_recommended_ld",
+           "fpv_reset", "fpv_step", "fpv_rollout", "fpv_step_n", "fpv_rollout_graph", "fpv_return_triple", "fpv_widen_state", "fpv_set_params", "fpv_set_step_counter", "fpv_get_step_counter", "fpv_set_rotation", "fpv_get_rotation", "fpv_recommended_ld",
            "fpv_diag_stream_copy", "fpv_diag_stream_copy_wide", "fpv_diag_busy", "fpv_pid_reset", "fpv_pid_call", "fpv_comm_unique_id", "fpv_comm_create", "fpv_comm_destroy", "fpv_comm_info",
            "fpv_allgather_done", "fpv_allgather_f32", "fpv_last_error",
            "fpv_error_name")
@@ -186,6 +186,8 @@ def lib() -> C.CDLL:
     L.fpv_set_params.argtypes = [vp, pp]
     L.fpv_set_step_counter.argtypes = [vp, C.c_uint64]
     L.fpv_get_step_counter.argtypes = [vp, C.POINTER(C.c_uint64)]
+    L.fpv_set_rotation.argtypes = [vp, C.c_int64]
+    L.fpv_get_rotation.argtypes = [vp, C.POINTER(C.c_int64)]
     L.fpv_recommended_ld.argtypes = [i64]
     L.fpv_recommended_ld.restype = i64
     L.fpv_diag_stream_copy.argtypes = [vp, vp, i64, vp]

@@ -337,14 +337,27 @@ __device__ __forceinline__ const FpvStepArgs& fpv_step_args_again()
     return *(const FpvStepArgs*)p;
 }
 
+// The fp32 drone step kernels take `n` and a START BLOCK in one preloaded argument (n in the low 32 bits - n <= 2^28 -, the
+// block in the high 32): workgroup b works on block (b + start) mod blocks, ascending addresses all the way, one wrap.  The host
+// moves the start BACK by the Infinity Cache's worth of drones from launch to launch (launch_step: rotation), so that a
+// launch BEGINS on the state rows the previous launch wrote LAST - the ones the 256 MiB cache still holds - instead of
+// on the ones it wrote first, which a population larger than the cache has pushed out by then (every launch in the same
+// order re-reads everything from HBM: cyclic access is the worst case of a recency cache).  Results do not depend on the
+// order in which blocks run; start = 0 (every population that fits the cache, the headline's included) is the plain order.
+#define FPV_DRONE_STEP_PARAMS float* __restrict__ a_state, const int64_t a_ld, const float4* __restrict__ a_action, \
+                              const int64_t a_action_ld, uint16_t* __restrict__ a_state_h, const int64_t n_start, const FpvK K, const FpvBufD B_
 template <bool NOISE = false, bool OBJ = false, bool KAHAN = false, bool OVR = false>
-__global__ __launch_bounds__(kStepBlock) FPV_EXP_STEP_ATTR void fpv_drone_step_kernel(FPV_STEP_PARAMS)
+__global__ __launch_bounds__(kStepBlock) FPV_EXP_STEP_ATTR void fpv_drone_step_kernel(FPV_DRONE_STEP_PARAMS)
 {
     constexpr bool SECTIONED = NOISE || (OBJ && OVR);
     FPV_STEP_VIEW;
     __shared__ FpvNormalRow ntab[NOISE ? FPV_NTAB_ROWS : 1];
     if (NOISE) stage_normal_table(ntab);
-    const uint32_t i = blockIdx.x * (uint32_t)kStepBlock + threadIdx.x;    // n <= 2^28 (fpv_create)
+    const int64_t n = n_start & 0xffffffffll;                              // n <= 2^28 (fpv_create)
+    const uint32_t nblk = (uint32_t)((n + kStepBlock - 1) / kStepBlock);   // from the preloaded argument (gridDim.x would be a cold scalar load ahead of the first vector loads)
+    uint32_t blk = blockIdx.x + (uint32_t)(n_start >> 32);
+    blk = blk >= nblk ? blk - nblk : blk;
+    const uint32_t i = blk * (uint32_t)kStepBlock + threadIdx.x;
     // lanes past the end leave at once (a ballot over the remaining lanes still yields the right done bits:
     // exited lanes contribute 0, and a wave whose lane 0 is gone is empty)
     if (i >= n) return;
@@ -1115,6 +1128,9 @@ struct fpv_env {
     int mode;
     uint64_t launches;   // 64-bit step index: counts the steps launched so far; keys the stick-noise stream (Philox
                          // counter words 2 and 3) and the stochastic rounding (fpv_round_seed)
+    // rotation of the fp32 drone step kernels' start block (FPV_DRONE_STEP_PARAMS): blocks the start moves back per launch
+    // (0 = plain order), where the next launch starts, and what the caller asked for (fpv_set_rotation: -1 = automatic)
+    int64_t rot_blocks = 0, start_block = 0, rot_request = -1;
     // cached hipGraph of the last fpv_rollout_graph call (launch-bound small batches): rebuilt when the
     // SHAPE key changes, re-pointed node by node when only buffer addresses change
     hipGraph_t graph = nullptr;
@@ -1242,7 +1258,7 @@ struct DeviceGuard {
 
 // ---- kernel selection: every step kernel has the signature FPV_STEP_PARAMS ------------------------------
 typedef void (*StepKernel)(float*, const int64_t, const float4*, const int64_t, uint16_t*, const int64_t, const FpvK, const FpvBufD);
-struct KernelChoice { StepKernel func; unsigned grid, block; };
+struct KernelChoice { StepKernel func; unsigned grid, block; bool rotates; };
 
 StepKernel drone_kernel(bool noise, bool obj, bool kahan)
 {
@@ -1300,6 +1316,7 @@ KernelChoice choose_kernel(const fpv_env* h, const FpvBufD& d)
 {
     KernelChoice c;
     c.block = (unsigned)kStepBlock;
+    c.rotates = false;
     if (h->mode != FPV_MODE_DRONE) {
         c.func = racer_kernel(h->K.r_wide != 0, h->K.r_pid_variant != 0);
     } else if (h->K.flags & FPV_FLAG_FP16_STATE) {
@@ -1312,6 +1329,7 @@ KernelChoice choose_kernel(const fpv_env* h, const FpvBufD& d)
             c.func = obj ? fpv_drone_step_kernel<false, true, false, true> : fpv_drone_step_kernel<false, false, false, true>;
         else
             c.func = drone_kernel(noise, obj, kahan);
+        c.rotates = true;                   // the fpv_drone_step_kernel family reads n and the start block from one argument
     }
     c.grid = (unsigned)((h->n + kStepBlock - 1) / kStepBlock);
     return c;
@@ -1322,11 +1340,45 @@ int launch_step(fpv_env* h, const FpvBufD& d_in, hipStream_t s)
     FpvBufD d = d_in;
     d.step = h->launches;
     const KernelChoice c = choose_kernel(h, d);
-    hipLaunchKernelGGL(c.func, dim3(c.grid), dim3(c.block), 0, s, d.state, d.ld, d.action, d.action_ld, d.state_h, h->n, h->K, d);
+    const int64_t nblk = (int64_t)c.grid;
+    const int64_t start = (c.rotates && h->rot_blocks > 0) ? h->start_block % nblk : 0;
+    hipLaunchKernelGGL(c.func, dim3(c.grid), dim3(c.block), 0, s, d.state, d.ld, d.action, d.action_ld, d.state_h, h->n | (start << 32), h->K, d);
     const hipError_t e = hipGetLastError();
     if (e != hipSuccess) return hip_fail(e, "step kernel launch");
     ++h->launches;                     // a refused launch leaves the step index where it was
+    if (c.rotates && h->rot_blocks > 0) h->start_block = (start + nblk - h->rot_blocks % nblk) % nblk;
     return FPV_OK;
+}
+
+// MI355X: 256 MiB Infinity Cache (memory-side, all eight XCDs; /opt/skills/guides/MI355X_MICROARCH.md).  The rotation step is 7/8
+// of the drones whose re-read rows fit it: measured at 2^23 drones the launch time is flat from 30 000 to 35 000 blocks of
+// 128 drones and 7 % worse at 36 000 (profiles/r05_exp_rotation_step_sweep.log); 7/8 * 256 MiB / 56 B = 2^22 drones = 32 768 blocks.
+constexpr int64_t kInfinityCacheBytes = (int64_t)256 << 20;
+
+void update_rotation(fpv_env* h)
+{
+    const int64_t nblk = (h->n + kStepBlock - 1) / kStepBlock;
+    int64_t blocks = 0;
+    if (h->mode == FPV_MODE_DRONE && !(h->K.flags & FPV_FLAG_FP16_STATE)) {
+        if (h->rot_request < 0) {
+            const int64_t rows = FPV_DRONE_ROWS + ((h->K.flags & FPV_FLAG_STICK_NOISE) ? 4 : 0);     // rows read AND written every step
+            const int64_t fit = kInfinityCacheBytes / 8 * 7 / (4 * rows) / kStepBlock;
+            blocks = nblk > fit ? fit : 0;          // a population that fits the cache keeps the plain order
+        } else {
+            blocks = (h->rot_request / kStepBlock) % (nblk > 0 ? nblk : 1);
+        }
+    }
+    h->rot_blocks = blocks;
+    h->start_block = 0;
+}
+
+// node t of a replayed graph: the same rotation, counted from the first node (a replay begins where the previous one began: one
+// launch in k starts on cold rows)
+int64_t graph_n_start(const fpv_env* h, const KernelChoice& c, int t)
+{
+    const int64_t nblk = (int64_t)c.grid;
+    const int64_t start = (c.rotates && h->rot_blocks > 0) ? (int64_t)(((uint64_t)t * (uint64_t)(nblk - h->rot_blocks % nblk)) % (uint64_t)nblk) : 0;
+    return h->n | (start << 32);
 }
 
 }  // namespace
@@ -1392,6 +1444,7 @@ int fpv_create(const fpv_params_t* params, int64_t n, int device, fpv_handle_t* 
     if (!h) return fail(FPV_EINVAL, "out of host memory");
     h->K = K; h->P = *params; h->n = n; h->device = device; h->mode = (int)params->mode;
     h->launches = 0;
+    update_rotation(h);
     *out = h;
     return FPV_OK;
 }
@@ -1415,6 +1468,23 @@ int fpv_set_params(fpv_handle_t h, const fpv_params_t* params)
     const int rc = fpv_derive_constants(params, &K, &why);
     if (rc != FPV_OK) return fail(rc, why);
     h->K = K; h->P = *params;
+    return FPV_OK;
+}
+
+int fpv_set_rotation(fpv_handle_t h, int64_t drones)
+{
+    if (!h) return fail(FPV_EINVAL, "null handle");
+    if (drones < -1) return fail(FPV_EINVAL, "fpv_set_rotation: -1 = automatic, 0 = plain order, > 0 = drones the start moves back per launch");
+    h->rot_request = drones;
+    update_rotation(h);
+    h->graph_shape_key.clear();         // a cached graph carries the starts of the old setting: rebuilt at its next use
+    return FPV_OK;
+}
+
+int fpv_get_rotation(fpv_handle_t h, int64_t* drones)
+{
+    if (!h || !drones) return fail(FPV_EINVAL, "null argument");
+    *drones = h->rot_blocks * kStepBlock;
     return FPV_OK;
 }
 
@@ -1610,7 +1680,6 @@ int fpv_rollout_graph(fpv_handle_t h, const fpv_buffers_t* b, int k, int64_t act
     // everything else in the view is a buffer address
     const std::string ptrs(reinterpret_cast<const char*>(&d0), sizeof(d0));
     FpvK K = h->K;
-    int64_t n = h->n;
     if (!h->graph_exec || shape != h->graph_shape_key) {
         drop_graph(h);
         hipError_t e = hipGraphCreate(&h->graph, 0);
@@ -1619,7 +1688,8 @@ int fpv_rollout_graph(fpv_handle_t h, const fpv_buffers_t* b, int k, int64_t act
         for (int t = 0; t < k; ++t) {
             FpvBufD d = graph_step_view(b, d0, t, action_stride, out_stride);
             const KernelChoice c = choose_kernel(h, d);
-            void* args[8] = {&d.state, &d.ld, &d.action, &d.action_ld, &d.state_h, &n, &K, &d};   // copied by hipGraphAddKernelNode
+            int64_t n_start = graph_n_start(h, c, t);
+            void* args[8] = {&d.state, &d.ld, &d.action, &d.action_ld, &d.state_h, &n_start, &K, &d};   // copied by hipGraphAddKernelNode
             hipKernelNodeParams np;
             memset(&np, 0, sizeof(np));
             np.func = reinterpret_cast<void*>(c.func);
@@ -1640,7 +1710,8 @@ int fpv_rollout_graph(fpv_handle_t h, const fpv_buffers_t* b, int k, int64_t act
         for (int t = 0; t < k; ++t) {
             FpvBufD d = graph_step_view(b, d0, t, action_stride, out_stride);
             const KernelChoice c = choose_kernel(h, d);
-            void* args[8] = {&d.state, &d.ld, &d.action, &d.action_ld, &d.state_h, &n, &K, &d};
+            int64_t n_start = graph_n_start(h, c, t);
+            void* args[8] = {&d.state, &d.ld, &d.action, &d.action_ld, &d.state_h, &n_start, &K, &d};
             hipKernelNodeParams np;
             memset(&np, 0, sizeof(np));
             np.func = reinterpret_cast<void*>(c.func);

@@ -219,6 +219,19 @@ class _Batch:
         _lib.check(self._L.fpv_get_step_counter(self._handle, C.byref(v)))
         return int(v.value)
 
+    def set_rotation(self, drones: int = -1) -> None:
+        """How far the start of the traversal moves back from launch to launch (fpv_set_rotation; fp32 drone state only):
+        -1 automatic (on when the state is larger than the 256 MiB Infinity Cache), 0 the plain order, > 0 that many drones.
+        Results do not depend on it; a population beyond the cache steps up to 25 % faster with it."""
+        _lib.check(self._L.fpv_set_rotation(self._handle, int(drones)))
+
+    @property
+    def rotation(self) -> int:
+        """Drones the start moves back per launch (0 = plain order): what fpv_get_rotation reports."""
+        v = C.c_int64()
+        _lib.check(self._L.fpv_get_rotation(self._handle, C.byref(v)))
+        return int(v.value)
+
     def set_params(self, params: DroneParams, auto_reset: Optional[bool] = None) -> None:
         flags_auto = bool(self._cparams.flags & _lib.FPV_FLAG_AUTO_RESET) if auto_reset is None else auto_reset
         cp = _lib.pack_params(params, auto_reset=flags_auto, **self._pack_kw)

@@ -2330,3 +2330,93 @@ def test_bench_line_auxiliary_legs_at_the_headline_size():
         assert abs(lf["floor_share_of_headline_launch"] - lf["floor_us"] / ro["sustained"]["avg_launch_us"]) < 1e-9
     else:
         assert lf["invalid_reason"] and lf["floor_share_of_headline_launch"] is None
+
+
+@pytest.mark.parametrize("kind", ["plain", "noise", "objects", "kahan", "guidance", "episodes"])
+def test_rotation_of_the_traversal_is_bit_identical(params_1k, kind):
+    """fpv_set_rotation (ABI 7): the fp32 drone step kernels start `drones` before the previous launch's start and wrap - so that a
+    population beyond the 256 MiB Infinity Cache begins each launch on the rows it wrote last.  The ORDER of the workgroups must
+    not matter: every buffer bit for bit the plain order's, for every instantiation, ragged n (a partial last block), steps through
+    step(), rollout(fused=False) and the hipGraph replay, a rotation smaller and larger than the population."""
+    from fpyv_amd.env import DroneBatch
+    from fpyv_amd.objects import Cylinder, Ground
+    n, T = 70001, 24
+    p = params_1k.replace(ceiling=10.2, init_position=np.array([0.0, 0.0, 0.25]), init_velocity=np.array([1.0, 0.2, -1.5]))
+    kw = dict(device=DEV, auto_reset=True, with_accel=True, with_done_bits=True, track_episodes=(kind == "episodes"))
+    objs = ()
+    if kind == "noise":
+        kw.update(stick_noise=True, noise_seed=5, with_action_out=True)
+    if kind == "kahan":
+        kw.update(kahan_position=True)
+    if kind == "objects":
+        objs = [Ground(), Cylinder(position=[1.0, 0.2, 0.0], radius=0.5, height=1.0)]
+    g = torch.Generator(device=DEV); g.manual_seed(4)
+    acts = torch.rand((T, n, 4), device=DEV, generator=g) * 2 - 1
+    R = torch.eye(3, device=DEV).expand(n, 3, 3).contiguous()
+    thrust = torch.full((n,), 6.0, device=DEV)
+
+    def run(rotation):
+        e = DroneBatch(p, n, **kw)
+        assert e.rotation == 0, "a population that fits the cache keeps the plain order by default"
+        e.set_rotation(rotation)
+        assert e.rotation == (rotation // 128 * 128) % ((n + 127) // 128 * 128) or rotation == 0
+        e.reset()
+        for t in range(8):
+            if kind == "guidance":
+                e.step(acts[t], rotation_matrix=R, thrust_force=thrust, return_imu=False)
+            else:
+                e.step(acts[t], object_list=objs, return_imu=False)
+        e.rollout(acts[8:16], fused=False, object_list=objs)
+        e.rollout(acts[16:24], graph=True, object_list=objs)
+        e.rollout(acts[16:24], graph=True, object_list=objs)                      # a replay of the cached graph
+        torch.cuda.synchronize()
+        return e
+
+    base = run(0)
+    for rotation in (384, 128 * 300, 128 * 9000):
+        other = run(rotation)
+        for name in ("state", "reward", "done_u8", "done_bits", "accel", "ep_return", "ep_length", "last_return", "last_length", "noise_state", "action_out", "pos_comp"):
+            x, y = getattr(base, name, None), getattr(other, name, None)
+            if x is not None:
+                assert torch.equal(x, y), (kind, rotation, name)
+    assert bool(base.done.any()) or kind in ("noise",), "the run must end episodes (auto-reset inside the rotated order too)"
+
+
+def test_rotation_is_automatic_beyond_the_infinity_cache_and_pays(params_1k):
+    """The automatic rule (fpv_abi.h): plain order while the re-read rows fit 7/8 of the 256 MiB Infinity Cache, else the start
+    moves back by that many drones per launch (2^22 for the plain kernel, fewer with the four noise rows).  At 2^23 drones the
+    rotated chain must be clearly faster than the plain one on the same buffers - measured 155 against 180-200 us."""
+    from fpyv_amd import sticks
+    from fpyv_amd.env import DroneBatch
+    assert DroneBatch(params_1k, 1 << 20, device=DEV, with_accel=False).rotation == 0
+    assert DroneBatch(params_1k, 1 << 22, device=DEV, with_accel=False).rotation == 0
+    assert DroneBatch(params_1k, (1 << 22) + 128, device=DEV, with_accel=False).rotation == 1 << 22
+    noisy = DroneBatch(params_1k, 5 << 20, device=DEV, with_accel=False, stick_noise=True)
+    assert noisy.rotation == (256 << 20) // 8 * 7 // (4 * 18) // 128 * 128
+    assert DroneBatch(params_1k, 5 << 20, device=DEV, with_accel=False, fp16_state=True).rotation == 0     # fp16 storage: not rotated
+    del noisy
+    torch.cuda.empty_cache()
+    n = 1 << 23
+    e = DroneBatch(params_1k.replace(ceiling=100.0), n, device=DEV, auto_reset=True, with_accel=False)
+    assert e.rotation == 1 << 22
+    acts = sticks.ema_noise_device(4, n, DEV, seed=9)
+
+    def timed():
+        e.reset()
+        e.rollout(acts, fused=False)
+        torch.cuda.synchronize()
+        out = []
+        for _ in range(3):
+            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            e0.record()
+            for _ in range(5):
+                e.rollout(acts, fused=False)
+            e1.record(); torch.cuda.synchronize()
+            out.append(e0.elapsed_time(e1) * 1e3 / 20)
+        return sorted(out)[1], e.state.clone()
+
+    t_rot, s_rot = timed()
+    e.set_rotation(0)
+    t_plain, s_plain = timed()
+    assert torch.equal(s_rot, s_plain)
+    assert t_rot < 0.95 * t_plain, (t_rot, t_plain)
