@@ -986,6 +986,13 @@ def main(argv=None):
         copy_before = time_copy(L.fpv_diag_stream_copy_wide)
         leg = timed_leg(big, acts_b, 100, 0, repeats=3)
         us = leg["avg_launch_us"]
+        # the same chain in the plain order (every launch from drone 0): what the rotation of the traversal buys beyond the cache
+        rotation = getattr(big, "rotation", 0) if not args.racer else 0
+        plain_us = None
+        if rotation:
+            big.set_rotation(0)
+            plain_us = timed_leg(big, acts_b, 100, 300, repeats=3)["avg_launch_us"]
+            big.set_rotation(-1)
         copy_after = time_copy(L.fpv_diag_stream_copy_wide)
         copy_dword = time_copy(L.fpv_diag_stream_copy)
         gbs = launch_bytes / (us * 1e-6) / 1e9
@@ -995,6 +1002,10 @@ def main(argv=None):
                   "host_enqueue_us": leg["host_enqueue_us"], "host_bound": leg["host_bound"],
                   "achieved": gbs, "frac": gbs / HBM_PEAK_GBS, "env_steps_per_s": nb / (us * 1e-6),
                   "copy_ceiling_GBs": ceiling, "frac_of_copy_ceiling": gbs / ceiling,
+                  "rotation_drones": rotation, "plain_order_avg_launch_us": plain_us,
+                  "rotation_note": (f"each launch starts {rotation} drones before the previous one's start and wraps (fpv_set_rotation, automatic beyond the "
+                                    "256 MiB Infinity Cache): it begins on the rows the previous launch wrote last; same results, the plain order timed beside it"
+                                    if rotation else None),
                   "addresses": {"state": hex(big.state.data_ptr()), "ld": big.ld, "action": hex(acts_b.data_ptr()),
                                 "reward": hex(big.reward.data_ptr()), "done": hex(big.done.data_ptr())},
                   "copy_GBs": {"float4_before": copy_before, "float4_after": copy_after, "dword": copy_dword,
@@ -1062,7 +1073,7 @@ def main(argv=None):
                        "drones_per_gpu": n, "global_drones": n * world, "action_ring": ring, "api": args.api,
                        "partitions": (venv.partitions if venv is not None else 1),
                        "partition_streams": (venv.stream_report if venv is not None else None),
-                       "steps_per_launch": steps_per_launch,
+                       "steps_per_launch": steps_per_launch, "rotation_drones": (env.rotation if hasattr(env, "rotation") and not args.racer else 0),
                        "parallelism": f"shard{world}" + ("+allgather(done_bits x" + str(args.gather_block) + " steps"
                                                               + (", last_return" if args.gather_returns else "") + ")" if gather is not None else "")},
             "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
@@ -1073,7 +1084,8 @@ def main(argv=None):
                          "host_enqueue_over": f"the first {k_host} steps of the timed region (before the hardware queue can fill)",
                          "host_bound": bool(host_enqueue_s / max(k_host, 1) > 0.9 * dev_ms * 1e-3 / args.steps),
                          "cache_note": "at 2^20 drones the 59 MB state is re-read from the 256 MiB Infinity Cache (MALL) every step; "
-                                       "only the action stream and reward/done cross HBM - `beyond_mall` is the same kernel at 2^23 drones",
+                                       "only the action stream and reward/done cross HBM - `beyond_mall` is the same kernel at 2^23 drones, where the traversal rotates so that "
+                                       "each launch starts on what the cache still holds",
                          "frac_beyond_mall": beyond["frac"] if beyond else None, "beyond_mall": beyond,
                          "sustained": sustained,
                          "launch_time_fit": None,

@@ -312,7 +312,21 @@ __device__ __forceinline__ float4 apply_stick_noise(const FpvK& K, const FpvBufD
 // prologue, which loads the same prefix with s_load: same results either way.)  The structs that follow still carry
 // the same fields; fpv_step_view() overrides them, so their kernarg copies are never loaded.
 #define FPV_STEP_PARAMS float* __restrict__ a_state, const int64_t a_ld, const float4* __restrict__ a_action, \
-                        const int64_t a_action_ld, uint16_t* __restrict__ a_state_h, const int64_t n, const FpvK K, const FpvBufD B_
+                        const int64_t a_action_ld, uint16_t* __restrict__ a_state_h, const int64_t n_start, const FpvK K, const FpvBufD B_
+// `n_start` = the number of drones (low 32 bits; n <= 2^28) and a START BLOCK (high 32 bits): workgroup b works on block
+// (b + start) mod blocks - ascending addresses all the way, one wrap.  The host moves the start BACK by the Infinity Cache's worth
+// of drones from launch to launch (launch_step: rotation), so that a launch BEGINS on the state rows the previous launch wrote
+// LAST - the ones the 256 MiB cache still holds - instead of on the ones it wrote first, which a population larger than the
+// cache has pushed out by then (every launch in the same order re-reads everything from HBM: cyclic access is the worst case of a
+// recency cache).  Results do not depend on the order in which blocks run; start = 0 (every population that fits the cache, the
+// headline's included) is the plain order.  n and the block count come from the preloaded argument: gridDim.x would be a cold
+// scalar load ahead of the first vector loads.
+#define FPV_STEP_INDEX \
+    const int64_t n = n_start & 0xffffffffll; \
+    const uint32_t nblk_ = (uint32_t)((n + kStepBlock - 1) / kStepBlock); \
+    uint32_t blk_ = blockIdx.x + (uint32_t)(n_start >> 32); \
+    blk_ = blk_ >= nblk_ ? blk_ - nblk_ : blk_; \
+    const uint32_t i = blk_ * (uint32_t)kStepBlock + threadIdx.x
 __device__ __forceinline__ FpvBufD fpv_step_view(const FpvBufD& B_, float* st, int64_t ld, const float4* act, int64_t act_ld, uint16_t* sh)
 {
     FpvBufD B = B_;
@@ -337,27 +351,14 @@ __device__ __forceinline__ const FpvStepArgs& fpv_step_args_again()
     return *(const FpvStepArgs*)p;
 }
 
-// The fp32 drone step kernels take `n` and a START BLOCK in one preloaded argument (n in the low 32 bits - n <= 2^28 -, the
-// block in the high 32): workgroup b works on block (b + start) mod blocks, ascending addresses all the way, one wrap.  The host
-// moves the start BACK by the Infinity Cache's worth of drones from launch to launch (launch_step: rotation), so that a
-// launch BEGINS on the state rows the previous launch wrote LAST - the ones the 256 MiB cache still holds - instead of
-// on the ones it wrote first, which a population larger than the cache has pushed out by then (every launch in the same
-// order re-reads everything from HBM: cyclic access is the worst case of a recency cache).  Results do not depend on the
-// order in which blocks run; start = 0 (every population that fits the cache, the headline's included) is the plain order.
-#define FPV_DRONE_STEP_PARAMS float* __restrict__ a_state, const int64_t a_ld, const float4* __restrict__ a_action, \
-                              const int64_t a_action_ld, uint16_t* __restrict__ a_state_h, const int64_t n_start, const FpvK K, const FpvBufD B_
 template <bool NOISE = false, bool OBJ = false, bool KAHAN = false, bool OVR = false>
-__global__ __launch_bounds__(kStepBlock) FPV_EXP_STEP_ATTR void fpv_drone_step_kernel(FPV_DRONE_STEP_PARAMS)
+__global__ __launch_bounds__(kStepBlock) FPV_EXP_STEP_ATTR void fpv_drone_step_kernel(FPV_STEP_PARAMS)
 {
     constexpr bool SECTIONED = NOISE || (OBJ && OVR);
     FPV_STEP_VIEW;
     __shared__ FpvNormalRow ntab[NOISE ? FPV_NTAB_ROWS : 1];
     if (NOISE) stage_normal_table(ntab);
-    const int64_t n = n_start & 0xffffffffll;                              // n <= 2^28 (fpv_create)
-    const uint32_t nblk = (uint32_t)((n + kStepBlock - 1) / kStepBlock);   // from the preloaded argument (gridDim.x would be a cold scalar load ahead of the first vector loads)
-    uint32_t blk = blockIdx.x + (uint32_t)(n_start >> 32);
-    blk = blk >= nblk ? blk - nblk : blk;
-    const uint32_t i = blk * (uint32_t)kStepBlock + threadIdx.x;
+    FPV_STEP_INDEX;
     // lanes past the end leave at once (a ballot over the remaining lanes still yields the right done bits:
     // exited lanes contribute 0, and a wave whose lane 0 is gone is empty)
     if (i >= n) return;
@@ -632,7 +633,7 @@ __global__ __launch_bounds__(kStepBlock) void fpv_drone_step_aos_kernel(FPV_STEP
     FPV_STEP_VIEW;
     constexpr int kPitch = 17;
     __shared__ float tile[kStepBlock / 64][64 * kPitch];
-    const uint32_t i = blockIdx.x * (uint32_t)kStepBlock + threadIdx.x;
+    FPV_STEP_INDEX;
     const bool live = i < n;
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     FpvStepOut o;
@@ -725,7 +726,7 @@ __device__ __forceinline__ void st_thrust_pair_h(const FpvBufD& B, uint32_t i, b
 __global__ __launch_bounds__(kStepBlock) void fpv_drone_step_h_kernel(FPV_STEP_PARAMS)
 {
     FPV_STEP_VIEW;
-    const uint32_t i = blockIdx.x * (uint32_t)kStepBlock + threadIdx.x;
+    FPV_STEP_INDEX;
     const bool live = i < n;                 // no early exit: the thrust-pair exchange needs whole lane pairs
     FpvStepOut o;
     o.done = false; o.reward = 0.0f; o.ax = o.ay = o.az = 0.0f;
@@ -876,7 +877,7 @@ template <bool WIDE, bool PIDV>
 __global__ __launch_bounds__(kStepBlock) void fpv_racer_step_kernel(FPV_STEP_PARAMS)
 {
     FPV_STEP_VIEW;
-    const uint32_t i = blockIdx.x * (uint32_t)kStepBlock + threadIdx.x;
+    FPV_STEP_INDEX;
     if (i >= n) return;
     FpvRacerState s;
     const float4 a = ld_action(B.action, i);
@@ -1128,7 +1129,7 @@ struct fpv_env {
     int mode;
     uint64_t launches;   // 64-bit step index: counts the steps launched so far; keys the stick-noise stream (Philox
                          // counter words 2 and 3) and the stochastic rounding (fpv_round_seed)
-    // rotation of the fp32 drone step kernels' start block (FPV_DRONE_STEP_PARAMS): blocks the start moves back per launch
+    // rotation of the single-step kernels' start block (FPV_STEP_INDEX): blocks the start moves back per launch
     // (0 = plain order), where the next launch starts, and what the caller asked for (fpv_set_rotation: -1 = automatic)
     int64_t rot_blocks = 0, start_block = 0, rot_request = -1;
     // cached hipGraph of the last fpv_rollout_graph call (launch-bound small batches): rebuilt when the
@@ -1329,8 +1330,8 @@ KernelChoice choose_kernel(const fpv_env* h, const FpvBufD& d)
             c.func = obj ? fpv_drone_step_kernel<false, true, false, true> : fpv_drone_step_kernel<false, false, false, true>;
         else
             c.func = drone_kernel(noise, obj, kahan);
-        c.rotates = true;                   // the fpv_drone_step_kernel family reads n and the start block from one argument
     }
+    c.rotates = true;                       // every single-step kernel reads n and the start block from one argument (FPV_STEP_INDEX)
     c.grid = (unsigned)((h->n + kStepBlock - 1) / kStepBlock);
     return c;
 }
@@ -1359,14 +1360,16 @@ void update_rotation(fpv_env* h)
 {
     const int64_t nblk = (h->n + kStepBlock - 1) / kStepBlock;
     int64_t blocks = 0;
-    if (h->mode == FPV_MODE_DRONE && !(h->K.flags & FPV_FLAG_FP16_STATE)) {
-        if (h->rot_request < 0) {
-            const int64_t rows = FPV_DRONE_ROWS + ((h->K.flags & FPV_FLAG_STICK_NOISE) ? 4 : 0);     // rows read AND written every step
-            const int64_t fit = kInfinityCacheBytes / 8 * 7 / (4 * rows) / kStepBlock;
-            blocks = nblk > fit ? fit : 0;          // a population that fits the cache keeps the plain order
-        } else {
-            blocks = (h->rot_request / kStepBlock) % (nblk > 0 ? nblk : 1);
-        }
+    if (h->rot_request < 0) {
+        // bytes per drone that are read AND written every step (what has to be found in the cache again)
+        int64_t bytes;
+        if (h->mode == FPV_MODE_RACER) bytes = 4 * (20 + (h->K.r_wide ? 6 : 0) + (h->K.r_pid_variant ? 3 : 0));
+        else if (h->K.flags & FPV_FLAG_FP16_STATE) bytes = 3 * 4 + FPV_HALF_PAIR_ROWS * 4 + 2;
+        else bytes = 4 * (FPV_DRONE_ROWS + ((h->K.flags & FPV_FLAG_STICK_NOISE) ? 4 : 0));
+        const int64_t fit = kInfinityCacheBytes / 8 * 7 / bytes / kStepBlock;
+        blocks = nblk > fit ? fit : 0;              // a population that fits the cache keeps the plain order
+    } else {
+        blocks = (h->rot_request / kStepBlock) % (nblk > 0 ? nblk : 1);
     }
     h->rot_blocks = blocks;
     h->start_block = 0;

@@ -2332,18 +2332,27 @@ def test_bench_line_auxiliary_legs_at_the_headline_size():
         assert lf["invalid_reason"] and lf["floor_share_of_headline_launch"] is None
 
 
-@pytest.mark.parametrize("kind", ["plain", "noise", "objects", "kahan", "guidance", "episodes"])
+@pytest.mark.parametrize("kind", ["plain", "noise", "objects", "kahan", "guidance", "fp16", "aos", "racer", "racer_written"])
 def test_rotation_of_the_traversal_is_bit_identical(params_1k, kind):
     """fpv_set_rotation (ABI 7): the fp32 drone step kernels start `drones` before the previous launch's start and wrap - so that a
     population beyond the 256 MiB Infinity Cache begins each launch on the rows it wrote last.  The ORDER of the workgroups must
     not matter: every buffer bit for bit the plain order's, for every instantiation, ragged n (a partial last block), steps through
     step(), rollout(fused=False) and the hipGraph replay, a rotation smaller and larger than the population."""
-    from fpyv_amd.env import DroneBatch
+    from fpyv_amd.env import DroneBatch, RacerBatch
     from fpyv_amd.objects import Cylinder, Ground
     n, T = 70001, 24
-    p = params_1k.replace(ceiling=10.2, init_position=np.array([0.0, 0.0, 0.25]), init_velocity=np.array([1.0, 0.2, -1.5]))
-    kw = dict(device=DEV, auto_reset=True, with_accel=True, with_done_bits=True, track_episodes=(kind == "episodes"))
+    p = params_1k.replace(ceiling=10.2, init_position=np.array([0.0, 0.0, 0.03]), init_velocity=np.array([1.0, 0.2, -3.0]))   # through z = 0 within 10 ms
+    kw = dict(device=DEV, auto_reset=True, with_accel=True, with_done_bits=True, track_episodes=True)
     objs = ()
+    racer = kind.startswith("racer")
+    if racer:
+        pid = np.array([[0.004, 0.02, 1e-6], [0.003, 0.01, 2e-6], [0.002, 0.005, 0]])
+        p = params_1k.replace(mode=1, racer_pid=pid, racer_omega_dt=(kind == "racer"), ceiling=2e-4)
+        kw.pop("with_accel")
+    if kind == "fp16":
+        kw.update(fp16_state=True, rounding_seed=3, with_accel=False)
+    if kind == "aos":
+        kw.update(with_obs_aos=True)
     if kind == "noise":
         kw.update(stick_noise=True, noise_seed=5, with_action_out=True)
     if kind == "kahan":
@@ -2356,30 +2365,35 @@ def test_rotation_of_the_traversal_is_bit_identical(params_1k, kind):
     thrust = torch.full((n,), 6.0, device=DEV)
 
     def run(rotation):
-        e = DroneBatch(p, n, **kw)
+        e = (RacerBatch if racer else DroneBatch)(p, n, **kw)
         assert e.rotation == 0, "a population that fits the cache keeps the plain order by default"
         e.set_rotation(rotation)
         assert e.rotation == (rotation // 128 * 128) % ((n + 127) // 128 * 128) or rotation == 0
         e.reset()
+        ol = {} if racer else dict(object_list=objs)
         for t in range(8):
             if kind == "guidance":
                 e.step(acts[t], rotation_matrix=R, thrust_force=thrust, return_imu=False)
+            elif racer:
+                e.step(acts[t] * torch.tensor([3.0, 3.0, 3.0, 4.0], device=DEV))
             else:
                 e.step(acts[t], object_list=objs, return_imu=False)
-        e.rollout(acts[8:16], fused=False, object_list=objs)
-        e.rollout(acts[16:24], graph=True, object_list=objs)
-        e.rollout(acts[16:24], graph=True, object_list=objs)                      # a replay of the cached graph
+        e.rollout(acts[8:16], fused=False, **ol)
+        e.rollout(acts[16:24], graph=True, **ol)
+        e.rollout(acts[16:24], graph=True, **ol)                                   # a replay of the cached graph
         torch.cuda.synchronize()
         return e
 
     base = run(0)
     for rotation in (384, 128 * 300, 128 * 9000):
         other = run(rotation)
-        for name in ("state", "reward", "done_u8", "done_bits", "accel", "ep_return", "ep_length", "last_return", "last_length", "noise_state", "action_out", "pos_comp"):
+        for name in ("state", "state_h", "reward", "done_u8", "done_bits", "accel", "ep_return", "ep_length", "last_return", "last_length", "noise_state", "action_out",
+                     "pos_comp", "obs_aos"):
             x, y = getattr(base, name, None), getattr(other, name, None)
             if x is not None:
+                x, y = (x.view(torch.int16), y.view(torch.int16)) if name == "state_h" else (x, y)
                 assert torch.equal(x, y), (kind, rotation, name)
-    assert bool(base.done.any()) or kind in ("noise",), "the run must end episodes (auto-reset inside the rotated order too)"
+    assert int(base.last_length.max()) > 0, "the run must end episodes (auto-reset inside the rotated order too)"
 
 
 def test_rotation_is_automatic_beyond_the_infinity_cache_and_pays(params_1k):
@@ -2393,7 +2407,8 @@ def test_rotation_is_automatic_beyond_the_infinity_cache_and_pays(params_1k):
     assert DroneBatch(params_1k, (1 << 22) + 128, device=DEV, with_accel=False).rotation == 1 << 22
     noisy = DroneBatch(params_1k, 5 << 20, device=DEV, with_accel=False, stick_noise=True)
     assert noisy.rotation == (256 << 20) // 8 * 7 // (4 * 18) // 128 * 128
-    assert DroneBatch(params_1k, 5 << 20, device=DEV, with_accel=False, fp16_state=True).rotation == 0     # fp16 storage: not rotated
+    assert DroneBatch(params_1k, 5 << 20, device=DEV, with_accel=False, fp16_state=True).rotation == 0     # 34 B per drone: 5 M drones still fit
+    assert DroneBatch(params_1k, 8 << 20, device=DEV, with_accel=False, fp16_state=True).rotation == (256 << 20) // 8 * 7 // 34 // 128 * 128
     del noisy
     torch.cuda.empty_cache()
     n = 1 << 23
