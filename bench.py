@@ -987,7 +987,7 @@ def main(argv=None):
         leg = timed_leg(big, acts_b, 100, 0, repeats=3)
         us = leg["avg_launch_us"]
         # the same chain in the plain order (every launch from drone 0): what the rotation of the traversal buys beyond the cache
-        rotation = getattr(big, "rotation", 0) if not args.racer else 0
+        rotation = big.rotation
         plain_us = None
         if rotation:
             big.set_rotation(0)
@@ -1073,7 +1073,7 @@ def main(argv=None):
                        "drones_per_gpu": n, "global_drones": n * world, "action_ring": ring, "api": args.api,
                        "partitions": (venv.partitions if venv is not None else 1),
                        "partition_streams": (venv.stream_report if venv is not None else None),
-                       "steps_per_launch": steps_per_launch, "rotation_drones": (env.rotation if hasattr(env, "rotation") and not args.racer else 0),
+                       "steps_per_launch": steps_per_launch, "rotation_drones": env.rotation,
                        "parallelism": f"shard{world}" + ("+allgather(done_bits x" + str(args.gather_block) + " steps"
                                                               + (", last_return" if args.gather_returns else "") + ")" if gather is not None else "")},
             "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",

@@ -1234,7 +1234,8 @@ def test_checkpoint_resume_is_bit_exact(params_1k, tmp_path):
         DroneBatch(p, 4999, **kw).load_state_dict(ck)
     # a checkpoint says what its bits mean: an fp16 state written with another storage encoding (ABI <= 4 recorded none) is
     # refused instead of decoded as garbage; another stick-noise generator is a warning (the run goes on, not bit for bit)
-    assert ck["abi_version"] == 6 and "philox4x32-7" in ck["noise_generator"]
+    from fpyv_amd import _lib as _l
+    assert ck["abi_version"] == _l.FPV_ABI_VERSION and "philox4x32-7" in ck["noise_generator"]
     with pytest.warns(RuntimeWarning, match="stick-noise generator"):
         b.load_state_dict({k: v for k, v in ck.items() if k != "noise_generator"})
     h = DroneBatch(p, 640, device=DEV, fp16_state=True, with_accel=False)
