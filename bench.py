@@ -1025,6 +1025,7 @@ def main(argv=None):
         fit_legs = []
         for nn in (n // 2, n, 2 * n):
             e = make_env(nn, False)
+            e.set_rotation(0)       # the plain order: the line is about ONE cache level (the rotation lets the L2s serve a part at 2^20 and 2^21 drones)
             e.reset()
             aa = sticks.ema_noise_device(8, nn, dev, seed=5)
             leg_preheat(e, aa)
@@ -1083,7 +1084,8 @@ def main(argv=None):
                          "host_enqueue_us": host_enqueue_s * 1e6 / max(k_host, 1) * steps_per_launch,
                          "host_enqueue_over": f"the first {k_host} steps of the timed region (before the hardware queue can fill)",
                          "host_bound": bool(host_enqueue_s / max(k_host, 1) > 0.9 * dev_ms * 1e-3 / args.steps),
-                         "cache_note": "at 2^20 drones the 59 MB state is re-read from the 256 MiB Infinity Cache (MALL) every step; "
+                         "cache_note": "at 2^20 drones the 59 MB state is re-read from the 256 MiB Infinity Cache (MALL) every step - and, with the rotation of the "
+                                       "traversal (config.rotation_drones: each launch starts on the rows the previous one wrote last), about half of it from the L2s; "
                                        "only the action stream and reward/done cross HBM - `beyond_mall` is the same kernel at 2^23 drones, where the traversal rotates so that "
                                        "each launch starts on what the cache still holds",
                          "frac_beyond_mall": beyond["frac"] if beyond else None, "beyond_mall": beyond,
@@ -1098,7 +1100,7 @@ def main(argv=None):
             lf = fit_launch_time([(g_["drones"], g_["bytes_per_launch"], g_["avg_launch_us"]) for g_ in fit_legs])
             head_us = sustained["avg_launch_us"] if sustained else kernel_s * 1e6
             lf.update(legs=[{k_: g_[k_] for k_ in ("drones", "avg_launch_us", "repeats_us", "launches", "host_enqueue_us", "host_bound")} for g_ in fit_legs],
-                      launched_by="fpv_rollout (k single-step launches per C call), fresh buffers, time-based preheat per leg, median of 3 x 400 launches",
+                      launched_by="fpv_rollout (k single-step launches per C call) in the PLAIN order (fpv_set_rotation 0), fresh buffers, time-based preheat per leg, median of 3 x 400 launches",
                       headline_point="roofline.sustained" if sustained else "the timed region",
                       floor_share_of_headline_launch=(lf["floor_us"] / head_us) if lf["valid"] else None)
             if any(g_["host_bound"] for g_ in fit_legs) and lf["valid"]:

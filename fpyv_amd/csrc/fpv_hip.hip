@@ -1351,10 +1351,18 @@ int launch_step(fpv_env* h, const FpvBufD& d_in, hipStream_t s)
     return FPV_OK;
 }
 
-// MI355X: 256 MiB Infinity Cache (memory-side, all eight XCDs; /opt/skills/guides/MI355X_MICROARCH.md).  The rotation step is 7/8
-// of the drones whose re-read rows fit it: measured at 2^23 drones the launch time is flat from 30 000 to 35 000 blocks of
-// 128 drones and 7 % worse at 36 000 (profiles/r05_exp_rotation_step_sweep.log); 7/8 * 256 MiB / 56 B = 2^22 drones = 32 768 blocks.
+// MI355X: 256 MiB Infinity Cache (memory-side, shared by the eight XCDs) behind eight L2s of 4 MiB, one per XCD
+// (/opt/skills/guides/MI355X_MICROARCH.md).  Both keep what was touched last, and both keep it across a kernel boundary (an L2
+// line written by workgroup b is read again by the workgroup that gets the same block in the next launch: workgroups go to
+// the XCDs round-robin, so a start that is a multiple of 8 blocks keeps every block on its XCD).  The rotation step is 7/8 of the
+// drones whose re-read rows fit the cache level that the population overflows:
+//   state <= 7/8 of the L2s                      plain order (everything is found again anyway)
+//   state beyond the L2s, inside the Infinity Cache   7/8 * 32 MiB / bytes per drone   (2^19 drones for the plain kernel's 56 B)
+//   state beyond the Infinity Cache               7/8 * 256 MiB / bytes per drone  (2^22 drones)
+// Measured (profiles/r05_exp_rotation_step_sweep.log): at 2^23 drones the launch time is flat from 30 000 to 35 000 blocks of 128 drones
+// and 7 % worse at 36 000; at 2^20 drones it falls from 22.7 us (plain) to 20.2 us at 4096 blocks and is back at 21.9 us at 5120.
 constexpr int64_t kInfinityCacheBytes = (int64_t)256 << 20;
+constexpr int64_t kL2Bytes = (int64_t)8 * (4 << 20);
 
 void update_rotation(fpv_env* h)
 {
@@ -1366,8 +1374,9 @@ void update_rotation(fpv_env* h)
         if (h->mode == FPV_MODE_RACER) bytes = 4 * (20 + (h->K.r_wide ? 6 : 0) + (h->K.r_pid_variant ? 3 : 0));
         else if (h->K.flags & FPV_FLAG_FP16_STATE) bytes = 3 * 4 + FPV_HALF_PAIR_ROWS * 4 + 2;
         else bytes = 4 * (FPV_DRONE_ROWS + ((h->K.flags & FPV_FLAG_STICK_NOISE) ? 4 : 0));
-        const int64_t fit = kInfinityCacheBytes / 8 * 7 / bytes / kStepBlock;
-        blocks = nblk > fit ? fit : 0;              // a population that fits the cache keeps the plain order
+        const int64_t fit_mall = kInfinityCacheBytes / 8 * 7 / bytes / kStepBlock / 8 * 8;      // whole rounds of the eight XCDs
+        const int64_t fit_l2 = kL2Bytes / 8 * 7 / bytes / kStepBlock / 8 * 8;
+        blocks = nblk > fit_mall ? fit_mall : nblk > fit_l2 ? fit_l2 : 0;
     } else {
         blocks = (h->rot_request / kStepBlock) % (nblk > 0 ? nblk : 1);
     }

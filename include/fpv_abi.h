@@ -38,8 +38,8 @@ extern "C" {
  *    for ten more kernels - a half-precision policy casts its sticks (`.float()`); sizeof(fpv_buffers_t) shrinks by 8.
  *    fp16 state: the stored quaternion fields saturate at +-16383 instead of wrapping (unit quaternions: unchanged bits). */
 /* 7: fpv_set_rotation / fpv_get_rotation added: the fp32 drone step kernels walk the population from a start block that moves
- *    back by the Infinity Cache's worth of drones per launch when the state does not fit the cache (same results, up to 25 % less
- *    time at 2^23 drones); automatic by default, nothing changes for populations that fit (2^20 drones: the plain order). */
+ *    back by a cache's worth of drones per launch - the L2s' when the state overflows them (2^20 drones: 11 % less time), the
+ *    Infinity Cache's beyond that (2^23 drones: up to 25 % less) - same results; automatic by default. */
 #define FPV_ABI_VERSION 7
 
 enum {
@@ -300,9 +300,11 @@ int fpv_get_step_counter(fpv_handle_t h, uint64_t* step);
  * recently touched 256 MiB in its Infinity Cache; a population whose state is larger than that, walked in the same order every
  * launch, finds nothing of it there (cyclic access).  With rotation the launch starts `drones` BEFORE the drone at which the
  * previous launch started - i.e. on the rows the previous launch wrote last - and wraps around, ascending addresses all the
- * way; the results do not depend on the order (bit-identical).  drones = -1 (default): automatic - 7/8 of the drones whose
- * re-read rows fit the cache (2^22 for the plain kernel) when the population is larger than that, else 0; 0: plain order;
- * > 0: that many drones (rounded down to whole 128-drone workgroups).  fpv_get_rotation returns the value in effect. */
+ * way; the results do not depend on the order (bit-identical).  The same holds one level up: the eight 4 MiB L2s keep the last
+ * 32 MiB across a kernel boundary.  drones = -1 (default): automatic - 7/8 of the drones whose re-read rows fit the cache
+ * level that the population overflows (2^19 drones for the plain kernel beyond the L2s, 2^22 beyond the Infinity Cache;
+ * whole rounds of the eight XCDs), 0 when everything fits the L2s; 0: plain order; > 0: that many drones (rounded down to whole
+ * 128-drone workgroups).  fpv_get_rotation returns the value in effect. */
 int fpv_set_rotation(fpv_handle_t h, int64_t drones);
 int fpv_get_rotation(fpv_handle_t h, int64_t* drones);
 

@@ -2398,18 +2398,22 @@ def test_rotation_of_the_traversal_is_bit_identical(params_1k, kind):
 
 
 def test_rotation_is_automatic_beyond_the_infinity_cache_and_pays(params_1k):
-    """The automatic rule (fpv_abi.h): plain order while the re-read rows fit 7/8 of the 256 MiB Infinity Cache, else the start
-    moves back by that many drones per launch (2^22 for the plain kernel, fewer with the four noise rows).  At 2^23 drones the
-    rotated chain must be clearly faster than the plain one on the same buffers - measured 155 against 180-200 us."""
+    """The automatic rule (fpv_abi.h): plain order while the re-read rows fit 7/8 of the eight L2s; beyond them the start moves
+    back by the L2s' share of drones per launch (2^19 for the plain kernel), beyond the 256 MiB Infinity Cache by its share (2^22;
+    fewer with the four noise rows).  At 2^23 drones the rotated chain must be clearly faster than the plain one on the same
+    buffers - measured 155 against 180-200 us - and at 2^20 drones too (20.2 against 22.6 us)."""
     from fpyv_amd import sticks
     from fpyv_amd.env import DroneBatch
-    assert DroneBatch(params_1k, 1 << 20, device=DEV, with_accel=False).rotation == 0
-    assert DroneBatch(params_1k, 1 << 22, device=DEV, with_accel=False).rotation == 0
-    assert DroneBatch(params_1k, (1 << 22) + 128, device=DEV, with_accel=False).rotation == 1 << 22
+    share = lambda cache, bytes_per_drone: cache // 8 * 7 // bytes_per_drone // 128 // 8 * 8 * 128      # noqa: E731  (whole rounds of the eight XCDs)
+    L2, MALL = 32 << 20, 256 << 20
+    assert DroneBatch(params_1k, 1 << 19, device=DEV, with_accel=False).rotation == 0                      # 29 MB of state: the L2s hold it
+    assert DroneBatch(params_1k, 1 << 20, device=DEV, with_accel=False).rotation == share(L2, 56) == 1 << 19
+    assert DroneBatch(params_1k, 1 << 22, device=DEV, with_accel=False).rotation == 1 << 19
+    assert DroneBatch(params_1k, (1 << 22) + 128, device=DEV, with_accel=False).rotation == share(MALL, 56) == 1 << 22
     noisy = DroneBatch(params_1k, 5 << 20, device=DEV, with_accel=False, stick_noise=True)
-    assert noisy.rotation == (256 << 20) // 8 * 7 // (4 * 18) // 128 * 128
-    assert DroneBatch(params_1k, 5 << 20, device=DEV, with_accel=False, fp16_state=True).rotation == 0     # 34 B per drone: 5 M drones still fit
-    assert DroneBatch(params_1k, 8 << 20, device=DEV, with_accel=False, fp16_state=True).rotation == (256 << 20) // 8 * 7 // 34 // 128 * 128
+    assert noisy.rotation == share(MALL, 4 * 18)
+    assert DroneBatch(params_1k, 5 << 20, device=DEV, with_accel=False, fp16_state=True).rotation == share(L2, 34)      # 34 B per drone: 5 M drones fit the Infinity Cache
+    assert DroneBatch(params_1k, 8 << 20, device=DEV, with_accel=False, fp16_state=True).rotation == share(MALL, 34)
     del noisy
     torch.cuda.empty_cache()
     n = 1 << 23
@@ -2436,3 +2440,13 @@ def test_rotation_is_automatic_beyond_the_infinity_cache_and_pays(params_1k):
     t_plain, s_plain = timed()
     assert torch.equal(s_rot, s_plain)
     assert t_rot < 0.95 * t_plain, (t_rot, t_plain)
+    del e, acts, s_rot, s_plain
+    torch.cuda.empty_cache()
+    n = 1 << 20
+    e = DroneBatch(params_1k.replace(ceiling=100.0), n, device=DEV, auto_reset=True, with_accel=False)
+    acts = sticks.ema_noise_device(16, n, DEV, seed=9)
+    t_rot, s_rot = timed()
+    e.set_rotation(0)
+    t_plain, s_plain = timed()
+    assert torch.equal(s_rot, s_plain)
+    assert t_rot < 0.97 * t_plain, (t_rot, t_plain)
