@@ -1079,6 +1079,10 @@ def main(argv=None):
                                                               + (", last_return" if args.gather_returns else "") + ")" if gather is not None else "")},
             "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": achieved / HBM_PEAK_GBS, "traffic": traffic, "traffic_source": traffic_src,
+                         "traffic_note": ("the counter passes serialise the launches and the L2s do not keep their lines from one to the next there (profiles/pmc_traffic.json: "
+                                          "pmc_pass_step_kernel_avg_ns against kernel_trace_avg_ns): `traffic` is what a launch with COLD L2s asks the memory side for - its "
+                                          "algorithmic bytes; in the running chain the rotation lets the L2s answer a part of the state reads, which no counter pass can watch "
+                                          "without undoing it" if traffic is not None else None),
                          "kernel": kernel, "algorithmic_bytes_per_env_step": bytes_per_step,
                          "avg_launch_us": kernel_s * 1e6,
                          "host_enqueue_us": host_enqueue_s * 1e6 / max(k_host, 1) * steps_per_launch,
