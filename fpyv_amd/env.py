@@ -855,6 +855,11 @@ class FpvVecEnv:
                     streams, self.stream_report = overlapping_streams(self.batch.device, len(bounds),
                                                                       avoid=[torch.cuda.current_stream(self.batch.device)])
                 self._parts = [_Partition(self.batch, lo, hi, st) for (lo, hi), st in zip(bounds, streams)]
+                # the partitions' chains run side by side and share the caches: each one rotates its traversal by ITS share of what the
+                # whole population would (a partition on its own would find that it fits the L2s and keep the plain order)
+                share = self.batch.rotation // len(self._parts) // 1024 * 1024
+                for P in self._parts:
+                    _lib.check(P._L.fpv_set_rotation(P._handle, share))
                 self._part_views = [None] * len(self._parts)
         self.partitions = max(1, len(self._parts))
 
