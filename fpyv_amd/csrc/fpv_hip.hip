@@ -314,13 +314,13 @@ __device__ __forceinline__ float4 apply_stick_noise(const FpvK& K, const FpvBufD
 #define FPV_STEP_PARAMS float* __restrict__ a_state, const int64_t a_ld, const float4* __restrict__ a_action, \
                         const int64_t a_action_ld, uint16_t* __restrict__ a_state_h, const int64_t n_start, const FpvK K, const FpvBufD B_
 // `n_start` = the number of drones (low 32 bits; n <= 2^28) and a START BLOCK (high 32 bits): workgroup b works on block
-// (b + start) mod blocks - ascending addresses all the way, one wrap.  The host moves the start BACK by the Infinity Cache's worth
-// of drones from launch to launch (launch_step: rotation), so that a launch BEGINS on the state rows the previous launch wrote
-// LAST - the ones the 256 MiB cache still holds - instead of on the ones it wrote first, which a population larger than the
-// cache has pushed out by then (every launch in the same order re-reads everything from HBM: cyclic access is the worst case of a
-// recency cache).  Results do not depend on the order in which blocks run; start = 0 (every population that fits the cache, the
-// headline's included) is the plain order.  n and the block count come from the preloaded argument: gridDim.x would be a cold
-// scalar load ahead of the first vector loads.
+// (b + start) mod blocks - ascending addresses all the way, one wrap.  The host moves the start BACK by a cache's worth of
+// drones from launch to launch (update_rotation / launch_step), so that a launch BEGINS on the state rows the previous launch wrote
+// LAST - the ones the cache still holds (the eight L2s for a population inside the Infinity Cache, the 256 MiB Infinity Cache for
+// a larger one) - instead of on the ones it wrote first, which a population larger than the cache has pushed out by then (every
+// launch in the same order finds nothing: cyclic access is the worst case of a recency cache).  Results do not depend on the
+// order in which blocks run; start = 0 is the plain order.  n and the block count come from the preloaded argument: gridDim.x
+// would be a cold scalar load ahead of the first vector loads.
 #define FPV_STEP_INDEX \
     const int64_t n = n_start & 0xffffffffll; \
     const uint32_t nblk_ = (uint32_t)((n + kStepBlock - 1) / kStepBlock); \
