@@ -2439,7 +2439,7 @@ def test_rotation_is_automatic_beyond_the_infinity_cache_and_pays(params_1k):
     e.set_rotation(0)
     t_plain, s_plain = timed()
     assert torch.equal(s_rot, s_plain)
-    assert t_rot < 0.95 * t_plain, (t_rot, t_plain)
+    assert t_rot < 0.97 * t_plain, (t_rot, t_plain)            # measured 0.78 - 0.87
     del e, acts, s_rot, s_plain
     torch.cuda.empty_cache()
     n = 1 << 20
@@ -2449,4 +2449,4 @@ def test_rotation_is_automatic_beyond_the_infinity_cache_and_pays(params_1k):
     e.set_rotation(0)
     t_plain, s_plain = timed()
     assert torch.equal(s_rot, s_plain)
-    assert t_rot < 0.97 * t_plain, (t_rot, t_plain)
+    assert t_rot < 0.985 * t_plain, (t_rot, t_plain)           # measured 0.89 - 0.90
