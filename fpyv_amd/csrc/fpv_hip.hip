@@ -1336,12 +1336,15 @@ KernelChoice choose_kernel(const fpv_env* h, const FpvBufD& d)
     return c;
 }
 
+int64_t rotation_blocks(const fpv_env* h, const FpvBufD* d);      // below, with the cache sizes
+
 int launch_step(fpv_env* h, const FpvBufD& d_in, hipStream_t s)
 {
     FpvBufD d = d_in;
     d.step = h->launches;
     const KernelChoice c = choose_kernel(h, d);
     const int64_t nblk = (int64_t)c.grid;
+    h->rot_blocks = rotation_blocks(h, &d);
     const int64_t start = (c.rotates && h->rot_blocks > 0) ? h->start_block % nblk : 0;
     hipLaunchKernelGGL(c.func, dim3(c.grid), dim3(c.block), 0, s, d.state, d.ld, d.action, d.action_ld, d.state_h, h->n | (start << 32), h->K, d);
     const hipError_t e = hipGetLastError();
@@ -1354,42 +1357,64 @@ int launch_step(fpv_env* h, const FpvBufD& d_in, hipStream_t s)
 // MI355X: 256 MiB Infinity Cache (memory-side, shared by the eight XCDs) behind eight L2s of 4 MiB, one per XCD
 // (/opt/skills/guides/MI355X_MICROARCH.md).  Both keep what was touched last, and both keep it across a kernel boundary (an L2
 // line written by workgroup b is read again by the workgroup that gets the same block in the next launch: workgroups go to
-// the XCDs round-robin, so a start that is a multiple of 8 blocks keeps every block on its XCD).  The rotation step is 7/8 of the
-// drones whose re-read rows fit the cache level that the population overflows:
-//   state <= 7/8 of the L2s                      plain order (everything is found again anyway)
-//   state beyond the L2s, inside the Infinity Cache   7/8 * 32 MiB / bytes per drone   (2^19 drones for the plain kernel's 56 B)
-//   state beyond the Infinity Cache               7/8 * 256 MiB / bytes per drone  (2^22 drones)
+// the XCDs round-robin, so a start that is a multiple of 8 blocks keeps every block on its XCD).  The rotation step is the
+// drones whose WRITTEN bytes fill the cache level that the launch overflows (rotation_blocks):
+//   a launch writes less than the L2s hold          plain order (everything is found again anyway)
+//   more than the L2s, less than the Infinity Cache   61/64 * 32 MiB / written bytes per drone   (2^19 drones for the plain kernel's 61 B)
+//   more than the Infinity Cache                    61/64 * 256 MiB / written bytes per drone  (2^22 drones)
 // Measured (profiles/r05_exp_rotation_step_sweep.log): at 2^23 drones the launch time is flat from 30 000 to 35 000 blocks of 128 drones
 // and 7 % worse at 36 000; at 2^20 drones it falls from 22.7 us (plain) to 20.2 us at 4096 blocks and is back at 21.9 us at 5120.
 constexpr int64_t kInfinityCacheBytes = (int64_t)256 << 20;
 constexpr int64_t kL2Bytes = (int64_t)8 * (4 << 20);
 
-void update_rotation(fpv_env* h)
+// Bytes per drone that one launch WRITES: what fills a cache between two visits of a drone (reads of rows that are written back
+// are the same lines; the stick rows are streamed with a non-temporal hint).  The plain kernel: 14 rows + reward + done = 61 B,
+// and 4096 blocks of 128 drones x 61 B are the 32 MB of the eight L2s - where the sweep has its optimum.  `d` = the buffers of
+// the launch, or null for an estimate from the handle alone (fpv_get_rotation before the first launch).
+int64_t written_bytes_per_drone(const fpv_env* h, const FpvBufD* d)
+{
+    int64_t b;
+    if (h->mode == FPV_MODE_RACER) b = 4 * (20 + (h->K.r_wide ? 6 : 0) + (h->K.r_pid_variant ? 3 : 0));
+    else if (h->K.flags & FPV_FLAG_FP16_STATE) b = 3 * 4 + FPV_HALF_PAIR_ROWS * 4 + 2;
+    else b = 4 * FPV_DRONE_ROWS;
+    if (h->K.flags & FPV_FLAG_STICK_NOISE) b += 16;            // the four EMA rows
+    if (!d) return b + 5;
+    if (d->reward) b += 4;
+    if (d->done) b += 1;
+    if (d->accel) b += 12;
+    if (d->obs_aos) b += 64;
+    if (d->pos_comp) b += 24;
+    if (d->action_out) b += 16;
+    if (d->ep_return) b += 8;                                   // running return and length (the last_* rows only when an episode ends)
+    return b;
+}
+
+// blocks the start moves back per launch for these buffers: the cache level that the launch's writes overflow, 61/64 of it
+// (the factor that puts the plain kernel on its measured optimum: 2^19 drones for the L2s, 2^22 for the Infinity Cache),
+// whole rounds of the eight XCDs; an explicit request (fpv_set_rotation >= 0) as given
+int64_t rotation_blocks(const fpv_env* h, const FpvBufD* d)
 {
     const int64_t nblk = (h->n + kStepBlock - 1) / kStepBlock;
-    int64_t blocks = 0;
-    if (h->rot_request < 0) {
-        // bytes per drone that are read AND written every step (what has to be found in the cache again)
-        int64_t bytes;
-        if (h->mode == FPV_MODE_RACER) bytes = 4 * (20 + (h->K.r_wide ? 6 : 0) + (h->K.r_pid_variant ? 3 : 0));
-        else if (h->K.flags & FPV_FLAG_FP16_STATE) bytes = 3 * 4 + FPV_HALF_PAIR_ROWS * 4 + 2;
-        else bytes = 4 * (FPV_DRONE_ROWS + ((h->K.flags & FPV_FLAG_STICK_NOISE) ? 4 : 0));
-        const int64_t fit_mall = kInfinityCacheBytes / 8 * 7 / bytes / kStepBlock / 8 * 8;      // whole rounds of the eight XCDs
-        const int64_t fit_l2 = kL2Bytes / 8 * 7 / bytes / kStepBlock / 8 * 8;
-        blocks = nblk > fit_mall ? fit_mall : nblk > fit_l2 ? fit_l2 : 0;
-    } else {
-        blocks = (h->rot_request / kStepBlock) % (nblk > 0 ? nblk : 1);
-    }
-    h->rot_blocks = blocks;
+    if (h->rot_request >= 0) return (h->rot_request / kStepBlock) % (nblk > 0 ? nblk : 1);
+    const int64_t bytes = written_bytes_per_drone(h, d);
+    const int64_t fit_mall = kInfinityCacheBytes / 64 * 61 / bytes / kStepBlock / 8 * 8;
+    const int64_t fit_l2 = kL2Bytes / 64 * 61 / bytes / kStepBlock / 8 * 8;
+    return nblk > fit_mall ? fit_mall : nblk > fit_l2 ? fit_l2 : 0;
+}
+
+void update_rotation(fpv_env* h)
+{
+    h->rot_blocks = rotation_blocks(h, nullptr);
     h->start_block = 0;
 }
 
 // node t of a replayed graph: the same rotation, counted from the first node (a replay begins where the previous one began: one
 // launch in k starts on cold rows)
-int64_t graph_n_start(const fpv_env* h, const KernelChoice& c, int t)
+int64_t graph_n_start(const fpv_env* h, const KernelChoice& c, const FpvBufD& d, int t)
 {
     const int64_t nblk = (int64_t)c.grid;
-    const int64_t start = (c.rotates && h->rot_blocks > 0) ? (int64_t)(((uint64_t)t * (uint64_t)(nblk - h->rot_blocks % nblk)) % (uint64_t)nblk) : 0;
+    const int64_t rot = rotation_blocks(h, &d);
+    const int64_t start = (c.rotates && rot > 0) ? (int64_t)(((uint64_t)t * (uint64_t)(nblk - rot % nblk)) % (uint64_t)nblk) : 0;
     return h->n | (start << 32);
 }
 
@@ -1700,7 +1725,7 @@ int fpv_rollout_graph(fpv_handle_t h, const fpv_buffers_t* b, int k, int64_t act
         for (int t = 0; t < k; ++t) {
             FpvBufD d = graph_step_view(b, d0, t, action_stride, out_stride);
             const KernelChoice c = choose_kernel(h, d);
-            int64_t n_start = graph_n_start(h, c, t);
+            int64_t n_start = graph_n_start(h, c, d, t);
             void* args[8] = {&d.state, &d.ld, &d.action, &d.action_ld, &d.state_h, &n_start, &K, &d};   // copied by hipGraphAddKernelNode
             hipKernelNodeParams np;
             memset(&np, 0, sizeof(np));
@@ -1722,7 +1747,7 @@ int fpv_rollout_graph(fpv_handle_t h, const fpv_buffers_t* b, int k, int64_t act
         for (int t = 0; t < k; ++t) {
             FpvBufD d = graph_step_view(b, d0, t, action_stride, out_stride);
             const KernelChoice c = choose_kernel(h, d);
-            int64_t n_start = graph_n_start(h, c, t);
+            int64_t n_start = graph_n_start(h, c, d, t);
             void* args[8] = {&d.state, &d.ld, &d.action, &d.action_ld, &d.state_h, &n_start, &K, &d};
             hipKernelNodeParams np;
             memset(&np, 0, sizeof(np));

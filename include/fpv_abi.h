@@ -301,10 +301,12 @@ int fpv_get_step_counter(fpv_handle_t h, uint64_t* step);
  * launch, finds nothing of it there (cyclic access).  With rotation the launch starts `drones` BEFORE the drone at which the
  * previous launch started - i.e. on the rows the previous launch wrote last - and wraps around, ascending addresses all the
  * way; the results do not depend on the order (bit-identical).  The same holds one level up: the eight 4 MiB L2s keep the last
- * 32 MiB across a kernel boundary.  drones = -1 (default): automatic - 7/8 of the drones whose re-read rows fit the cache
- * level that the population overflows (2^19 drones for the plain kernel beyond the L2s, 2^22 beyond the Infinity Cache;
- * whole rounds of the eight XCDs), 0 when everything fits the L2s; 0: plain order; > 0: that many drones (rounded down to whole
- * 128-drone workgroups).  fpv_get_rotation returns the value in effect. */
+ * 32 MiB across a kernel boundary.  drones = -1 (default): automatic - the drones whose WRITTEN bytes (state rows, reward,
+ * done and whatever else the call's buffers ask for: accel, AoS observations, Kahan rows ...) fill 61/64 of the cache level that
+ * a launch overflows (2^19 drones for the plain kernel's 61 B beyond the L2s, 2^22 beyond the Infinity Cache; whole rounds of the
+ * eight XCDs), 0 when a launch writes less than the L2s hold; 0: plain order; > 0: that many drones (rounded down to whole
+ * 128-drone workgroups).  fpv_get_rotation returns the value of the last launch (before the first: the estimate for reward
+ * and done only). */
 int fpv_set_rotation(fpv_handle_t h, int64_t drones);
 int fpv_get_rotation(fpv_handle_t h, int64_t* drones);
 

@@ -2398,22 +2398,27 @@ def test_rotation_of_the_traversal_is_bit_identical(params_1k, kind):
 
 
 def test_rotation_is_automatic_beyond_the_infinity_cache_and_pays(params_1k):
-    """The automatic rule (fpv_abi.h): plain order while the re-read rows fit 7/8 of the eight L2s; beyond them the start moves
-    back by the L2s' share of drones per launch (2^19 for the plain kernel), beyond the 256 MiB Infinity Cache by its share (2^22;
-    fewer with the four noise rows).  At 2^23 drones the rotated chain must be clearly faster than the plain one on the same
+    """The automatic rule (fpv_abi.h): plain order while what one launch writes fits 61/64 of the eight L2s; beyond them the start
+    moves back by the L2s' share of drones per launch (2^19 for the plain kernel's 61 B), beyond the 256 MiB Infinity Cache by its
+    share (2^22; fewer with the four noise rows, accel rows, Kahan rows).  At 2^23 drones the rotated chain must be clearly faster than the plain one on the same
     buffers - measured 155 against 180-200 us - and at 2^20 drones too (20.2 against 22.6 us)."""
     from fpyv_amd import sticks
     from fpyv_amd.env import DroneBatch
-    share = lambda cache, bytes_per_drone: cache // 8 * 7 // bytes_per_drone // 128 // 8 * 8 * 128      # noqa: E731  (whole rounds of the eight XCDs)
+    share = lambda cache, written: cache // 64 * 61 // written // 128 // 8 * 8 * 128      # noqa: E731  (61/64 of the cache, whole rounds of the eight XCDs)
     L2, MALL = 32 << 20, 256 << 20
-    assert DroneBatch(params_1k, 1 << 19, device=DEV, with_accel=False).rotation == 0                      # 29 MB of state: the L2s hold it
-    assert DroneBatch(params_1k, 1 << 20, device=DEV, with_accel=False).rotation == share(L2, 56) == 1 << 19
+    assert DroneBatch(params_1k, 1 << 19, device=DEV, with_accel=False).rotation == 0                      # a launch writes 32 MB: the L2s hold it
+    assert DroneBatch(params_1k, 1 << 20, device=DEV, with_accel=False).rotation == share(L2, 61) == 1 << 19
     assert DroneBatch(params_1k, 1 << 22, device=DEV, with_accel=False).rotation == 1 << 19
-    assert DroneBatch(params_1k, (1 << 22) + 128, device=DEV, with_accel=False).rotation == share(MALL, 56) == 1 << 22
+    assert DroneBatch(params_1k, (1 << 22) + 128, device=DEV, with_accel=False).rotation == share(MALL, 61) == 1 << 22
     noisy = DroneBatch(params_1k, 5 << 20, device=DEV, with_accel=False, stick_noise=True)
-    assert noisy.rotation == share(MALL, 4 * 18)
-    assert DroneBatch(params_1k, 5 << 20, device=DEV, with_accel=False, fp16_state=True).rotation == share(L2, 34)      # 34 B per drone: 5 M drones fit the Infinity Cache
-    assert DroneBatch(params_1k, 8 << 20, device=DEV, with_accel=False, fp16_state=True).rotation == share(MALL, 34)
+    assert noisy.rotation == share(MALL, 61 + 16)
+    assert DroneBatch(params_1k, 5 << 20, device=DEV, with_accel=False, fp16_state=True).rotation == share(L2, 39)      # 39 B written per drone: 5 M drones fit the Infinity Cache
+    assert DroneBatch(params_1k, 8 << 20, device=DEV, with_accel=False, fp16_state=True).rotation == share(MALL, 39)
+    acc = DroneBatch(params_1k, 1 << 20, device=DEV, with_accel=True, kahan_position=True)               # what a launch writes decides: + accel rows + Kahan rows
+    assert acc.rotation == 1 << 19                                                                       # (the estimate before the first launch knows reward and done only)
+    acc.reset(); acc.step(torch.zeros((1 << 20, 4), device=DEV), return_imu=False)
+    assert acc.rotation == share(L2, 61 + 12 + 24)
+    del acc
     del noisy
     torch.cuda.empty_cache()
     n = 1 << 23
