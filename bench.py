@@ -1014,8 +1014,12 @@ def main(argv=None):
                                        "step-kernel launch at 2^23 drones, same process, before and after the kernel run"}}
         del big, acts_b, src, dst
 
-    # what a launch costs as a function of the population, on this box, in this process: the same kernel at half, at one
-    # and at twice the headline population (all inside the Infinity Cache), each leg on fresh buffers after its own
+    # what a launch costs as a function of the population, on this box, in this process: the same kernel at three quarters,
+    # at one and at twice the headline population - all inside the Infinity Cache and all well beyond the L2s, so that in the
+    # plain order every byte comes from ONE cache level (half the population, 2^19 drones, was a point of this line while its
+    # row stride made the rows collide in the L2s' sets; with the stride of fpv_recommended_ld the L2s hold it and it runs
+    # 2.4 us below the line; fp16 storage writes 39 B per drone: its points start at the headline population) -
+    # each leg on fresh buffers after its own
     # time-based preheat, launched from the C loop (fpv_rollout: the same single-step kernel; one Python call per ring span,
     # so the host's per-call cost cannot bound a leg), median of three 400-launch repeats.  The straight line
     # t(n) = floor + bytes / rate says how much of the headline launch is the per-launch floor of a dependent
@@ -1023,7 +1027,7 @@ def main(argv=None):
     fit_legs = None
     if aux_ok and not args.no_beyond_mall and n == (1 << 20) and not args.racer and venv is None:
         fit_legs = []
-        for nn in (n // 2, n, 2 * n):
+        for nn in ((n, 3 * n // 2, 2 * n) if args.fp16_state else (3 * n // 4, n, 2 * n)):
             e = make_env(nn, False)
             e.set_rotation(0)       # the plain order: the line is about ONE cache level (the rotation lets the L2s serve a part at 2^20 and 2^21 drones)
             e.reset()

@@ -2301,7 +2301,7 @@ def test_bench_line_schema_small(extra):
 
 def test_bench_line_auxiliary_legs_at_the_headline_size():
     """The legs only the full-size line has: `beyond_mall` at 2^23 drones with its three repeats, host enqueue
-    time and buffer addresses, and `launch_time_fit` over 2^19 / 2^20 / 2^21 drones with per-leg repeats, host enqueue time
+    time and buffer addresses, and `launch_time_fit` over 3 * 2^18 / 2^20 / 2^21 drones (beyond the L2s, inside the Infinity Cache) with per-leg repeats, host enqueue time
     and a verdict on its own validity - on a warm GPU the fit must be valid with a floor of a few microseconds."""
     import json
     import os
@@ -2321,7 +2321,7 @@ def test_bench_line_auxiliary_legs_at_the_headline_size():
     assert max(b["repeats_us"]) < 1.10 * min(b["repeats_us"]), b["repeats_us"]
     assert 0.4 < b["frac"] < 0.95 and 0.7 < b["frac_of_copy_ceiling"] < 1.15 and set(b["addresses"]) == {"state", "ld", "action", "reward", "done"}
     lf = ro["launch_time_fit"]
-    assert lf["drones"] == [1 << 19, 1 << 20, 1 << 21] and len(lf["legs"]) == 3
+    assert lf["drones"] == [3 << 18, 1 << 20, 1 << 21] and len(lf["legs"]) == 3
     for leg in lf["legs"]:
         assert len(leg["repeats_us"]) == 3 and leg["launches"] == 400 and 0 < leg["host_enqueue_us"] < leg["avg_launch_us"]
     # the fit judges itself: on a warm, quiet GPU it is valid (floor of a few microseconds); a box on which a leg is off the line
@@ -2369,7 +2369,7 @@ def test_rotation_of_the_traversal_is_bit_identical(params_1k, kind):
         e = (RacerBatch if racer else DroneBatch)(p, n, **kw)
         assert e.rotation == 0, "a population that fits the cache keeps the plain order by default"
         e.set_rotation(rotation)
-        assert e.rotation == (rotation // 128 * 128) % ((n + 127) // 128 * 128) or rotation == 0
+        assert e.rotation == (rotation // 128 * 128) % ((n + 1023) // 1024 * 1024) or rotation == 0      # blocks in whole rounds of the eight XCDs
         e.reset()
         ol = {} if racer else dict(object_list=objs)
         for t in range(8):
@@ -2455,3 +2455,84 @@ def test_rotation_is_automatic_beyond_the_infinity_cache_and_pays(params_1k):
     t_plain, s_plain = timed()
     assert torch.equal(s_rot, s_plain)
     assert t_rot < 0.985 * t_plain, (t_rot, t_plain)           # measured 0.89 - 0.90
+
+
+def test_ragged_population_keeps_its_blocks_on_their_xcds(params_1k):
+    """1 000 000 drones are 7812.5 blocks of 128: with the block count itself as the modulus of the rotating traversal, every
+    block changed its XCD at each wrap and the L2 share of the rotation was lost (22.3 us with, 22.1 us without the rotation).  The
+    traversal runs over whole rounds of the eight XCDs (7816 blocks, three of them empty): measured 19.4 against 21.6 us.  Same
+    results either way, and equal to the sum of two batches that split the population at a block boundary."""
+    from fpyv_amd import sticks
+    from fpyv_amd.env import DroneBatch
+    n = 1_000_000
+    p = params_1k.replace(ceiling=100.0)
+    e = DroneBatch(p, n, device=DEV, auto_reset=True, with_accel=False)
+    assert e.rotation == 1 << 19 and e.ld == _lib.lib().fpv_recommended_ld(n) and e.ld % 512 == 256
+    acts = sticks.ema_noise_device(16, n, DEV, seed=4)
+
+    def timed():
+        e.reset()
+        e.rollout(acts, fused=False)
+        torch.cuda.synchronize()
+        out = []
+        for _ in range(3):
+            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            e0.record()
+            for _ in range(5):
+                e.rollout(acts, fused=False)
+            e1.record(); torch.cuda.synchronize()
+            out.append(e0.elapsed_time(e1) * 1e3 / 80)
+        return sorted(out)[1], e.state[:, :n].clone()
+
+    t_rot, s_rot = timed()
+    e.set_rotation(0)
+    t_plain, s_plain = timed()
+    assert torch.equal(s_rot, s_plain)
+    assert t_rot < 0.96 * t_plain, (t_rot, t_plain)            # measured 0.89 - 0.90
+    cut = 499_968                                               # a block boundary: the two halves see the same sticks, drone for drone
+    parts = [DroneBatch(p, m, device=DEV, auto_reset=True, with_accel=False) for m in (cut, n - cut)]
+    for q, lo in zip(parts, (0, cut)):
+        q.reset()
+        for _ in range(16):
+            q.rollout(acts[:, lo:lo + q.n].contiguous(), fused=False)
+    torch.cuda.synchronize()
+    assert torch.equal(torch.cat([q.state[:, :q.n] for q in parts], dim=1), s_rot)
+
+
+def test_row_stride_of_half_a_million_drones_spreads_over_the_l2_sets(params_1k):
+    """2^19 drones with the former pad of 256 floats (row stride 2 MiB + 1 KiB): the rows of a drone block meet in the same L2
+    sets, an XCD keeps a fraction of what it wrote and a launch takes 11.5 - 13.2 us; with the stride of fpv_recommended_ld (2 MiB +
+    1.25 KiB) 10.7 - 10.9 us (profiles/r05_exp_row_stride_l2_sets.log).  Same numbers in the same rows: results do not depend on ld."""
+    import ctypes as C
+    from fpyv_amd import sticks
+    L = _lib.lib()
+    n = 1 << 19
+    rec = int(L.fpv_recommended_ld(n))
+    assert rec == n + 320
+    cp = _lib.pack_params(params_1k.replace(ceiling=100.0), auto_reset=True)
+    h = C.c_void_p()
+    assert L.fpv_create(C.byref(cp), n, 0, C.byref(h)) == 0
+    acts = sticks.ema_noise_device(32, n, DEV, seed=2)
+    rew, done = torch.zeros(n, device=DEV), torch.zeros(n, dtype=torch.uint8, device=DEV)
+    big = torch.zeros(14 * (n + 512), device=DEV)
+    times, finals = {}, {}
+    for rnd in range(3):
+        for ld in (n + 256, rec):
+            st = big[:14 * ld].view(14, ld)
+            b = _lib.FpvBuffers()
+            b.state, b.ld, b.reward, b.done, b.action = st.data_ptr(), ld, rew.data_ptr(), done.data_ptr(), acts.data_ptr()
+            big.zero_(); st[2] = 10; st[3] = 1; st[6] = 1
+            assert L.fpv_set_step_counter(h, 0) == 0
+            assert L.fpv_rollout(h, C.byref(b), 32, n * 4, 0, None) == 0
+            torch.cuda.synchronize()
+            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            e0.record()
+            for _ in range(8):
+                assert L.fpv_rollout(h, C.byref(b), 32, n * 4, 0, None) == 0
+            e1.record(); torch.cuda.synchronize()
+            times.setdefault(ld, []).append(e0.elapsed_time(e1) * 1e3 / 256)
+            finals[ld] = st[:, :n].clone()
+    L.fpv_destroy(h)
+    assert torch.equal(finals[n + 256], finals[rec])
+    t_old, t_rec = sorted(times[n + 256])[1], sorted(times[rec])[1]
+    assert t_rec < 0.975 * t_old, (t_rec, t_old)              # measured 0.81 - 0.95

@@ -22,6 +22,7 @@ ap.add_argument("--n", type=int, default=1 << 20)
 ap.add_argument("--families", nargs="*", default=["f32", "accel", "noise", "kahan", "aos", "h", "racerW", "racerD", "racerWC"])
 ap.add_argument("--rounds", type=int, default=5)
 ap.add_argument("--launches", type=int, default=320)
+ap.add_argument("--base-blocks", type=int, default=0, help="sweep around this many blocks instead of the automatic rotation (a population the rule leaves in the plain order)")
 ap.add_argument("--scales", nargs="*", type=float, default=[0.0, 0.6, 0.7, 0.8, 0.85, 0.9, 0.95, 1.0, 1.05, 1.1, 1.2])
 a = ap.parse_args()
 dev = torch.device("cuda:0")
@@ -61,7 +62,7 @@ def run(e, f, launches):
 for f in a.families:
     e = build(f)
     run(e, f, 64)
-    auto = e.rotation // 128
+    auto = a.base_blocks or e.rotation // 128
     rots = sorted({int(auto * s) // 8 * 8 for s in a.scales}) if auto else [0]
     res = {r: [] for r in rots}
     for k in range(a.rounds + 1):
