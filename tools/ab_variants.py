@@ -27,6 +27,7 @@ ap.add_argument("--build", action="store_true")
 ap.add_argument("--n", type=int, default=1 << 20)
 ap.add_argument("--rounds", type=int, default=8)
 ap.add_argument("--only", nargs="*", default=None)
+ap.add_argument("--rotations", nargs="*", type=int, default=[-1], help="fpv_set_rotation values (drones; -1 automatic, 0 plain order) to time every variant at")
 ap.add_argument("--states", type=int, default=1, help="time every variant on this many separately allocated state matrices (placement matters beyond the cache)")
 a = ap.parse_args()
 names = [k for k in VARIANTS if not a.only or k in a.only]
@@ -51,6 +52,7 @@ for k in names:
     l.fpv_rollout.argtypes = [C.c_void_p, C.c_void_p, C.c_int, C.c_int64, C.c_int64, C.c_void_p]
     l.fpv_recommended_ld.argtypes = [C.c_int64]; l.fpv_recommended_ld.restype = C.c_int64
     l.fpv_last_error.restype = C.c_char_p
+    l.fpv_set_rotation.argtypes = [C.c_void_p, C.c_int64]
     h = C.c_void_p(); rc = l.fpv_create(C.byref(cp), n, 0, C.byref(h)); assert rc == 0, l.fpv_last_error()
     L[k], H[k] = l, h
 ld = int(L[names[0]].fpv_recommended_ld(n))
@@ -97,21 +99,24 @@ def reset(k="base"):
         v[:, 2] = 10; v[:, 3] = 1; v[:, 6] = 1
     else:
         st[2] = 10; st[3] = 1; st[6] = 1
-res = {k: [] for k in names}; fin = {}
+res = {(k, rot): [] for k in names for rot in a.rotations}; fin = {}
 e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
 reps = 8 if n <= (1 << 21) else 16
 for r in range(a.rounds):
     for k in names:
-        reset(k); torch.cuda.synchronize(); e0.record()
-        for rep in range(reps):
-            rc = L[k].fpv_rollout(H[k], C.byref(b), ring, n * 4, 0, None); assert rc == 0, L[k].fpv_last_error()
-        e1.record(); torch.cuda.synchronize()
-        if r: res[k].append(e0.elapsed_time(e1) * 1e3 / (reps * ring))
+        for rot in a.rotations:
+            assert L[k].fpv_set_rotation(H[k], rot) == 0
+            reset(k); torch.cuda.synchronize(); e0.record()
+            for rep in range(reps):
+                rc = L[k].fpv_rollout(H[k], C.byref(b), ring, n * 4, 0, None); assert rc == 0, L[k].fpv_last_error()
+            e1.record(); torch.cuda.synchronize()
+            if r: res[(k, rot)].append(e0.elapsed_time(e1) * 1e3 / (reps * ring))
         fin[k] = st.clone()
         if k.startswith("tile"):        # back to rows [14][n] for the comparison with the row layout
             T = int(VARIANTS[k][0].split("=")[1])
             flat = st.reshape(-1)[:(n // T) * 14 * T].view(n // T, 14, T).permute(1, 0, 2).reshape(14, n)
             fin[k] = torch.zeros_like(st); fin[k][:, :n] = flat
 for k in names:
-    med = statistics.median(res[k])
-    print(f"n={n} {k:12s}: median {med:8.3f} us  min {min(res[k]):8.3f} us   {133 * n / med / 1e3:8.1f} GB/s   bitwise==base {bool(torch.equal(fin[k][:, :n], fin[names[0]][:, :n]))}", flush=True)
+    for rot in a.rotations:
+        med = statistics.median(res[(k, rot)])
+        print(f"n={n} {k:12s} rotation {rot:8d}: median {med:8.3f} us  min {min(res[(k, rot)]):8.3f} us   {133 * n / med / 1e3:8.1f} GB/s   bitwise==base {bool(torch.equal(fin[k][:, :n], fin[names[0]][:, :n]))}", flush=True)
