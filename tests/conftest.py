@@ -14,6 +14,18 @@ def pytest_configure(config):
     config.addinivalue_line("markers", "gpu: needs a real MI355X (run with -m gpu on the GPU box)")
 
 
+# Property tests (tests/test_properties.py): the suite that gates a commit draws the SAME examples on every run - a red run is a
+# change in the code, not a draw.  Exploring is a separate, deliberate act: `HYPOTHESIS_PROFILE=explore pytest tests/test_properties.py
+# --hypothesis-seed=N` (round 5 walked seeds 1-120 that way; it found a tie case the decoded-quaternion test had over-asserted).
+try:
+    from hypothesis import settings as _hyp_settings
+    _hyp_settings.register_profile("ci", derandomize=True, database=None)
+    _hyp_settings.register_profile("explore", derandomize=False)
+    _hyp_settings.load_profile(os.environ.get("HYPOTHESIS_PROFILE", "ci"))
+except ImportError:             # hypothesis is optional: test_properties.py skips itself without it
+    pass
+
+
 def load_golden(name):
     with np.load(os.path.join(GOLDEN, name + ".npz"), allow_pickle=False) as z:
         return {k: z[k] for k in z.files}
