@@ -27,9 +27,11 @@ def test_unit_quaternion_finite_state_and_oracle_agreement(a, ypr, v0, steps, fp
     ref = oracle.drone_initial_state(1, [0, 0, 50.0], v0, ypr)
     oracle.drone_run(p, ref, act.astype(np.float64), steps=steps)
     err = soa_vs_oracle(s, ref, 1)
-    # fp32 vs float64 over <= 400 steps from arbitrary attitudes and speeds (the bound of BASELINE's configs, 1e-5, is for their
-    # sticks and horizons; the worst draw of 330 explored seeds - 5.7 s of powered fall at 60 fps, 160 m - reaches 2.03e-5)
-    assert err["pos_rel"] < 4e-5 and err["quat_abs"] < 2e-5, err
+    # fp32 vs float64 over <= 400 steps from arbitrary attitudes and speeds.  Per component with a 1 m floor (`pos_comp`): the
+    # drone starts at (0, 0, 50) and a powered fall takes it THROUGH the origin, where the error relative to |p| (`pos_rel`)
+    # is a division by nearly nothing (seed 209 of the explored ones: 5.6e-5 at |p| = 0.04 m with pos_comp = 2.0e-6)
+    # (the worst of 330 explored seeds: 2.03e-5 after a 5.7 s powered fall of 160 m at 60 fps - BASELINE's 1e-5 is for its configs)
+    assert err["pos_comp"] < 3e-5 and err["quat_abs"] < 2e-5, err
 
 
 @settings(max_examples=25, deadline=None)
