@@ -1431,6 +1431,7 @@ def test_soa_action_layout_equals_row_layout(params_1k):
     torch.cuda.synchronize()
     assert torch.equal(e1.state, e2.state) and torch.equal(e1.reward, e2.reward)
     # closed loop: a linear policy on the zero-copy SoA observation
+    torch.manual_seed(11)
     W = torch.randn(4, 13, device=DEV) * 0.02
     for t in range(50):
         obs_soa = e2.state[:13, :n]                    # [13, n], no copy
@@ -2067,6 +2068,7 @@ def test_reference_scalar_attributes_of_drone(params_1k):
     assert env.mass == float(g["mass"]) and env.gravity == float(g["gravity"]) and env.max_rates == float(g["max_rates"])
     assert env.prev_rates.shape == (7, 3) and env.prev_thrust.shape == (7,)
     # after a rollout `throttle` reports the LAST step's sticks of that rollout, not the step() before it
+    torch.manual_seed(12)
     acts = torch.rand((5, 7, 4), device=DEV) * 2 - 1
     env.rollout(acts)
     assert torch.equal(env.throttle, acts[-1, :, 3])
