@@ -16,6 +16,7 @@ VARIANTS = {
     "ld_nt": ["-DFPV_EXP_LD_NT=1"],
     "st_nt": ["-DFPV_EXP_ST_NT=1"],
     "ld_st_nt": ["-DFPV_EXP_LD_NT=1", "-DFPV_EXP_ST_NT=1"],
+    "st_nt_w7": ["-DFPV_EXP_ST_NT=1", "-DFPV_EXP_STEP_WAVES=7"],
     "st_sys": ["-DFPV_EXP_ST_NT=2"],          # state stores write through and leave L2 (sc0 sc1)
     "st_agent": ["-DFPV_EXP_ST_NT=3"],        # agent-scope stores (sc1)
     "w4": ["-DFPV_EXP_STEP_WAVES=4"], "w5": ["-DFPV_EXP_STEP_WAVES=5"], "w7": ["-DFPV_EXP_STEP_WAVES=7"], "w8": ["-DFPV_EXP_STEP_WAVES=8"], "w44": ["-DFPV_EXP_STEP_WAVES=4,4"], "w55": ["-DFPV_EXP_STEP_WAVES=5,5"], "w33": ["-DFPV_EXP_STEP_WAVES=3,3"],   # occupancy of the step kernel
