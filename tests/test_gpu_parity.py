@@ -2539,3 +2539,44 @@ def test_row_stride_of_half_a_million_drones_spreads_over_the_l2_sets(params_1k)
     assert torch.equal(finals[n + 256], finals[rec])
     t_old, t_rec = sorted(times[n + 256])[1], sorted(times[rec])[1]
     assert t_rec < 0.985 * t_old, (t_rec, t_old)              # measured 0.81 - 0.95
+
+
+def test_handle_lifecycle_does_not_leak(params_1k):
+    """Create - use - destroy, a few hundred times: plain and noise handles, single steps, the k-step kernel, a cached hipGraph and its
+    replay, a partitioned env with its streams, a PID handle.  Device memory outside torch's allocator (the handles' own tables,
+    graphs, events) and the host's resident set must not grow with the count."""
+    import gc
+    import resource
+    from fpyv_amd import sticks
+    from fpyv_amd.env import DroneBatch, FpvVecEnv
+    n = 4096
+    acts = sticks.ema_noise_device(8, n, DEV, seed=1)
+
+    def cycle(k):
+        for i in range(k):
+            e = DroneBatch(params_1k, n, device=DEV, auto_reset=True, stick_noise=(i % 2 == 1), noise_seed=i, with_done_bits=True, track_episodes=True)
+            e.reset()
+            a = None if i % 2 else acts
+            e.step(None if i % 2 else acts[0], return_imu=False)
+            e.rollout(a, steps=8)
+            e.rollout(a, steps=8, graph=True) if i % 2 else e.rollout(acts, graph=True)
+            e.rollout(a, steps=8, graph=True) if i % 2 else e.rollout(acts, graph=True)
+            e.close()
+            if i % 10 == 0:
+                v = FpvVecEnv(params_1k, num_envs=n, device=DEV, partitions=2, auto_reset=True)
+                v.reset()
+                v.step(acts[1])
+                v.close()
+        torch.cuda.synchronize()
+        gc.collect()
+        torch.cuda.empty_cache()
+
+    # the first few hundred lifecycles grow the runtime's own pools once (torch hands out its 32 pooled streams one after the other, and
+    # HIP sets a stream up at its first use: 28 MiB in all); a leak would keep growing - so the SECOND window is the one that counts
+    cycle(40)
+    cycle(160)
+    free1, rss1 = torch.cuda.mem_get_info()[0], resource.getrusage(resource.RUSAGE_SELF).ru_maxrss
+    cycle(160)
+    free2, rss2 = torch.cuda.mem_get_info()[0], resource.getrusage(resource.RUSAGE_SELF).ru_maxrss
+    assert free1 - free2 < (4 << 20), f"device memory shrank by {(free1 - free2) >> 20} MiB over 160 further handle lifecycles"
+    assert rss2 - rss1 < (32 << 10), f"host resident set grew by {(rss2 - rss1) >> 10} MiB over 160 further handle lifecycles"       # ru_maxrss is in KiB
