@@ -325,10 +325,16 @@ __device__ __forceinline__ float4 apply_stick_noise(const FpvK& K, const FpvBufD
 // XCDs (step_grid; up to seven blocks of a launch have no drone and leave at once): workgroups go to the XCDs round-robin, so
 // with a modulus and a start that are multiples of eight every block stays on its XCD across the wrap and across launches -
 // a ragged count would hand each block to another XCD's L2 every launch (1 000 000 drones: no gain from the rotation at all).
+#ifdef FPV_EXP_HEAD      // experiment: both cache tiers at once beyond the Infinity Cache - of the FPV_EXP_ROT blocks a launch finds again, the LAST
+// FPV_EXP_HEAD written (the L2s' share) come first, then the other FPV_EXP_ROT - FPV_EXP_HEAD (Infinity Cache), then the rest; host rotation = FPV_EXP_ROT
+#define FPV_EXP_HEAD_ORDER(b) ((b) < (uint32_t)(FPV_EXP_HEAD) ? (b) + (uint32_t)((FPV_EXP_ROT) - (FPV_EXP_HEAD)) : (b) < (uint32_t)(FPV_EXP_ROT) ? (b) - (uint32_t)(FPV_EXP_HEAD) : (b))
+#else
+#define FPV_EXP_HEAD_ORDER(b) (b)
+#endif
 #define FPV_STEP_INDEX \
     const int64_t n = n_start & 0xffffffffll; \
     const uint32_t nblk_ = (uint32_t)((n + 8 * kStepBlock - 1) / (8 * kStepBlock)) * 8u; \
-    uint32_t blk_ = blockIdx.x + (uint32_t)(n_start >> 32); \
+    uint32_t blk_ = FPV_EXP_HEAD_ORDER(blockIdx.x) + (uint32_t)(n_start >> 32); \
     blk_ = blk_ >= nblk_ ? blk_ - nblk_ : blk_; \
     const uint32_t i = blk_ * (uint32_t)kStepBlock + threadIdx.x
 __device__ __forceinline__ FpvBufD fpv_step_view(const FpvBufD& B_, float* st, int64_t ld, const float4* act, int64_t act_ld, uint16_t* sh)
