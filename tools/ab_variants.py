@@ -13,6 +13,7 @@ OUT = os.path.join(HERE, "_variants")
 sys.path.insert(0, REPO)
 VARIANTS = {
     "base": [],
+    "new": [],            # not built here: a library put into tools/_variants/libfpv_v_new.so by hand (a candidate of the product against the shipped "base")
     "ld_nt": ["-DFPV_EXP_LD_NT=1"],
     "st_nt": ["-DFPV_EXP_ST_NT=1"],
     "ld_st_nt": ["-DFPV_EXP_LD_NT=1", "-DFPV_EXP_ST_NT=1"],
@@ -22,6 +23,7 @@ VARIANTS = {
     "w4": ["-DFPV_EXP_STEP_WAVES=4"], "w5": ["-DFPV_EXP_STEP_WAVES=5"], "w7": ["-DFPV_EXP_STEP_WAVES=7"], "w8": ["-DFPV_EXP_STEP_WAVES=8"], "w44": ["-DFPV_EXP_STEP_WAVES=4,4"], "w55": ["-DFPV_EXP_STEP_WAVES=5,5"], "w33": ["-DFPV_EXP_STEP_WAVES=3,3"],   # occupancy of the step kernel
     "tile256": ["-DFPV_EXP_TILE=256"], "tile512": ["-DFPV_EXP_TILE=512"], "tile1k": ["-DFPV_EXP_TILE=1024"], "tile4k": ["-DFPV_EXP_TILE=4096"], "tile16k": ["-DFPV_EXP_TILE=16384"],   # [n/T][14][T] state (results are the same numbers in another order)
     "b64": ["-DFPV_EXP_BLOCK=64"], "b256": ["-DFPV_EXP_BLOCK=256"],       # drones per workgroup (the rotation's block, the XCD's share of a row: 256 B of 2 KiB / 1 KiB of 8 KiB)
+    "head4k_st_nt": ["-DFPV_EXP_HEAD=4096", "-DFPV_EXP_ROT=32768", "-DFPV_EXP_ST_NT=1"],
     "head4k": ["-DFPV_EXP_HEAD=4096", "-DFPV_EXP_ROT=32768"], "head2k": ["-DFPV_EXP_HEAD=2048", "-DFPV_EXP_ROT=32768"], "head3k": ["-DFPV_EXP_HEAD=3072", "-DFPV_EXP_ROT=32768"],   # with --rotations 4194304 at 2^23 drones
     "rowskew": ["-DFPV_EXP_ROWSKEW=1"],       # per-row offsets of the state matrix from a __constant__ table (tools/rowskew_search.py)
 }
