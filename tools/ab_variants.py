@@ -25,6 +25,7 @@ VARIANTS = {
     "b64": ["-DFPV_EXP_BLOCK=64"], "b256": ["-DFPV_EXP_BLOCK=256"],       # drones per workgroup (the rotation's block, the XCD's share of a row: 256 B of 2 KiB / 1 KiB of 8 KiB)
     "head4k_st_nt": ["-DFPV_EXP_HEAD=4096", "-DFPV_EXP_ROT=32768", "-DFPV_EXP_ST_NT=1"],
     "head4k": ["-DFPV_EXP_HEAD=4096", "-DFPV_EXP_ROT=32768"], "head2k": ["-DFPV_EXP_HEAD=2048", "-DFPV_EXP_ROT=32768"], "head3k": ["-DFPV_EXP_HEAD=3072", "-DFPV_EXP_ROT=32768"],   # with --rotations 4194304 at 2^23 drones
+    "pre12": ["PRELOAD=12"], "pre16": ["PRELOAD=16"], "pre8": ["PRELOAD=8"],       # kernel-argument dwords preloaded into SGPRs (shipped: 6 = state, ld, action; 12 reaches n_start)
     "rowskew": ["-DFPV_EXP_ROWSKEW=1"],       # per-row offsets of the state matrix from a __constant__ table (tools/rowskew_search.py)
 }
 ap = argparse.ArgumentParser()
@@ -41,7 +42,11 @@ if a.build:
         os.makedirs(OUT, exist_ok=True)
         out = os.path.join(OUT, f"libfpv_v_{k}.so")
         from __graft_entry__ import HIPCC_FLAGS
-        subprocess.run(["/opt/rocm/bin/hipcc", *HIPCC_FLAGS, *VARIANTS[k], "-o", out, os.path.join(REPO, "fpyv_amd", "csrc", "fpv_hip.hip")], check=True)
+        flags, extra = list(HIPCC_FLAGS), [f for f in VARIANTS[k] if not f.startswith("PRELOAD=")]
+        for f in VARIANTS[k]:
+            if f.startswith("PRELOAD="):
+                flags = [("-amdgpu-kernarg-preload-count=" + f.split("=")[1]) if x.startswith("-amdgpu-kernarg-preload-count=") else x for x in flags]
+        subprocess.run(["/opt/rocm/bin/hipcc", *flags, *extra, "-o", out, os.path.join(REPO, "fpyv_amd", "csrc", "fpv_hip.hip")], check=True)
         print("built", out)
     sys.exit(0)
 import torch
