@@ -32,6 +32,7 @@ ap.add_argument("--drones", type=int, default=1 << 20)
 ap.add_argument("--steps", type=int, default=2000)
 ap.add_argument("--hidden", type=int, default=0, help="0: linear policy; >0: one hidden layer of this width")
 ap.add_argument("--partitions", type=int, nargs="+", default=[1, 2], help="partition counts to run, one after the other")
+ap.add_argument("--rotation", type=int, default=-1, help="fpv_set_rotation: -1 automatic, 0 plain order, > 0 drones (unpartitioned loop only)")
 a = ap.parse_args()
 dev = torch.device("cuda:0")
 torch.cuda.set_stream(torch.cuda.Stream(device=dev))
@@ -50,6 +51,7 @@ for parts in a.partitions:
     n = env.num_envs
     if env.partitions == 1:
         obs_soa = env.batch.state[:13, :n]                        # [13, N] view of the live state
+        env.batch.set_rotation(a.rotation)
 
         def run(k):
             for _ in range(k):

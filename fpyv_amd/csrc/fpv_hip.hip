@@ -30,6 +30,7 @@
 
 #include "../../include/fpv_abi.h"
 #include "fpv_addr.h"
+#include "fpv_exp.h"
 #include "fpv_derive.h"
 #include "fpv_math.h"
 
@@ -37,10 +38,7 @@ namespace {
 
 constexpr int kBlock = 256;   // reset / pid / diag kernels: 4 wave64 per workgroup
 // step and k-step kernels: 128-thread workgroups (2 wave64), the fastest of 64/128/256/512/1024 in every measurement
-// (profiles/r01_exp10_shapes_clean.log, r02_sweep_geometry.log); -DFPV_EXP_BLOCK=N rebuilds them all for an A/B
-#ifndef FPV_EXP_BLOCK
-#define FPV_EXP_BLOCK 128
-#endif
+// (profiles/r01_exp10_shapes_clean.log, r02_sweep_geometry.log); fpv_exp.h: -DFPV_EXP_BLOCK=N rebuilds them all for an A/B
 constexpr int kStepBlock = FPV_EXP_BLOCK;
 static_assert(kStepBlock % 64 == 0 && kStepBlock >= 64 && kStepBlock <= 1024, "whole wave64s");
 
@@ -85,47 +83,8 @@ __device__ __forceinline__ T& row_at(T* row_base, uint32_t i)
 }
 #define ROW(st, r, ld) ((st) + (int64_t)(r) * (ld))
 
-// ---- experiment hooks (tools/ab_variants.py builds variants with -DFPV_EXP_*; the shipped values are the defaults)
-#ifndef FPV_EXP_LD_NT
-#define FPV_EXP_LD_NT 0
-#endif
-#ifndef FPV_EXP_ST_NT
-#define FPV_EXP_ST_NT 0
-#endif
-#ifndef FPV_EXP_ROWSKEW
-#define FPV_EXP_ROWSKEW 0
-#endif
-#if FPV_EXP_ROWSKEW      // experiment (tools/rowskew_search.py): every state row moved by its own offset (floats), set from the host
-__constant__ int64_t fpv_exp_skew[16];
-extern "C" int fpv_exp_set_skew(const int64_t* skew) { return (int)hipMemcpyToSymbol(HIP_SYMBOL(fpv_exp_skew), skew, sizeof(int64_t) * 16); }
-#define SROW(st, r, ld) ((st) + (int64_t)(r) * (ld) + fpv_exp_skew[(r)])
-#else
-#define SROW(st, r, ld) ROW(st, r, ld)
-#endif
-#ifndef FPV_EXP_TILE
-#define FPV_EXP_TILE 0
-#endif
-#if FPV_EXP_TILE      // experiment (tools/ab_variants.py): the fp32 drone state as tiles [n / T][14][T] instead of rows [14][ld] - a wave's
-#undef SROW           // 14 rows sit within 14 * T * 4 contiguous bytes (n * 14 * 4 < 2^32: n <= 2^26)
-#define SROW(st, r, ld) ((st) + (int64_t)(r) * FPV_EXP_TILE)
-#define TIDX(i) ((((i) / (uint32_t)FPV_EXP_TILE) * (14u * (uint32_t)FPV_EXP_TILE)) + ((i) % (uint32_t)FPV_EXP_TILE))
-#else
-#define TIDX(i) (i)
-#endif
-#if FPV_EXP_LD_NT
-#define LDROW(st, r, ld, i) __builtin_nontemporal_load(&row_at(SROW(st, r, ld), TIDX(i)))
-#else
-#define LDROW(st, r, ld, i) row_at(SROW(st, r, ld), TIDX(i))
-#endif
-#if FPV_EXP_ST_NT == 2       // write-through and drop from L2: global_store ... sc0 sc1
-#define STROW(st, r, ld, i, v) __hip_atomic_store(&row_at(SROW(st, r, ld), TIDX(i)), (v), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM)
-#elif FPV_EXP_ST_NT == 3     // agent scope: sc1
-#define STROW(st, r, ld, i, v) __hip_atomic_store(&row_at(SROW(st, r, ld), TIDX(i)), (v), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)
-#elif FPV_EXP_ST_NT
-#define STROW(st, r, ld, i, v) __builtin_nontemporal_store((v), &row_at(SROW(st, r, ld), TIDX(i)))
-#else
-#define STROW(st, r, ld, i, v) (row_at(SROW(st, r, ld), TIDX(i)) = (v))
-#endif
+#define LDROW(st, r, ld, i) row_at(ROW(st, r, ld), i)
+#define STROW(st, r, ld, i, v) (row_at(ROW(st, r, ld), i) = (v))
 
 __device__ __forceinline__ void ld_drone(const float* __restrict__ st, int64_t ld, uint32_t i, FpvDroneState& s)
 {
@@ -297,11 +256,6 @@ __device__ __forceinline__ float4 apply_stick_noise(const FpvK& K, const FpvBufD
 // matrices arrive in the caller's [n][3][3] layout; this is the closed-loop guidance path, not the headline one.
 // One drone per lane, kStepBlock threads per workgroup: 2 / 4 drones per lane and 256-thread workgroups lost every
 // measurement of rounds 1-2 (profiles/r01_exp10_shapes_clean.log, r02_sweep_geometry.log) and were removed in round 3.
-#ifdef FPV_EXP_STEP_WAVES
-#define FPV_EXP_STEP_ATTR __attribute__((amdgpu_waves_per_eu(FPV_EXP_STEP_WAVES)))
-#else
-#define FPV_EXP_STEP_ATTR
-#endif
 // The single-step kernels take what their FIRST instructions need - the state and action bases, the row stride, n - as
 // plain leading scalars, ahead of the two argument structs.  The library is built with
 // -mllvm -amdgpu-kernarg-preload-count=6 (six leading 8-byte arguments = 12 dwords): on gfx950 the command processor then
@@ -325,16 +279,10 @@ __device__ __forceinline__ float4 apply_stick_noise(const FpvK& K, const FpvBufD
 // XCDs (step_grid; up to seven blocks of a launch have no drone and leave at once): workgroups go to the XCDs round-robin, so
 // with a modulus and a start that are multiples of eight every block stays on its XCD across the wrap and across launches -
 // a ragged count would hand each block to another XCD's L2 every launch (1 000 000 drones: no gain from the rotation at all).
-#ifdef FPV_EXP_HEAD      // experiment: both cache tiers at once beyond the Infinity Cache - of the FPV_EXP_ROT blocks a launch finds again, the LAST
-// FPV_EXP_HEAD written (the L2s' share) come first, then the other FPV_EXP_ROT - FPV_EXP_HEAD (Infinity Cache), then the rest; host rotation = FPV_EXP_ROT
-#define FPV_EXP_HEAD_ORDER(b) ((b) < (uint32_t)(FPV_EXP_HEAD) ? (b) + (uint32_t)((FPV_EXP_ROT) - (FPV_EXP_HEAD)) : (b) < (uint32_t)(FPV_EXP_ROT) ? (b) - (uint32_t)(FPV_EXP_HEAD) : (b))
-#else
-#define FPV_EXP_HEAD_ORDER(b) (b)
-#endif
 #define FPV_STEP_INDEX \
     const int64_t n = n_start & 0xffffffffll; \
     const uint32_t nblk_ = (uint32_t)((n + 8 * kStepBlock - 1) / (8 * kStepBlock)) * 8u; \
-    uint32_t blk_ = FPV_EXP_HEAD_ORDER(blockIdx.x) + (uint32_t)(n_start >> 32); \
+    uint32_t blk_ = blockIdx.x + (uint32_t)(n_start >> 32); \
     blk_ = blk_ >= nblk_ ? blk_ - nblk_ : blk_; \
     const uint32_t i = blk_ * (uint32_t)kStepBlock + threadIdx.x
 __device__ __forceinline__ FpvBufD fpv_step_view(const FpvBufD& B_, float* st, int64_t ld, const float4* act, int64_t act_ld, uint16_t* sh)
@@ -458,22 +406,8 @@ __device__ __forceinline__ const FpvRollArgs& fpv_args_again()
 //   3. the stores.
 // SQ: launched only for the X frame without the ground-spring flag and without objects (choose_rollout_kernel):
 // the quiet steps use the two-height ground flag (fpv_drone_step_lane<.., SQ = true>).
-#ifdef FPV_EXP_ROLL_WAVES
-#define FPV_EXP_ROLL_ATTR __attribute__((amdgpu_waves_per_eu(FPV_EXP_ROLL_WAVES, FPV_EXP_ROLL_WAVES)))
-#else
-#define FPV_EXP_ROLL_ATTR
-#endif
-#ifndef FPV_EXP_QUIET_UNROLL
-#define FPV_EXP_QUIET_UNROLL 2
-#endif
-#ifndef FPV_EXP_VCONST
-#define FPV_EXP_VCONST 0
-#endif
-#ifndef FPV_EXP_PREFETCH2
-#define FPV_EXP_PREFETCH2 0
-#endif
 template <bool NOISE, bool OBJ, bool KAHAN, bool SQ = false>
-__global__ __launch_bounds__(kStepBlock) FPV_EXP_ROLL_ATTR void fpv_drone_rollout_kernel(const FpvRollArgs A)
+__global__ __launch_bounds__(kStepBlock) void fpv_drone_rollout_kernel(const FpvRollArgs A)
 {
     static_assert(!(SQ && OBJ), "the two-height ground flag does not feed the object pass");
     __shared__ FpvNormalRow ntab[NOISE ? FPV_NTAB_ROWS : 1];
@@ -500,21 +434,12 @@ __global__ __launch_bounds__(kStepBlock) FPV_EXP_ROLL_ATTR void fpv_drone_rollou
     if (NOISE) { fpv_settle(ns[0]); fpv_settle(ns[1]); fpv_settle(ns[2]); fpv_settle(ns[3]); }
     if (KAHAN) { for (int c = 0; c < 6; ++c) fpv_settle(kc[c]); }
     float av[4] = {0.f, 0.f, 0.f, 0.f};
-    [[maybe_unused]] float4 a_next2 = a_next;              // (FPV_EXP_PREFETCH2) the action row after the next one
 
     // one step on the view V of the arguments.  QUIET steps take their next action unconditionally (there is always
     // a step t + 1 behind a quiet one; a held action - stride 0 - is simply read again: 16 bytes from the cache)
     auto one_step = [&](const FpvRollArgs& V, const FpvObjects* objs, const float* ap_next, bool prefetch, int t, auto quiet_c) -> FpvStepOut {
         constexpr bool QUIET = decltype(quiet_c)::value;
         av[0] = a_next.x; av[1] = a_next.y; av[2] = a_next.z; av[3] = a_next.w;
-#if FPV_EXP_PREFETCH2
-        // QUIET steps keep TWO action rows in flight: ap_next is the row of step t + 2 (clamped to the last one), the row of
-        // step t + 1 is already here in a_next2.  One row ahead gives a wave ~1.4 us of cover (eight waves share a SIMD, a
-        // step is ~165 instructions each) against an HBM latency of 1-3 us under this load; two rows cover it.
-        if (QUIET) {
-            if (!NOISE || has_action) { a_next = a_next2; a_next2 = ld_action(reinterpret_cast<const float4*>(ap_next), i); }
-        } else
-#endif
         if ((!NOISE || has_action) && (QUIET || prefetch)) a_next = ld_action(reinterpret_cast<const float4*>(ap_next), i);
         if (NOISE) {
             // the Philox round keys are uniform and loop-invariant: left alone the compiler keeps all fourteen words
@@ -547,37 +472,9 @@ __global__ __launch_bounds__(kStepBlock) FPV_EXP_ROLL_ATTR void fpv_drone_rollou
         const int64_t astride = A.R.action_stride;
         unsigned long long* bp = A.R.bits_stride ? A.B.done_bits : nullptr;
         const int64_t bstride = A.R.bits_stride;
-#if FPV_EXP_VCONST
-        // The physics constants of the loop as VECTOR registers.  On gfx950 a VALU instruction with an SGPR source
-        // issues in ~4.2 cycles per SIMD against ~2.4 for the same instruction on two VGPRs (a hand-written issue
-        // probe, profiles/r03_exp_issue_probe.log), and about a quarter of this loop's instructions read
-        // one of these uniforms.  A copy of the arguments whose hot fields went through a "+v" constraint keeps them in
-        // VGPRs for the k steps (one v_mov each, before the loop).
-        FpvRollArgs Q;
-        Q.K = A.K; Q.B.wx = A.B.wx; Q.B.wy = A.B.wy; Q.B.wz = A.B.wz; Q.B.step = A.B.step;
-#define FPV_VREG(x) do { if (!OBJ && !NOISE) asm volatile("" : "+v"(x)); } while (0)
-        FPV_VREG(Q.K.rate_gain); FPV_VREG(Q.K.rate_lim); FPV_VREG(Q.K.omkr); FPV_VREG(Q.K.omkt);
-        FPV_VREG(Q.K.dk3); FPV_VREG(Q.K.dk2); FPV_VREG(Q.K.dk1); FPV_VREG(Q.K.dk0);
-        FPV_VREG(Q.K.inv_mass); FPV_VREG(Q.K.g); FPV_VREG(Q.K.kdrag_m[0]); FPV_VREG(Q.K.kdrag_m[1]); FPV_VREG(Q.K.kdrag_m[2]);
-        FPV_VREG(Q.K.half_k); FPV_VREG(Q.K.dt);
-        if (SQ) FPV_VREG(Q.K.motor_c);
-#undef FPV_VREG
-        const FpvRollArgs& QA = Q;
-#else
-        const FpvRollArgs& QA = A;
-#endif
-#if FPV_EXP_PREFETCH2
-        const float* const ap_last = ap + (int64_t)(k - 1) * astride;             // row of the last step: nothing is read beyond it
-        if (has_action) a_next2 = ld_action(reinterpret_cast<const float4*>(ap + astride), i);     // row of step 1 (k > 1 here)
-        ap += astride;
-#endif
         auto quiet_step = [&]() {
-#if FPV_EXP_PREFETCH2
-            ap = (t + 2 < k) ? ap + astride : ap_last;                            // row of step t + 2, clamped (uniform)
-#else
             ap += astride;
-#endif
-            const FpvStepOut o = one_step(QA, &A.B.objs, ap, true, t, std::true_type{});
+            const FpvStepOut o = one_step(A, &A.B.objs, ap, true, t, std::true_type{});
             if (bp) {
                 const unsigned long long mask = __ballot(o.done);
                 if ((threadIdx.x & 63) == 0) bp[i >> 6] = mask;
@@ -585,13 +482,11 @@ __global__ __launch_bounds__(kStepBlock) FPV_EXP_ROLL_ATTR void fpv_drone_rollou
             }
             ++t;
         };
-#if FPV_EXP_QUIET_UNROLL == 2
         // two steps per trip, written out (the compiler declines `#pragma unroll` on this loop - it holds ballots and
         // opaque asm -, which is why round 3's "unrolled by two" measured nothing): the register allocator can then
         // alternate the loop-carried registers instead of copying five of them back every step (+2 %, one-process A/B)
         // (not with an object list: its per-object uniforms already fill the SGPR file, two copies of the pass spill)
         if constexpr (!OBJ) { while (t + 1 < k - 1) { quiet_step(); quiet_step(); } }
-#endif
         while (t < k - 1) quiet_step();
     }
     // ---- 2. the remaining steps, with every output the caller asked for
@@ -807,9 +702,7 @@ __global__ __launch_bounds__(kStepBlock) void fpv_drone_rollout_h_kernel(const F
             }
             ++t;
         };
-#if FPV_EXP_QUIET_UNROLL == 2
         while (t + 1 < k - 1) { quiet_step(); quiet_step(); }        // two steps per trip (see fpv_drone_rollout_kernel)
-#endif
         while (t < k - 1) quiet_step();
     }
     FpvStepOut o;
@@ -946,9 +839,7 @@ __global__ __launch_bounds__(kStepBlock) void fpv_racer_rollout_kernel(const Fpv
             }
             ++t;
         };
-#if FPV_EXP_QUIET_UNROLL == 2
         while (t + 1 < k - 1) { quiet_step(); quiet_step(); }        // two steps per trip (see fpv_drone_rollout_kernel)
-#endif
         while (t < k - 1) quiet_step();
     }
     {

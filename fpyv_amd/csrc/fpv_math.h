@@ -89,7 +89,7 @@ struct FpvQuat { float w, x, y, z; };
 // NaN included (v_med3 with a NaN operand returns the minimum of the others = lo, and fmaxf(NaN, lo) = lo too).
 FPV_HD float fpv_clamp(float x, float lo, float hi)
 {
-#if defined(__HIP_DEVICE_COMPILE__) && !defined(FPV_EXP_NO_MED3)
+#if defined(__HIP_DEVICE_COMPILE__)
     return __builtin_amdgcn_fmed3f(x, lo, hi);
 #else
     return fminf(fmaxf(x, lo), hi);
@@ -103,7 +103,7 @@ FPV_HD float fpv_clamp(float x, float lo, float hi)
 // the same bits for every normal x, +0 and +inf.
 FPV_HD float fpv_sqrt_flushed(float x)
 {
-#if defined(__HIP_DEVICE_COMPILE__) && !defined(FPV_EXP_LIB_SQRT)
+#if defined(__HIP_DEVICE_COMPILE__)
     const float r = __builtin_amdgcn_sqrtf(x);
     const float r_dn = __uint_as_float(__float_as_uint(r) - 1u), r_up = __uint_as_float(__float_as_uint(r) + 1u);
     const float e_dn = fmaf(-r_dn, r, x), e_up = fmaf(-r_up, r, x);
@@ -174,13 +174,7 @@ FPV_HD void fpv_sincos3(uint32_t mode, float x0, float x1, float x2, float s[3],
         fpv_sincos_small(x0, &s[0], &c[0]); fpv_sincos_small(x1, &s[1], &c[1]); fpv_sincos_small(x2, &s[2], &c[2]);
     } else {
         fpv_sincos_reduced(x0, &s[0], &c[0]);
-#if defined(__HIP_DEVICE_COMPILE__) && defined(FPV_EXP_SERIAL_REDUCED)
-        asm volatile("" : "+v"(x1) : "v"(s[0]), "v"(c[0]));      // experiment: one axis after the other (register pressure of the rare path)
-#endif
         fpv_sincos_reduced(x1, &s[1], &c[1]);
-#if defined(__HIP_DEVICE_COMPILE__) && defined(FPV_EXP_SERIAL_REDUCED)
-        asm volatile("" : "+v"(x2) : "v"(s[1]), "v"(c[1]));
-#endif
         fpv_sincos_reduced(x2, &s[2], &c[2]);
     }
 }

@@ -12,6 +12,8 @@ GOLDEN = os.path.join(REPO, "tests", "golden")
 
 def pytest_configure(config):
     config.addinivalue_line("markers", "gpu: needs a real MI355X (run with -m gpu on the GPU box)")
+    config.addinivalue_line("markers", "gpu_timing: wall-clock ratios on a real MI355X (tests/test_gpu_timing.py); NOT selected by -m gpu - "
+                                       "regression guards with margins no healthy box trips, measured ratios written to JSON")
 
 
 # Property tests (tests/test_properties.py): the suite that gates a commit draws the SAME examples on every run - a red run is a

@@ -2245,27 +2245,22 @@ def test_sharded_example_under_the_launcher_two_ranks_on_one_gpu():
     assert "equals its slice of the unsharded run bit for bit" in r.stdout
 
 
-def test_stream_overlap_probe_and_busy_kernel():
-    """fpyv_amd.streams: the measured choice of the split-phase API's partition streams.  fpv_diag_busy is a kernel of known
-    duration on one CU; two chains of it on ONE stream take twice as long as one chain (ratio ~2), on streams the probe
-    accepted they take as long as one (ratio ~1); the accepted set overlaps pairwise and with the caller's stream."""
-    import time
-    from fpyv_amd.streams import chain_time_ratio, overlapping_streams
+def test_stream_probe_and_busy_kernel_surface():
+    """fpyv_amd.streams: the choice of the split-phase API's partition streams.  fpv_diag_busy is a kernel of known duration on one
+    CU: it refuses durations outside (0, 1000] us, launches on the caller's stream and completes; the probe hands out two distinct
+    streams that are not the caller's.  (How long the busy kernels take and whether the chosen streams overlap are wall-clock
+    questions: tests/test_gpu_timing.py, marker gpu_timing - not part of the parity gate.)"""
+    from fpyv_amd.streams import overlapping_streams
     L = _lib.lib()
     assert L.fpv_diag_busy(0.0, None) == -1 and L.fpv_diag_busy(2000.0, None) == -1 and b"microseconds" in L.fpv_last_error()
     s = torch.cuda.Stream(device=DEV)
-    torch.cuda.synchronize()
-    t0 = time.perf_counter()
     for _ in range(20):
         _lib.check(L.fpv_diag_busy(200.0, s.cuda_stream))
     s.synchronize()
-    took = time.perf_counter() - t0
-    assert 20 * 200e-6 * 0.8 < took < 20 * 200e-6 * 5, f"20 busy kernels of 200 us took {took * 1e3:.2f} ms"
-    assert chain_time_ratio(s, s) > 1.7, "one stream cannot overlap with itself"
     cur = torch.cuda.current_stream(DEV)
     picked, rep = overlapping_streams(DEV, 2, avoid=[cur])
-    assert len(picked) == 2 and rep["verified"] and rep["draws"] >= 2 and picked[0] != picked[1] and cur not in picked
-    assert chain_time_ratio(picked[0], picked[1]) < 1.3 and chain_time_ratio(picked[0], cur) < 1.3
+    assert len(picked) == 2 and picked[0] != picked[1] and cur not in picked
+    assert isinstance(rep["verified"], bool) and rep["draws"] >= 1 and len(rep["ratios"]) >= 1
 
 
 @pytest.mark.parametrize("extra", [[], ["--partitions", "2"], ["--api", "rollout"]], ids=["step", "partitions2", "rollout"])
@@ -2304,7 +2299,8 @@ def test_bench_line_schema_small(extra):
 def test_bench_line_auxiliary_legs_at_the_headline_size():
     """The legs only the full-size line has: `beyond_mall` at 2^23 drones with its three repeats, host enqueue
     time and buffer addresses, and `launch_time_fit` over 3 * 2^18 / 2^20 / 2^21 drones (beyond the L2s, inside the Infinity Cache) with per-leg repeats, host enqueue time
-    and a verdict on its own validity - on a warm GPU the fit must be valid with a floor of a few microseconds."""
+    and a verdict on its own validity: the line must be consistent with that verdict (what the numbers ARE is the bench line's
+    business, not the parity gate's)."""
     import json
     import os
     import subprocess
@@ -2320,8 +2316,7 @@ def test_bench_line_auxiliary_legs_at_the_headline_size():
     assert ro["host_bound"] == (ro["host_enqueue_us"] > 0.9 * ro["avg_launch_us"])
     b = ro["beyond_mall"]
     assert b["drones"] == 1 << 23 and len(b["repeats_us"]) == 3 and b["launches_per_repeat"] == 100 and b["host_enqueue_us"] > 0
-    assert max(b["repeats_us"]) < 1.10 * min(b["repeats_us"]), b["repeats_us"]
-    assert 0.4 < b["frac"] < 1.0 and 0.7 < b["frac_of_copy_ceiling"] < 1.4 and set(b["addresses"])       # (with the rotation: 0.87 - 0.90 of peak, 1.13 - 1.16 x the copy)
+    assert all(t > 0 for t in b["repeats_us"]) and 0.0 < b["frac"] < 1.0 and b["frac_of_copy_ceiling"] > 0 and set(b["addresses"])   # how large: the line itself says (bench.py), no gate
     assert set(b["addresses"]) == {"state", "ld", "action", "reward", "done"}
     lf = ro["launch_time_fit"]
     assert lf["drones"] == [3 << 18, 1 << 20, 1 << 21] and len(lf["legs"]) == 3
@@ -2330,7 +2325,7 @@ def test_bench_line_auxiliary_legs_at_the_headline_size():
     # the fit judges itself: on a warm, quiet GPU it is valid (floor of a few microseconds); a box on which a leg is off the line
     # must say so instead of printing a floor - either way the line is consistent with its own verdict
     if lf["valid"]:
-        assert lf["invalid_reason"] is None and 2.0 < lf["floor_us"] < 7.0 and lf["max_residual_us"] <= 0.5 and 0.7 < lf["streaming_frac_of_peak"] <= 1.0
+        assert lf["invalid_reason"] is None and 0.0 < lf["floor_us"] < ro["sustained"]["avg_launch_us"] and lf["max_residual_us"] <= 0.5 and 0.0 < lf["streaming_frac_of_peak"] <= 1.0
         assert abs(lf["floor_share_of_headline_launch"] - lf["floor_us"] / ro["sustained"]["avg_launch_us"]) < 1e-9
     else:
         assert lf["invalid_reason"] and lf["floor_share_of_headline_launch"] is None
@@ -2400,11 +2395,12 @@ def test_rotation_of_the_traversal_is_bit_identical(params_1k, kind):
     assert int(base.last_length.max()) > 0, "the run must end episodes (auto-reset inside the rotated order too)"
 
 
-def test_rotation_is_automatic_beyond_the_infinity_cache_and_pays(params_1k):
+def test_rotation_is_automatic_beyond_the_l2s_and_beyond_the_infinity_cache(params_1k):
     """The automatic rule (fpv_abi.h): plain order while what one launch writes fits 61/64 of the eight L2s; beyond them the start
     moves back by the L2s' share of drones per launch (2^19 for the plain kernel's 61 B), beyond the 256 MiB Infinity Cache by its
-    share (2^22; fewer with the four noise rows, accel rows, Kahan rows).  At 2^23 drones the rotated chain must be clearly faster than the plain one on the same
-    buffers - measured 155 against 180-200 us - and at 2^20 drones too (20.2 against 22.6 us)."""
+    share (2^22; fewer with the four noise rows, accel rows, Kahan rows).  At 2^23 and at 2^20 drones the automatically rotated
+    chain leaves the same bits as the plain order on the same buffers.  (What the rotation is worth in time:
+    tests/test_gpu_timing.py and bench.py's `beyond_mall.plain_order_avg_launch_us` - not a parity question.)"""
     from fpyv_amd import sticks
     from fpyv_amd.env import DroneBatch
     share = lambda cache, written: cache // 64 * 61 // written // 128 // 8 * 8 * 128      # noqa: E731  (61/64 of the cache, whole rounds of the eight XCDs)
@@ -2424,47 +2420,30 @@ def test_rotation_is_automatic_beyond_the_infinity_cache_and_pays(params_1k):
     del acc
     del noisy
     torch.cuda.empty_cache()
-    n = 1 << 23
-    e = DroneBatch(params_1k.replace(ceiling=100.0), n, device=DEV, auto_reset=True, with_accel=False)
-    assert e.rotation == 1 << 22
-    acts = sticks.ema_noise_device(4, n, DEV, seed=9)
+    for n, ring, want in ((1 << 23, 4, 1 << 22), (1 << 20, 16, 1 << 19)):
+        e = DroneBatch(params_1k.replace(ceiling=100.0), n, device=DEV, auto_reset=True, with_accel=False)
+        assert e.rotation == want
+        acts = sticks.ema_noise_device(ring, n, DEV, seed=9)
 
-    def timed():
-        e.reset()
-        e.rollout(acts, fused=False)
-        torch.cuda.synchronize()
-        out = []
-        for _ in range(3):
-            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-            e0.record()
-            for _ in range(5):
+        def final():
+            e.reset()
+            for _ in range(3):
                 e.rollout(acts, fused=False)
-            e1.record(); torch.cuda.synchronize()
-            out.append(e0.elapsed_time(e1) * 1e3 / 20)
-        return sorted(out)[1], e.state.clone()
+            torch.cuda.synchronize()
+            return e.state.clone()
 
-    t_rot, s_rot = timed()
-    e.set_rotation(0)
-    t_plain, s_plain = timed()
-    assert torch.equal(s_rot, s_plain)
-    assert t_rot < 0.97 * t_plain, (t_rot, t_plain)            # measured 0.78 - 0.87
-    del e, acts, s_rot, s_plain
-    torch.cuda.empty_cache()
-    n = 1 << 20
-    e = DroneBatch(params_1k.replace(ceiling=100.0), n, device=DEV, auto_reset=True, with_accel=False)
-    acts = sticks.ema_noise_device(16, n, DEV, seed=9)
-    t_rot, s_rot = timed()
-    e.set_rotation(0)
-    t_plain, s_plain = timed()
-    assert torch.equal(s_rot, s_plain)
-    assert t_rot < 0.985 * t_plain, (t_rot, t_plain)           # measured 0.89 - 0.90
+        s_rot = final()
+        e.set_rotation(0)
+        assert e.rotation == 0
+        assert torch.equal(s_rot, final())
+        del e, acts, s_rot
+        torch.cuda.empty_cache()
 
 
-def test_ragged_population_keeps_its_blocks_on_their_xcds(params_1k):
-    """1 000 000 drones are 7812.5 blocks of 128: with the block count itself as the modulus of the rotating traversal, every
-    block changed its XCD at each wrap and the L2 share of the rotation was lost (22.3 us with, 22.1 us without the rotation).  The
-    traversal runs over whole rounds of the eight XCDs (7816 blocks, three of them empty): measured 19.4 against 21.6 us.  Same
-    results either way, and equal to the sum of two batches that split the population at a block boundary."""
+def test_ragged_population_runs_in_whole_rounds_of_the_xcds(params_1k):
+    """1 000 000 drones are 7812.5 blocks of 128: the traversal runs over whole rounds of the eight XCDs (7816 blocks, three of
+    them empty) so that a block keeps its XCD across the wrap (profiles/r05_exp_row_stride_l2_sets.log sections 3-4).  Same results
+    as the plain order, and equal to the sum of two batches that split the population at a block boundary."""
     from fpyv_amd import sticks
     from fpyv_amd.env import DroneBatch
     n = 1_000_000
@@ -2473,39 +2452,27 @@ def test_ragged_population_keeps_its_blocks_on_their_xcds(params_1k):
     assert e.rotation == 1 << 19 and e.ld == _lib.lib().fpv_recommended_ld(n) and e.ld % 512 == 256
     acts = sticks.ema_noise_device(16, n, DEV, seed=4)
 
-    def timed():
+    def final():
         e.reset()
         e.rollout(acts, fused=False)
         torch.cuda.synchronize()
-        out = []
-        for _ in range(3):
-            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-            e0.record()
-            for _ in range(5):
-                e.rollout(acts, fused=False)
-            e1.record(); torch.cuda.synchronize()
-            out.append(e0.elapsed_time(e1) * 1e3 / 80)
-        return sorted(out)[1], e.state[:, :n].clone()
+        return e.state[:, :n].clone()
 
-    t_rot, s_rot = timed()
+    s_rot = final()
     e.set_rotation(0)
-    t_plain, s_plain = timed()
-    assert torch.equal(s_rot, s_plain)
-    assert t_rot < 0.96 * t_plain, (t_rot, t_plain)            # measured 0.89 - 0.90
+    assert torch.equal(s_rot, final())
     cut = 499_968                                               # a block boundary: the two halves see the same sticks, drone for drone
     parts = [DroneBatch(p, m, device=DEV, auto_reset=True, with_accel=False) for m in (cut, n - cut)]
     for q, lo in zip(parts, (0, cut)):
         q.reset()
-        for _ in range(16):
-            q.rollout(acts[:, lo:lo + q.n].contiguous(), fused=False)
+        q.rollout(acts[:, lo:lo + q.n].contiguous(), fused=False)
     torch.cuda.synchronize()
     assert torch.equal(torch.cat([q.state[:, :q.n] for q in parts], dim=1), s_rot)
 
 
-def test_row_stride_of_half_a_million_drones_spreads_over_the_l2_sets(params_1k):
-    """2^19 drones with the former pad of 256 floats (row stride 2 MiB + 1 KiB): the rows of a drone block meet in the same L2
-    sets, an XCD keeps a fraction of what it wrote and a launch takes 11.5 - 13.2 us; with the stride of fpv_recommended_ld (2 MiB +
-    1.25 KiB) 10.7 - 10.9 us (profiles/r05_exp_row_stride_l2_sets.log).  Same numbers in the same rows: results do not depend on ld."""
+def test_results_do_not_depend_on_the_row_stride(params_1k):
+    """2^19 drones with the former pad of 256 floats and with the stride of fpv_recommended_ld (2 MiB + 1.25 KiB, chosen by the L2
+    set model: profiles/r05_exp_row_stride_l2_sets.log): the same numbers in the same rows - results do not depend on ld."""
     import ctypes as C
     from fpyv_amd import sticks
     L = _lib.lib()
@@ -2518,27 +2485,19 @@ def test_row_stride_of_half_a_million_drones_spreads_over_the_l2_sets(params_1k)
     acts = sticks.ema_noise_device(32, n, DEV, seed=2)
     rew, done = torch.zeros(n, device=DEV), torch.zeros(n, dtype=torch.uint8, device=DEV)
     big = torch.zeros(14 * (n + 512), device=DEV)
-    times, finals = {}, {}
-    for rnd in range(3):
-        for ld in (n + 256, rec):
-            st = big[:14 * ld].view(14, ld)
-            b = _lib.FpvBuffers()
-            b.state, b.ld, b.reward, b.done, b.action = st.data_ptr(), ld, rew.data_ptr(), done.data_ptr(), acts.data_ptr()
-            big.zero_(); st[2] = 10; st[3] = 1; st[6] = 1
-            assert L.fpv_set_step_counter(h, 0) == 0
+    finals = {}
+    for ld in (n + 256, rec):
+        st = big[:14 * ld].view(14, ld)
+        b = _lib.FpvBuffers()
+        b.state, b.ld, b.reward, b.done, b.action = st.data_ptr(), ld, rew.data_ptr(), done.data_ptr(), acts.data_ptr()
+        big.zero_(); st[2] = 10; st[3] = 1; st[6] = 1
+        assert L.fpv_set_step_counter(h, 0) == 0
+        for _ in range(3):
             assert L.fpv_rollout(h, C.byref(b), 32, n * 4, 0, None) == 0
-            torch.cuda.synchronize()
-            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-            e0.record()
-            for _ in range(8):
-                assert L.fpv_rollout(h, C.byref(b), 32, n * 4, 0, None) == 0
-            e1.record(); torch.cuda.synchronize()
-            times.setdefault(ld, []).append(e0.elapsed_time(e1) * 1e3 / 256)
-            finals[ld] = st[:, :n].clone()
+        torch.cuda.synchronize()
+        finals[ld] = st[:, :n].clone()
     L.fpv_destroy(h)
     assert torch.equal(finals[n + 256], finals[rec])
-    t_old, t_rec = sorted(times[n + 256])[1], sorted(times[rec])[1]
-    assert t_rec < 0.985 * t_old, (t_rec, t_old)              # measured 0.81 - 0.95
 
 
 def test_handle_lifecycle_does_not_leak(params_1k):

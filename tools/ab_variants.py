@@ -1,32 +1,23 @@
 #!/usr/bin/env python3
-"""A/B builds of libfpv_hip.so that differ by -DFPV_EXP_* macros, in ONE process on the SAME buffers,
-interleaved (cdna_hip_programming.md 5.4 rule 24).  Variants are built here (hipcc cross-compiles) by
-`--build`, timed on the GPU box without flags.
+"""A/B builds of libfpv_hip.so that differ by a -DFPV_EXP_* switch (csrc/fpv_exp.h) or a code-generation flag, in ONE process on
+the SAME buffers, interleaved (cdna_hip_programming.md 5.4 rule 24).  Variants are built where they are timed - hipcc is on the
+GPU box too - into gpurun_out/_variants/ (scratch: never pushed, never committed):
 
-    python tools/ab_variants.py --build            # in the build container (libraries land in tools/_variants/, git-ignored)
-    python tools/ab_variants.py [--n 1048576]      # on the GPU box
+    python tools/ab_variants.py --build --only base w4 b256 && python tools/ab_variants.py --only base w4 b256 [--n 1048576]
+
+The switches of rounds 1-5 whose questions are closed (non-temporal hints, tiled state, row skew, two-tier head order,
+VGPR constants, double prefetch) left the sources in round 6; what each measured is in profiles/HISTORY.md.
 """
 import argparse, ctypes as C, os, statistics, subprocess, sys
 HERE = os.path.dirname(os.path.abspath(__file__))
 REPO = os.path.dirname(HERE)
-OUT = os.path.join(HERE, "_variants")
+OUT = os.path.join(REPO, "gpurun_out", "_variants")
 sys.path.insert(0, REPO)
 VARIANTS = {
     "base": [],
-    "new": [],            # not built here: a library put into tools/_variants/libfpv_v_new.so by hand (a candidate of the product against the shipped "base")
-    "ld_nt": ["-DFPV_EXP_LD_NT=1"],
-    "st_nt": ["-DFPV_EXP_ST_NT=1"],
-    "ld_st_nt": ["-DFPV_EXP_LD_NT=1", "-DFPV_EXP_ST_NT=1"],
-    "st_nt_w7": ["-DFPV_EXP_ST_NT=1", "-DFPV_EXP_STEP_WAVES=7"],
-    "st_sys": ["-DFPV_EXP_ST_NT=2"],          # state stores write through and leave L2 (sc0 sc1)
-    "st_agent": ["-DFPV_EXP_ST_NT=3"],        # agent-scope stores (sc1)
     "w4": ["-DFPV_EXP_STEP_WAVES=4"], "w5": ["-DFPV_EXP_STEP_WAVES=5"], "w7": ["-DFPV_EXP_STEP_WAVES=7"], "w8": ["-DFPV_EXP_STEP_WAVES=8"], "w44": ["-DFPV_EXP_STEP_WAVES=4,4"], "w55": ["-DFPV_EXP_STEP_WAVES=5,5"], "w33": ["-DFPV_EXP_STEP_WAVES=3,3"],   # occupancy of the step kernel
-    "tile256": ["-DFPV_EXP_TILE=256"], "tile512": ["-DFPV_EXP_TILE=512"], "tile1k": ["-DFPV_EXP_TILE=1024"], "tile4k": ["-DFPV_EXP_TILE=4096"], "tile16k": ["-DFPV_EXP_TILE=16384"],   # [n/T][14][T] state (results are the same numbers in another order)
     "b64": ["-DFPV_EXP_BLOCK=64"], "b256": ["-DFPV_EXP_BLOCK=256"],       # drones per workgroup (the rotation's block, the XCD's share of a row: 256 B of 2 KiB / 1 KiB of 8 KiB)
-    "head4k_st_nt": ["-DFPV_EXP_HEAD=4096", "-DFPV_EXP_ROT=32768", "-DFPV_EXP_ST_NT=1"],
-    "head4k": ["-DFPV_EXP_HEAD=4096", "-DFPV_EXP_ROT=32768"], "head2k": ["-DFPV_EXP_HEAD=2048", "-DFPV_EXP_ROT=32768"], "head3k": ["-DFPV_EXP_HEAD=3072", "-DFPV_EXP_ROT=32768"],   # with --rotations 4194304 at 2^23 drones
     "pre12": ["PRELOAD=12"], "pre16": ["PRELOAD=16"], "pre8": ["PRELOAD=8"],       # kernel-argument dwords preloaded into SGPRs (shipped: 6 = state, ld, action; 12 reaches n_start)
-    "rowskew": ["-DFPV_EXP_ROWSKEW=1"],       # per-row offsets of the state matrix from a __constant__ table (tools/rowskew_search.py)
 }
 ap = argparse.ArgumentParser()
 ap.add_argument("--build", action="store_true")
@@ -81,11 +72,7 @@ if a.states > 1:
         for k in names:
             ts = []
             for r in range(3):
-                st.zero_()
-                if k.startswith("tile"):
-                    T = int(VARIANTS[k][0].split("=")[1]); v = st.reshape(-1)[:(n // T) * 14 * T].view(n // T, 14, T); v[:, 2] = 10; v[:, 3] = 1; v[:, 6] = 1
-                else:
-                    st[2] = 10; st[3] = 1; st[6] = 1
+                st.zero_(); st[2] = 10; st[3] = 1; st[6] = 1
                 assert L[k].fpv_rollout(H[k], C.byref(b), ring, n * 4, 0, None) == 0
                 torch.cuda.synchronize(); e0.record()
                 for rep in range(6):
@@ -102,13 +89,7 @@ st = torch.zeros((14, ld), device=dev)
 b = _lib.FpvBuffers(); b.state, b.ld, b.reward, b.done = st.data_ptr(), ld, rew.data_ptr(), done.data_ptr()
 b.action = acts.data_ptr()
 def reset(k="base"):
-    st.zero_()
-    if k.startswith("tile"):
-        T = int(VARIANTS[k][0].split("=")[1])
-        v = st.reshape(-1)[:(n // T) * 14 * T].view(n // T, 14, T)
-        v[:, 2] = 10; v[:, 3] = 1; v[:, 6] = 1
-    else:
-        st[2] = 10; st[3] = 1; st[6] = 1
+    st.zero_(); st[2] = 10; st[3] = 1; st[6] = 1
 res = {(k, rot): [] for k in names for rot in a.rotations}; fin = {}
 e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
 reps = 8 if n <= (1 << 21) else 16
@@ -122,10 +103,6 @@ for r in range(a.rounds):
             e1.record(); torch.cuda.synchronize()
             if r: res[(k, rot)].append(e0.elapsed_time(e1) * 1e3 / (reps * ring))
         fin[k] = st.clone()
-        if k.startswith("tile"):        # back to rows [14][n] for the comparison with the row layout
-            T = int(VARIANTS[k][0].split("=")[1])
-            flat = st.reshape(-1)[:(n // T) * 14 * T].view(n // T, 14, T).permute(1, 0, 2).reshape(14, n)
-            fin[k] = torch.zeros_like(st); fin[k][:, :n] = flat
 for k in names:
     for rot in a.rotations:
         med = statistics.median(res[(k, rot)])
