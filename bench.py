@@ -100,6 +100,18 @@ def fit_launch_time(points):
             "max_residual_us": resid, "valid": not why, "invalid_reason": "; ".join(why) or None}
 
 
+def hbm_roofline(value_per_gpu, bytes_per_env_step, drones, steps_per_launch, avg_launch_s):
+    """The two clocks of one line, named.  `achieved` / `frac` FOLLOW `value`: algorithmic bytes per env-step x env-steps/s of one
+    GPU by the wall clock of the whole timed region (barrier to synchronise, the tail after the last launch included) - a reader
+    recomputes them from `value` alone: frac = value / n_gpus x algorithmic_bytes_per_env_step / 1e9 / peak.  `achieved_events` /
+    `frac_events` are the same bytes over the HIP-event time from the first launch's start to the last launch's end
+    (avg_launch_us): the kernel chain without the host's synchronise tail, which is what the rocprofv3 kernel trace sees.  In a
+    2000-step run the two agree within a fraction of a per cent; in the driver's 20-step shape the ~20 us tail is 5 % of the region."""
+    achieved = bytes_per_env_step * value_per_gpu / 1e9
+    achieved_events = bytes_per_env_step * drones * steps_per_launch / avg_launch_s / 1e9
+    return {"achieved": achieved, "frac": achieved / HBM_PEAK_GBS, "achieved_events": achieved_events, "frac_events": achieved_events / HBM_PEAK_GBS}
+
+
 def median(xs):
     xs = sorted(xs)
     m = len(xs) // 2
@@ -1049,7 +1061,8 @@ def main(argv=None):
             bytes_per_step = io + (rw_state + 5) / steps_per_launch
         else:
             bytes_per_step = state_bytes
-        achieved = bytes_per_step * n * steps_per_launch / kernel_s / 1e9
+        rf = hbm_roofline(n * args.steps / elapsed, bytes_per_step, n, steps_per_launch, kernel_s)
+        achieved = rf["achieved"]
         traffic, traffic_src = None, None
         tp = os.path.join(REPO, "profiles", "pmc_traffic.json")
         if os.path.isfile(tp) and not args.fp16_state and not args.racer and args.api == "step" and n == (1 << 20):
@@ -1082,7 +1095,11 @@ def main(argv=None):
                        "parallelism": f"shard{world}" + ("+allgather(done_bits x" + str(args.gather_block) + " steps"
                                                               + (", last_return" if args.gather_returns else "") + ")" if gather is not None else "")},
             "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                         "frac": achieved / HBM_PEAK_GBS, "traffic": traffic, "traffic_source": traffic_src,
+                         "frac": rf["frac"], "achieved_events": rf["achieved_events"], "frac_events": rf["frac_events"],
+                         "frac_formula": "frac = value / n_gpus x algorithmic_bytes_per_env_step / 1e9 / peak (the wall clock of the whole timed region, synchronise tail "
+                                         "included - the same clock as `value` and `ms_per_step`); frac_events = algorithmic bytes per launch / avg_launch_us / peak (HIP events, "
+                                         "first launch to last launch - the clock of the rocprofv3 kernel trace)",
+                         "traffic": traffic, "traffic_source": traffic_src,
                          "traffic_note": ("the counter passes serialise the launches and the L2s do not keep their lines from one to the next there (profiles/pmc_traffic.json: "
                                           "pmc_pass_step_kernel_avg_ns against kernel_trace_avg_ns): `traffic` is what a launch with COLD L2s asks the memory side for - its "
                                           "algorithmic bytes; in the running chain the rotation lets the L2s answer a part of the state reads, which no counter pass can watch "
@@ -1092,14 +1109,18 @@ def main(argv=None):
                          "host_enqueue_us": host_enqueue_s * 1e6 / max(k_host, 1) * steps_per_launch,
                          "host_enqueue_over": f"the first {k_host} steps of the timed region (before the hardware queue can fill)",
                          "host_bound": bool(host_enqueue_s / max(k_host, 1) > 0.9 * dev_ms * 1e-3 / args.steps),
-                         "cache_note": "at 2^20 drones the 59 MB state is re-read from the 256 MiB Infinity Cache (MALL) every step - and, with the rotation of the "
+                         "cache_note": "this line is a STEP-ONLY chain (sticks from a pre-generated ring: BASELINE configs[2] is a noise profile, not a policy). At 2^20 drones "
+                                       "the 59 MB state is re-read from the 256 MiB Infinity Cache (MALL) every step - and, with the rotation of the "
                                        "traversal (config.rotation_drones: each launch starts on the rows the previous one wrote last), about half of it from the L2s; "
                                        "only the action stream and reward/done cross HBM - `beyond_mall` is the same kernel at 2^23 drones, where the traversal rotates so that "
-                                       "each launch starts on what the cache still holds",
+                                       "each launch starts on what the cache still holds. With another kernel's pass over the state between two steps (a policy: action -> step -> "
+                                       "action) the caches hold what THAT kernel touched last and the rotation is neutral - measured: profiles/r06_closed_loop.md (step kernel "
+                                       "21.7 us inside the loop with or without it at 2^20 drones)",
                          "frac_beyond_mall": beyond["frac"] if beyond else None, "beyond_mall": beyond,
                          "sustained": sustained,
                          "launch_time_fit": None,
-                         "note": "avg = HIP-event time over the timed region / launches (includes inter-launch gaps)"},
+                         "note": "avg_launch_us = HIP-event time over the timed region / launches (includes inter-launch gaps); achieved / frac follow `value` "
+                                 "(wall clock), achieved_events / frac_events follow avg_launch_us - see frac_formula"},
         }
         if venv is not None:
             out["roofline"]["note"] = (f"split phase: one step = {venv.partitions} launches on {venv.partitions} streams that overlap; avg_launch_us is the "
@@ -1122,7 +1143,7 @@ def main(argv=None):
             # profiles/pmc_valu.json) and are used ONLY for the configuration they were measured on - same kernel sources
             # (hash), same kernel family, same steps per launch, quiet steps (no per-step mask rows) - otherwise the line
             # says so instead of quoting a stale count
-            out["roofline"]["hbm_view"] = {k: out["roofline"][k] for k in ("achieved", "peak", "unit", "frac")}
+            out["roofline"]["hbm_view"] = {k: out["roofline"][k] for k in ("achieved", "peak", "unit", "frac", "achieved_events", "frac_events")}
             valu, why = None, None
             vp = os.path.join(REPO, "profiles", "pmc_valu.json")
             fam = "racer" if args.racer else "fp16" if args.fp16_state else "f32"
@@ -1139,10 +1160,12 @@ def main(argv=None):
                     why = "profiles/pmc_valu.json holds no count for this configuration (kernel family / steps per launch / per-step mask rows)"
                 else:
                     inst = ent["valu_per_wave"] / ent["steps_per_launch"]
-                    rate = inst * n * steps_per_launch / kernel_s / 1e9
+                    rate = inst * n * args.steps / elapsed / 1e9                          # follows `value` (wall clock), like the HBM view
+                    rate_ev = inst * n * steps_per_launch / kernel_s / 1e9                # HIP events
                     valu = {"valu_inst_per_env_step": inst, "salu_inst_per_env_step": ent.get("salu_per_wave", 0) / ent["steps_per_launch"],
                             "source": vj.get("source"), "kernel": ent.get("kernel"),
-                            "achieved_Glane_inst_per_s": rate, "peak_Glane_inst_per_s": VALU_PEAK_GINST, "frac": rate / VALU_PEAK_GINST}
+                            "achieved_Glane_inst_per_s": rate, "peak_Glane_inst_per_s": VALU_PEAK_GINST, "frac": rate / VALU_PEAK_GINST,
+                            "achieved_events_Glane_inst_per_s": rate_ev, "frac_events": rate_ev / VALU_PEAK_GINST}
             out["roofline"]["valu"] = valu
             out["roofline"]["valu_unavailable"] = why
             if valu is not None:
@@ -1150,7 +1173,10 @@ def main(argv=None):
                 # one the line keeps bound = "hbm" and its algorithmic-bytes figures (an HBM fraction labelled as a VALU
                 # bound would be a number about nothing)
                 out["roofline"].update(bound="valu", achieved=valu["achieved_Glane_inst_per_s"], peak=VALU_PEAK_GINST,
-                                       unit="G lane-instructions/s", frac=valu["frac"])
+                                       unit="G lane-instructions/s", frac=valu["frac"], achieved_events=valu["achieved_events_Glane_inst_per_s"],
+                                       frac_events=valu["frac_events"],
+                                       frac_formula="frac = value / n_gpus x valu.valu_inst_per_env_step / 1e9 / peak (wall clock, the clock of `value`); frac_events: the same "
+                                                    "instructions over avg_launch_us (HIP events)")
                 out["roofline"]["note"] = ("bound = vector-ALU issue (256 CUs x 4 SIMD-32 x 2.4 GHz = 78.6 T lane-instructions/s); "
                                            "`hbm_view` keeps the algorithmic-bytes figures of the same run; " + out["roofline"]["note"])
             else:

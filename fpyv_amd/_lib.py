@@ -13,7 +13,7 @@ from typing import Optional
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, "libfpv_hip.so")
 
-FPV_ABI_VERSION = 7
+FPV_ABI_VERSION = 8
 FPV_OK = 0
 FPV_MODE_DRONE, FPV_MODE_RACER = 0, 1
 FPV_DRONE_ROWS, FPV_RACER_ROWS = 14, 29
@@ -32,9 +32,10 @@ R_OMEGA, R_IERR, R_LERR, R_FIRST, R_OMEGA_LO, R_IERR_LO, R_DFILT = 10, 13, 16, 1
 # every symbol include/fpv_abi.h declares
 EXPORTS = ("fpv_abi_version", "fpv_sizeof", "fpv_state_rows", "fpv_algorithmic_bytes", "fpv_handle_algorithmic_bytes", "fpv_create", "fpv_destroy",
            "fpv_reset", "fpv_step", "fpv_rollout", "fpv_step_n", "fpv_rollout_graph", "fpv_return_triple", "fpv_widen_state", "fpv_set_params", "fpv_set_step_counter", "fpv_get_step_counter", "fpv_set_rotation", "fpv_get_rotation", "fpv_recommended_ld",
+           "fpv_recommended_ld_device", "fpv_check_cache_model", "fpv_device_cache_model", "fpv_get_cache_model",
            "fpv_diag_stream_copy", "fpv_diag_stream_copy_wide", "fpv_diag_busy", "fpv_pid_reset", "fpv_pid_call", "fpv_comm_unique_id", "fpv_comm_create", "fpv_comm_destroy", "fpv_comm_info",
            "fpv_allgather_done", "fpv_allgather_f32", "fpv_last_error",
-           "fpv_error_name")
+           "fpv_error_name", "fpv_encoding_id")
 
 
 class FpvParams(C.Structure):
@@ -147,6 +148,17 @@ def pack_params(p, auto_reset: bool = False, fp16_state: bool = False, stick_noi
     return s
 
 
+class FpvCacheModel(C.Structure):
+    """fpv_cache_model_t: what a device says about itself, held against the cache model of the rotation / row stride."""
+    _fields_ = [("struct_size", C.c_uint32), ("matches", C.c_int32), ("compute_units", C.c_int32), ("xcds", C.c_int32),
+                ("l2_bytes_per_xcd", C.c_int64), ("infinity_cache_bytes", C.c_int64), ("arch", C.c_char * 64), ("reason", C.c_char * 256)]
+
+    def as_dict(self):
+        return {"matches": bool(self.matches), "arch": self.arch.decode(), "compute_units": int(self.compute_units), "xcds": int(self.xcds),
+                "l2_bytes_per_xcd": int(self.l2_bytes_per_xcd), "infinity_cache_bytes": int(self.infinity_cache_bytes),
+                "reason": self.reason.decode() or None}
+
+
 class FpvError(RuntimeError):
     def __init__(self, code: int, name: str, msg: str):
         super().__init__(f"{name} ({code}): {msg}")
@@ -190,6 +202,11 @@ def lib() -> C.CDLL:
     L.fpv_get_rotation.argtypes = [vp, C.POINTER(C.c_int64)]
     L.fpv_recommended_ld.argtypes = [i64]
     L.fpv_recommended_ld.restype = i64
+    L.fpv_recommended_ld_device.argtypes = [i64, C.c_int]
+    L.fpv_recommended_ld_device.restype = i64
+    L.fpv_check_cache_model.argtypes = [C.c_char_p, C.c_int, i64, C.POINTER(FpvCacheModel)]
+    L.fpv_device_cache_model.argtypes = [C.c_int, C.POINTER(FpvCacheModel)]
+    L.fpv_get_cache_model.argtypes = [vp, C.POINTER(FpvCacheModel)]
     L.fpv_diag_stream_copy.argtypes = [vp, vp, i64, vp]
     L.fpv_diag_stream_copy_wide.argtypes = [vp, vp, i64, vp]
     L.fpv_diag_busy.argtypes = [C.c_double, vp]
@@ -205,11 +222,13 @@ def lib() -> C.CDLL:
     L.fpv_last_error.restype = C.c_char_p
     L.fpv_error_name.argtypes = [C.c_int]
     L.fpv_error_name.restype = C.c_char_p
+    L.fpv_encoding_id.argtypes = [C.c_int]
+    L.fpv_encoding_id.restype = C.c_char_p
     L.fpv_sizeof.argtypes = [C.c_int]
     if L.fpv_abi_version() != FPV_ABI_VERSION:
         raise ImportError(f"libfpv_hip.so ABI {L.fpv_abi_version()} != binding {FPV_ABI_VERSION} - rebuild the library "
                           "(`python -c 'import __graft_entry__ as g; g.build()'`)")
-    for which, struct in ((0, FpvParams), (1, FpvBuffers), (2, FpvObjects), (3, FpvPidParams)):
+    for which, struct in ((0, FpvParams), (1, FpvBuffers), (2, FpvObjects), (3, FpvPidParams), (4, FpvCacheModel)):
         if L.fpv_sizeof(which) != C.sizeof(struct):
             raise ImportError(f"{struct.__name__}: ctypes declares {C.sizeof(struct)} bytes, libfpv_hip.so has "
                               f"{L.fpv_sizeof(which)} - _lib.py and include/fpv_abi.h are out of step")

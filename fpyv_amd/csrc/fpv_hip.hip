@@ -18,6 +18,7 @@
 #include <dlfcn.h>
 #include <math.h>
 #include <stdint.h>
+#include <stdio.h>
 #include <stdlib.h>
 #include <string.h>
 
@@ -1033,6 +1034,9 @@ struct fpv_env {
     // rotation of the single-step kernels' start block (FPV_STEP_INDEX): blocks the start moves back per launch
     // (0 = plain order), where the next launch starts, and what the caller asked for (fpv_set_rotation: -1 = automatic)
     int64_t rot_blocks = 0, start_block = 0, rot_request = -1;
+    // what the device said about itself at fpv_create, held against the cache model the rotation and the row stride are built on
+    // (device_cache_model): a device that is not the one the model was measured on gets the plain order
+    fpv_cache_model_t cache;
     // cached hipGraph of the last fpv_rollout_graph call (launch-bound small batches): rebuilt when the
     // SHAPE key changes, re-pointed node by node when only buffer addresses change
     hipGraph_t graph = nullptr;
@@ -1160,7 +1164,7 @@ struct DeviceGuard {
 
 // ---- kernel selection: every step kernel has the signature FPV_STEP_PARAMS ------------------------------
 typedef void (*StepKernel)(float*, const int64_t, const float4*, const int64_t, uint16_t*, const int64_t, const FpvK, const FpvBufD);
-struct KernelChoice { StepKernel func; unsigned grid, block; bool rotates; };
+struct KernelChoice { StepKernel func; unsigned grid, block; };
 // blocks of one single-step launch: n's, in whole rounds of the eight XCDs (FPV_STEP_INDEX computes the same number from n)
 inline int64_t step_grid(int64_t n) { return (n + 8 * kStepBlock - 1) / (8 * kStepBlock) * 8; }
 
@@ -1220,7 +1224,6 @@ KernelChoice choose_kernel(const fpv_env* h, const FpvBufD& d)
 {
     KernelChoice c;
     c.block = (unsigned)kStepBlock;
-    c.rotates = false;
     if (h->mode != FPV_MODE_DRONE) {
         c.func = racer_kernel(h->K.r_wide != 0, h->K.r_pid_variant != 0);
     } else if (h->K.flags & FPV_FLAG_FP16_STATE) {
@@ -1234,8 +1237,7 @@ KernelChoice choose_kernel(const fpv_env* h, const FpvBufD& d)
         else
             c.func = drone_kernel(noise, obj, kahan);
     }
-    c.rotates = true;                       // every single-step kernel reads n and the start block from one argument (FPV_STEP_INDEX)
-    c.grid = (unsigned)step_grid(h->n);
+    c.grid = (unsigned)step_grid(h->n);      // every single-step kernel - drone, fp16 state, AoS head, Racer - reads n and the start block from one argument (FPV_STEP_INDEX)
     return c;
 }
 
@@ -1248,12 +1250,12 @@ int launch_step(fpv_env* h, const FpvBufD& d_in, hipStream_t s)
     const KernelChoice c = choose_kernel(h, d);
     const int64_t nblk = (int64_t)c.grid;
     h->rot_blocks = rotation_blocks(h, &d);
-    const int64_t start = (c.rotates && h->rot_blocks > 0) ? h->start_block % nblk : 0;
+    const int64_t start = h->rot_blocks > 0 ? h->start_block % nblk : 0;
     hipLaunchKernelGGL(c.func, dim3(c.grid), dim3(c.block), 0, s, d.state, d.ld, d.action, d.action_ld, d.state_h, h->n | (start << 32), h->K, d);
     const hipError_t e = hipGetLastError();
     if (e != hipSuccess) return hip_fail(e, "step kernel launch");
     ++h->launches;                     // a refused launch leaves the step index where it was
-    if (c.rotates && h->rot_blocks > 0) h->start_block = (start + nblk - h->rot_blocks % nblk) % nblk;
+    if (h->rot_blocks > 0) h->start_block = (start + nblk - h->rot_blocks % nblk) % nblk;
     return FPV_OK;
 }
 
@@ -1267,8 +1269,58 @@ int launch_step(fpv_env* h, const FpvBufD& d_in, hipStream_t s)
 //   more than the Infinity Cache                    61/64 * 256 MiB / written bytes per drone  (2^22 drones)
 // Measured (profiles/r05_exp_rotation_step_sweep.log): at 2^23 drones the launch time is flat from 30 000 to 35 000 blocks of 128 drones
 // and 7 % worse at 36 000; at 2^20 drones it falls from 22.7 us (plain) to 20.2 us at 4096 blocks and is back at 21.9 us at 5120.
+constexpr int kModelXcds = 8, kModelComputeUnits = 256;
+constexpr int64_t kModelL2BytesPerXcd = (int64_t)4 << 20;
 constexpr int64_t kInfinityCacheBytes = (int64_t)256 << 20;
-constexpr int64_t kL2Bytes = (int64_t)8 * (4 << 20);
+constexpr int64_t kL2Bytes = (int64_t)kModelXcds * kModelL2BytesPerXcd;
+
+// The rotation (block -> XCD round-robin over EIGHT XCDs, 8 x 4 MiB of L2, 256 MiB of Infinity Cache) and the row-stride rule (an
+// L2 set hash fitted on this silicon) are a model of ONE device: gfx950 in its single-partition mode, 256 compute units.  HIP says
+// which architecture a device is, how many compute units the process sees and how large ONE L2 is; it does not say how many XCDs
+// there are or how large the Infinity Cache is - those follow from "gfx950 with all 256 CUs" (a CPX / DPX / QPX compute partition
+// shows 32 / 128 / 64 CUs and one, four or two L2s: other rounds, another share).  Anything else gets the plain order and the
+// conservative stride: results are the same bits either way, only the traversal's cache reuse is at stake.
+void check_cache_model(const char* arch, int compute_units, int64_t l2_bytes, fpv_cache_model_t* m)
+{
+    memset(m, 0, sizeof(*m));
+    m->struct_size = (uint32_t)sizeof(*m);
+    m->compute_units = compute_units;
+    m->l2_bytes_per_xcd = l2_bytes;
+    snprintf(m->arch, sizeof(m->arch), "%s", arch ? arch : "");
+    std::string why;
+    if (strncmp(m->arch, "gfx950", 6) != 0 || (m->arch[6] != '\0' && m->arch[6] != ':'))
+        why = std::string("architecture '") + m->arch + "' is not gfx950";
+    else if (compute_units != kModelComputeUnits)
+        why = "the process sees " + std::to_string(compute_units) + " compute units, not " + std::to_string(kModelComputeUnits)
+              + " (a compute partition of the chip? the model is eight XCDs of 32 CUs in single-partition mode)";
+    else if (l2_bytes != 0 && l2_bytes != kModelL2BytesPerXcd)          // 0 = the runtime does not report it: architecture and CU count pin the silicon
+        why = "the device reports an L2 of " + std::to_string(l2_bytes) + " bytes, not " + std::to_string(kModelL2BytesPerXcd);
+    if (why.empty()) {
+        m->matches = 1; m->xcds = kModelXcds; m->infinity_cache_bytes = kInfinityCacheBytes;
+    } else {
+        why += ": plain traversal order and the conservative row stride (same results; no cache-aware rotation)";
+        snprintf(m->reason, sizeof(m->reason), "%s", why.c_str());
+    }
+}
+
+// asked once per device and process (hipGetDeviceProperties is a millisecond, fpv_create may be called hundreds of times)
+int device_cache_model(int device, fpv_cache_model_t* out)
+{
+    static std::mutex mu;
+    static std::vector<std::pair<int, fpv_cache_model_t>> known;
+    {
+        const std::lock_guard<std::mutex> lock(mu);
+        for (const auto& k : known)
+            if (k.first == device) { *out = k.second; return FPV_OK; }
+    }
+    hipDeviceProp_t prop;
+    const hipError_t e = hipGetDeviceProperties(&prop, device);
+    if (e != hipSuccess) return hip_fail(e, "hipGetDeviceProperties");
+    check_cache_model(prop.gcnArchName, prop.multiProcessorCount, (int64_t)prop.l2CacheSize, out);
+    const std::lock_guard<std::mutex> lock(mu);
+    known.emplace_back(device, *out);
+    return FPV_OK;
+}
 
 // Bytes per drone that one launch WRITES: what fills a cache between two visits of a drone (reads of rows that are written back
 // are the same lines; the stick rows are streamed with a non-temporal hint).  The plain kernel: 14 rows + reward + done = 61 B,
@@ -1299,6 +1351,7 @@ int64_t rotation_blocks(const fpv_env* h, const FpvBufD* d)
 {
     const int64_t nblk = step_grid(h->n);
     if (h->rot_request >= 0) return (h->rot_request / kStepBlock) % (nblk > 0 ? nblk : 1);
+    if (!h->cache.matches) return 0;             // not the device the model was measured on: plain order (fpv_get_cache_model says why)
     const int64_t bytes = written_bytes_per_drone(h, d);
     const int64_t fit_mall = kInfinityCacheBytes / 64 * 61 / bytes / kStepBlock / 8 * 8;
     const int64_t fit_l2 = kL2Bytes / 64 * 61 / bytes / kStepBlock / 8 * 8;
@@ -1349,8 +1402,29 @@ int64_t graph_n_start(const fpv_env* h, const KernelChoice& c, const FpvBufD& d,
 {
     const int64_t nblk = (int64_t)c.grid;
     const int64_t rot = rotation_blocks(h, &d);
-    const int64_t start = (c.rotates && rot > 0) ? (int64_t)(((uint64_t)t * (uint64_t)(nblk - rot % nblk)) % (uint64_t)nblk) : 0;
+    const int64_t start = rot > 0 ? (int64_t)(((uint64_t)t * (uint64_t)(nblk - rot % nblk)) % (uint64_t)nblk) : 0;
     return h->n | (start << 32);
+}
+
+// The row stride that needs no model of the caches: n rounded up to 64 floats and kept at least 1 KiB past a multiple of 8 KiB.
+// 14 rows whose stride is (nearly) a multiple of 8 KiB land on the same HBM channel/bank set: measured at 2^20 drones, stride mod
+// 8 KiB = 0 costs 6-9 %, 256-448 B still 2-3 %, 1-4 KiB nothing.
+int64_t conservative_ld(int64_t n)
+{
+    int64_t ld = (n + 63) / 64 * 64;
+    const int64_t r = ld % 2048;
+    if (r < 256) ld += 256 - r;
+    return ld;
+}
+
+int check_device_index(int device)
+{
+    int count = 0;
+    const hipError_t e = hipGetDeviceCount(&count);
+    if (e != hipSuccess || count <= 0)
+        return fail(FPV_ENODEV, std::string("no HIP device available: ") + (e != hipSuccess ? hipGetErrorString(e) : "device count is 0"));
+    if (device < 0 || device >= count) return fail(FPV_ENODEV, "device index out of range");
+    return FPV_OK;
 }
 
 }  // namespace
@@ -1366,7 +1440,8 @@ int fpv_sizeof(int which)
         case 1: return (int)sizeof(fpv_buffers_t);
         case 2: return (int)sizeof(fpv_objects_t);
         case 3: return (int)sizeof(fpv_pid_params_t);
-        default: return fail(FPV_EINVAL, "fpv_sizeof: 0 = fpv_params_t, 1 = fpv_buffers_t, 2 = fpv_objects_t, 3 = fpv_pid_params_t");
+        case 4: return (int)sizeof(fpv_cache_model_t);
+        default: return fail(FPV_EINVAL, "fpv_sizeof: 0 = fpv_params_t, 1 = fpv_buffers_t, 2 = fpv_objects_t, 3 = fpv_pid_params_t, 4 = fpv_cache_model_t");
     }
 }
 
@@ -1403,11 +1478,8 @@ int fpv_create(const fpv_params_t* params, int64_t n, int device, fpv_handle_t* 
     *out = nullptr;
     if (n <= 0) return fail(FPV_EINVAL, "n must be positive");
     if (n > FPV_MAX_DRONES) return fail(FPV_EINVAL, "n exceeds 2^28 drones per handle (32-bit lane byte offsets into 16-byte action rows); split the population over handles");
-    int count = 0;
-    hipError_t e = hipGetDeviceCount(&count);
-    if (e != hipSuccess || count <= 0)
-        return fail(FPV_ENODEV, std::string("no HIP device available: ") + (e != hipSuccess ? hipGetErrorString(e) : "device count is 0"));
-    if (device < 0 || device >= count) return fail(FPV_ENODEV, "device index out of range");
+    const int drc = check_device_index(device);
+    if (drc != FPV_OK) return drc;
     FpvK K;
     const char* why = "";
     const int rc = fpv_derive_constants(params, &K, &why);
@@ -1416,6 +1488,8 @@ int fpv_create(const fpv_params_t* params, int64_t n, int device, fpv_handle_t* 
     if (!h) return fail(FPV_EINVAL, "out of host memory");
     h->K = K; h->P = *params; h->n = n; h->device = device; h->mode = (int)params->mode;
     h->launches = 0;
+    const int mrc = device_cache_model(device, &h->cache);
+    if (mrc != FPV_OK) { delete h; return mrc; }
     update_rotation(h);
     *out = h;
     return FPV_OK;
@@ -1457,6 +1531,30 @@ int fpv_get_rotation(fpv_handle_t h, int64_t* drones)
 {
     if (!h || !drones) return fail(FPV_EINVAL, "null argument");
     *drones = h->rot_blocks * kStepBlock;
+    // the plain order because the device is not the model's: the reason is the call's message (the call itself succeeds)
+    if (h->rot_request < 0 && !h->cache.matches) g_err = h->cache.reason;
+    return FPV_OK;
+}
+
+int fpv_check_cache_model(const char* arch, int compute_units, int64_t l2_bytes_per_xcd, fpv_cache_model_t* out)
+{
+    if (!arch || !out) return fail(FPV_EINVAL, "null argument");
+    check_cache_model(arch, compute_units, l2_bytes_per_xcd, out);
+    return FPV_OK;
+}
+
+int fpv_device_cache_model(int device, fpv_cache_model_t* out)
+{
+    if (!out) return fail(FPV_EINVAL, "null argument");
+    const int rc = check_device_index(device);
+    if (rc != FPV_OK) return rc;
+    return device_cache_model(device, out);
+}
+
+int fpv_get_cache_model(fpv_handle_t h, fpv_cache_model_t* out)
+{
+    if (!h || !out) return fail(FPV_EINVAL, "null argument");
+    *out = h->cache;
     return FPV_OK;
 }
 
@@ -1474,15 +1572,19 @@ int fpv_get_step_counter(fpv_handle_t h, uint64_t* step)
     return FPV_OK;
 }
 
+int64_t fpv_recommended_ld_device(int64_t n, int device)
+{
+    if (n <= 0) return fail(FPV_EINVAL, "n must be positive");
+    fpv_cache_model_t m;
+    const int rc = fpv_device_cache_model(device, &m);
+    if (rc != FPV_OK) return rc;
+    return m.matches ? fpv_recommended_ld(n) : conservative_ld(n);
+}
+
 int64_t fpv_recommended_ld(int64_t n)
 {
     if (n <= 0) return fail(FPV_EINVAL, "n must be positive");
-    int64_t ld = (n + 63) / 64 * 64;
-    // 14 rows whose stride is (nearly) a multiple of 8 KiB land on the same HBM channel/bank set:
-    // measured at 2^20 drones, stride mod 8 KiB = 0 costs 6-9 %, 256-448 B still 2-3 %, 1-4 KiB nothing.
-    // Keep the stride at least 1 KiB past a multiple of 8 KiB.
-    const int64_t r = ld % 2048;
-    if (r < 256) ld += 256 - r;
+    int64_t ld = conservative_ld(n);
     if (n <= kL2ModelFromDrones) return ld;
     // Larger populations: a stride of 1 KiB past a multiple of 2 KiB (ld = 256 mod 512 floats) is the best or within 1 % of the
     // best of the eight 256-byte classes at every size measured from 2^18 to 2^23 drones, ragged ones included (2 000 000 drones:
@@ -1753,18 +1855,6 @@ int fpv_return_triple(fpv_handle_t h, const fpv_buffers_t* b, float* rt, float* 
     return FPV_OK;
 }
 
-namespace {
-int check_device_index(int device)
-{
-    int count = 0;
-    const hipError_t e = hipGetDeviceCount(&count);
-    if (e != hipSuccess || count <= 0)
-        return fail(FPV_ENODEV, std::string("no HIP device available: ") + (e != hipSuccess ? hipGetErrorString(e) : "device count is 0"));
-    if (device < 0 || device >= count) return fail(FPV_ENODEV, "device index out of range");
-    return FPV_OK;
-}
-}  // namespace
-
 int fpv_pid_reset(float* pid_state, int64_t ld, int64_t n, const uint8_t* mask, int device, void* stream)
 {
     if (!pid_state) return fail(FPV_EINVAL, "pid_state is null");
@@ -1952,6 +2042,11 @@ int fpv_allgather_f32(fpv_comm_t c, const float* send, float* recv, int64_t coun
 }
 
 const char* fpv_last_error(void) { return g_err.c_str(); }
+
+const char* fpv_encoding_id(int which)
+{
+    return which == 0 ? FPV_STATE_H_ENCODING_ID : which == 1 ? FPV_NOISE_GENERATOR_ID : nullptr;
+}
 
 const char* fpv_error_name(int code)
 {

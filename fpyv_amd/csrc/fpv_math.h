@@ -436,6 +436,9 @@ FPV_HD uint32_t fpv_q3_field(float a, uint32_t rnd8)
     return (uint32_t)n & 0x7fffu;
 }
 
+// what the eleven words mean, as a checkpoint records it (fpv_encoding_id(0); fpyv_amd/env.py STATE_H_ENCODING): change the
+// encoding below and this string changes with it
+#define FPV_STATE_H_ENCODING_ID "abi5: v f16+5-bit low words, q smallest-three 15-bit fixed point, rates/thrust f16"
 FPV_HD void fpv_pack_half(const FpvDroneState& s, uint32_t seed, uint32_t drone, FpvHalfState& h)
 {
     // one full-avalanche hash of (seed, drone); the second word by one multiply-xorshift (a bijection of a uniform word:
@@ -527,6 +530,8 @@ FPV_HD void fpv_normal4(uint32_t seed_lo, uint32_t seed_hi, uint32_t drone_lo, u
 }
 
 // advance the EMA state ns[4] and perturb the action in place
+// which stream a (seed, drone, step) triple names, as a checkpoint records it (fpv_encoding_id(1); env.py NOISE_GENERATOR)
+#define FPV_NOISE_GENERATOR_ID "abi5: philox4x32-7, table-driven inverse normal CDF"
 FPV_HD void fpv_stick_noise(const FpvNoiseK& N, uint64_t step, uint64_t local_id, const FpvNormalRow* __restrict__ table,
                             float ns[4], float a[4])
 {

@@ -27,9 +27,14 @@ from . import _lib
 from .params import DroneParams, MODE_DRONE, MODE_RACER, load_params
 
 
-# identifiers stored in checkpoints (state_dict): what the fp16 storage words and the in-kernel stick-noise stream mean
+# identifiers stored in checkpoints (state_dict): what the fp16 storage words and the in-kernel stick-noise stream mean.
+# The strings are defined next to the code they describe (csrc/fpv_math.h FPV_STATE_H_ENCODING_ID / FPV_NOISE_GENERATOR_ID) and
+# exported as fpv_encoding_id(0 / 1); tests/test_abi_load.py holds the two copies below to them, so they cannot drift apart.
 STATE_H_ENCODING = "abi5: v f16+5-bit low words, q smallest-three 15-bit fixed point, rates/thrust f16"     # csrc/fpv_math.h fpv_pack_half
 NOISE_GENERATOR = "abi5: philox4x32-7, table-driven inverse normal CDF"                                     # csrc/fpv_math.h fpv_stick_noise
+# the first ABI whose fp16 checkpoints carry `state_h_encoding`; ABI 5 wrote the same encoding without the label
+_FIRST_ABI_WITH_ENCODING_LABEL = 6
+CHECKPOINT_LAYOUT = "columns"        # row tensors are stored as their logical columns [rows, num_envs]: independent of the row stride
 
 
 def _round_up(x: int, m: int) -> int:
@@ -54,9 +59,10 @@ class _Batch:
         self._L = _lib.lib()
         self.mode = int(params.mode)
         self.rows = _lib.state_rows(self.mode)
-        self.ld = int(self._L.fpv_recommended_ld(self.n))
         dev_index = self.device.index if self.device.index is not None else torch.cuda.current_device()
         self._dev_index = int(dev_index)
+        # the row stride for THIS device: the L2-aware rule on the MI355X it was measured on, the model-free one elsewhere
+        self.ld = int(_lib.check(self._L.fpv_recommended_ld_device(self.n, self._dev_index)))
         self._handle = C.c_void_p()
         self.fp16_state = bool(fp16_state)
         self.rounding_seed = int(rounding_seed) & 0xFFFFFFFF
@@ -202,9 +208,24 @@ class _Batch:
             action = self._bcast_action
         if action.shape != (self.n, 4):
             raise ValueError(f"action must have shape ({self.n}, 4), got {tuple(action.shape)}")
+        if action.dtype in (torch.float16, torch.bfloat16, torch.float64) and action.device == self.state.device:
+            action = self._cast_sticks(action)           # one rule for step(), rollout() and step_async()
         if action.dtype != torch.float32 or action.device != self.state.device or not action.is_contiguous():
             action = action.to(device=self.device, dtype=torch.float32).contiguous()
         return action
+
+    _warned_cast = False
+
+    def _cast_sticks(self, action: torch.Tensor) -> torch.Tensor:
+        """A stick tensor of another floating dtype as contiguous float32 (one cast kernel per call; warned about once: a
+        half-precision policy that cares writes `.float()` into a preallocated buffer itself).  The same rule in step(),
+        rollout() and step_async()."""
+        if not _Batch._warned_cast:
+            import warnings
+            warnings.warn(f"sticks of dtype {action.dtype} are cast to float32 on every call (the kernels read float32 sticks since ABI 6)",
+                          RuntimeWarning, stacklevel=3)
+            _Batch._warned_cast = True
+        return action.to(torch.float32).contiguous()
 
     def set_step_counter(self, step: int) -> None:
         """64-bit step index keying the stick-noise stream / stochastic rounding (counts the steps launched, from 0)."""
@@ -220,9 +241,13 @@ class _Batch:
         return int(v.value)
 
     def set_rotation(self, drones: int = -1) -> None:
-        """How far the start of the traversal moves back from launch to launch (fpv_set_rotation; fp32 drone state only):
-        -1 automatic (on when the state is larger than the 256 MiB Infinity Cache), 0 the plain order, > 0 that many drones.
-        Results do not depend on it; a population beyond the cache steps up to 25 % faster with it."""
+        """How far the start of the traversal moves back from launch to launch (fpv_set_rotation; every single-step kernel:
+        drone fp32 / fp16 state / AoS head / Racer): -1 automatic - two cache tiers: the L2s' share of drones when a launch
+        writes more than the eight L2s hold (2^20 drones: 2^19), the Infinity Cache's share beyond 256 MiB (2^23 drones: 2^22),
+        plain order below, and plain order on a device that is not the one the model was measured on (`cache_model`) -,
+        0 the plain order, > 0 that many drones.  Results do not depend on it.  What it buys is a property of step-only
+        chains (profiles/r06_closed_loop.md: with a policy kernel between steps it is neutral).  A hipGraph replay
+        (rollout(graph=True)) counts its own rotation from its first node and leaves this one where it was."""
         _lib.check(self._L.fpv_set_rotation(self._handle, int(drones)))
 
     @property
@@ -231,6 +256,15 @@ class _Batch:
         v = C.c_int64()
         _lib.check(self._L.fpv_get_rotation(self._handle, C.byref(v)))
         return int(v.value)
+
+    @property
+    def cache_model(self) -> Dict[str, Any]:
+        """What fpv_create found when it held the device against the cache model of the rotation and the row stride
+        (fpv_get_cache_model): `matches`, the device's architecture / compute units / L2 size, and - when it does not match -
+        the reason the handle runs the plain order."""
+        m = _lib.FpvCacheModel()
+        _lib.check(self._L.fpv_get_cache_model(self._handle, C.byref(m)))
+        return m.as_dict()
 
     def set_params(self, params: DroneParams, auto_reset: Optional[bool] = None) -> None:
         flags_auto = bool(self._cparams.flags & _lib.FPV_FLAG_AUTO_RESET) if auto_reset is None else auto_reset
@@ -241,13 +275,36 @@ class _Batch:
     # -- checkpoint / resume (the reference has none; state is just tensors here) ------------------
     _CKPT_TENSORS = ("state", "state_h", "reward", "done", "ep_return", "ep_length", "last_return",
                      "last_length", "noise_state", "pos_comp")
+    _CKPT_ROW_TENSORS = ("state", "noise_state", "pos_comp")        # [rows, ld]: stored as their logical columns [rows, num_envs]
+
+    def _state_h_views(self, t: Optional[torch.Tensor] = None, ld: Optional[int] = None):
+        """(pair rows [5, ld, 2], thrust row [ld]) int16 views of an fp16 storage tensor laid out with row stride `ld`"""
+        t = self.state_h if t is None else t
+        ld = self.ld if ld is None else ld
+        raw, npair = t.view(torch.int16), _lib.FPV_HALF_PAIR_ROWS
+        return raw[:2 * npair * ld].view(npair, ld, 2), raw[2 * npair * ld:2 * npair * ld + ld]
 
     def state_dict(self) -> Dict[str, Any]:
-        """Everything needed to continue a run bit-for-bit: the device tensors (cloned) and the step
-        counter that keys the stick-noise stream / stochastic rounding."""
-        d: Dict[str, Any] = {k: getattr(self, k).clone() for k in self._CKPT_TENSORS if getattr(self, k, None) is not None}
+        """Everything needed to continue a run bit-for-bit: the device tensors (cloned) and the step counter that keys the
+        stick-noise stream / stochastic rounding.  Row tensors are stored as their LOGICAL columns - `state` [rows, num_envs],
+        the fp16 words as `state_h` [11, num_envs] int16 in storage order (five pair rows interleaved, then thrust) - so a
+        checkpoint does not depend on the row stride the writing library chose (fpv_recommended_ld has changed between
+        rounds and differs between devices)."""
+        d: Dict[str, Any] = {}
+        for k in self._CKPT_TENSORS:
+            t = getattr(self, k, None)
+            if t is None:
+                continue
+            if k in self._CKPT_ROW_TENSORS:
+                d[k] = t[:, :self.n].clone()
+            elif k == "state_h":
+                pairs, thrust = self._state_h_views()
+                d[k] = torch.cat([pairs[:, :self.n].permute(0, 2, 1).reshape(-1, self.n), thrust[:self.n].view(1, self.n)], dim=0)
+            else:
+                d[k] = t.clone()
         d["step_counter"] = int(self._steps_launched)
         d["num_envs"], d["mode"] = self.n, self.mode
+        d["layout"], d["ld"] = CHECKPOINT_LAYOUT, self.ld                # ld: for the record only - load does not need it
         # what the bits mean: the fp16 storage words and the stick-noise streams changed between ABI versions
         d["abi_version"] = _lib.FPV_ABI_VERSION
         if self.fp16_state:
@@ -257,23 +314,57 @@ class _Batch:
         return d
 
     def load_state_dict(self, d: Dict[str, Any]) -> None:
+        """Accepts this library's checkpoints (logical columns) and those of rounds <= 5 (padded tensors with the writer's own
+        row stride, whatever it was: the stride is read off the tensor's shape)."""
+        import warnings
         if d["num_envs"] != self.n or d["mode"] != self.mode:
             raise ValueError("checkpoint was taken from a batch of different size or mode")
         if "done_u8" in d and "done" not in d:        # checkpoints written before the bool view existed
             d = dict(d, done=d["done_u8"].bool())
         if self.fp16_state and d.get("state_h_encoding") != STATE_H_ENCODING:
-            # an older library's eleven words decode as garbage here (e.g. its qw half would be read as the v_low bits)
-            raise ValueError(f"fp16-state checkpoint with storage encoding {d.get('state_h_encoding')!r} (ABI {d.get('abi_version', '<= 5, unrecorded')}); "
-                             f"this library reads {STATE_H_ENCODING!r} - widen the old state with the library that wrote it and load the fp32 rows")
+            abi = d.get("abi_version")
+            if "state_h_encoding" not in d and (abi is None or abi < _FIRST_ABI_WITH_ENCODING_LABEL) and "state_h" in d \
+                    and d["state_h"].numel() % _lib.FPV_HALF_HALVES == 0:
+                # an ABI-5 checkpoint: the encoding this library still reads (ABI 6 only made non-unit quaternion fields saturate
+                # instead of wrapping - the stored bits of unit quaternions are the same), written before checkpoints were labelled.
+                # (ABI <= 4 stored eleven separate half rows; such a file decodes as garbage and cannot be told apart by its shape.)
+                warnings.warn("fp16-state checkpoint without a `state_h_encoding` label (written by an ABI-5 library): read as "
+                              f"{STATE_H_ENCODING!r}; a checkpoint of ABI <= 4 must be widened with the library that wrote it", RuntimeWarning, stacklevel=2)
+            else:
+                # another library's eleven words decode as garbage here (e.g. its qw half would be read as the v_low bits)
+                raise ValueError(f"fp16-state checkpoint with storage encoding {d.get('state_h_encoding')!r} (ABI {abi if abi is not None else '<= 5, unrecorded'}); "
+                                 f"this library reads {STATE_H_ENCODING!r} - widen the old state with the library that wrote it and load the fp32 rows")
         if self.stick_noise and d.get("noise_generator") != NOISE_GENERATOR:
-            import warnings
             warnings.warn(f"checkpoint was written with stick-noise generator {d.get('noise_generator')!r}, this library runs {NOISE_GENERATOR!r}: "
                           "the run continues with a different (equally distributed) stick stream, not bit for bit", RuntimeWarning, stacklevel=2)
         for k in self._CKPT_TENSORS:
-            if k in d:
-                if getattr(self, k, None) is None:
-                    raise ValueError(f"checkpoint has {k!r} but this batch was built without it")
-                getattr(self, k).copy_(d[k])
+            if k not in d:
+                continue
+            mine, src = getattr(self, k, None), d[k]
+            if mine is None:
+                raise ValueError(f"checkpoint has {k!r} but this batch was built without it")
+            if k in self._CKPT_ROW_TENSORS:
+                if src.dim() != 2 or src.shape[0] != mine.shape[0] or src.shape[1] < self.n:
+                    raise ValueError(f"checkpoint tensor {k!r} has shape {tuple(src.shape)}; expected [{mine.shape[0]}, >= {self.n}]")
+                mine[:, :self.n].copy_(src[:, :self.n])             # logical columns, or a padded tensor of any row stride
+            elif k == "state_h":
+                pairs, thrust = self._state_h_views()
+                npair = _lib.FPV_HALF_PAIR_ROWS
+                if src.dim() == 2:                                   # [11, num_envs] int16 in storage order
+                    if tuple(src.shape) != (_lib.FPV_HALF_HALVES, self.n):
+                        raise ValueError(f"checkpoint tensor 'state_h' has shape {tuple(src.shape)}; expected [{_lib.FPV_HALF_HALVES}, {self.n}]")
+                    w = src.view(torch.int16)
+                    pairs[:, :self.n].copy_(w[:2 * npair].view(npair, 2, self.n).permute(0, 2, 1))
+                    thrust[:self.n].copy_(w[2 * npair])
+                else:                                                # rounds <= 5: the flat padded tensor, FPV_HALF_HALVES * ld_then halves
+                    ld_then = src.numel() // _lib.FPV_HALF_HALVES
+                    if src.numel() % _lib.FPV_HALF_HALVES or ld_then < self.n:
+                        raise ValueError(f"checkpoint tensor 'state_h' has {src.numel()} halves: not {_lib.FPV_HALF_HALVES} rows of >= {self.n}")
+                    op, ot = self._state_h_views(src, ld_then)
+                    pairs[:, :self.n].copy_(op[:, :self.n])
+                    thrust[:self.n].copy_(ot[:self.n])
+            else:
+                mine.copy_(src)
         self.set_step_counter(d["step_counter"])
 
     def close(self) -> None:
@@ -393,9 +484,12 @@ class _Batch:
             if rewards is None and dones is None and steps is None:
                 raise ValueError("held-action rollouts need rewards/dones [k, num_envs] or steps=k to define k")
             k, stride = (int(steps) if steps is not None else (rewards if rewards is not None else dones).shape[0]), 0
+        if actions is not None and actions.dtype in (torch.float16, torch.bfloat16, torch.float64) and actions.device == self.state.device:
+            actions = self._cast_sticks(actions)           # as step() does: the kernels read float32 sticks (ABI 6 dropped the binary16 rows)
         if actions is not None and (actions.dtype != torch.float32 or not actions.is_contiguous()
                                     or actions.device != self.state.device):
-            raise ValueError("actions must be a contiguous float32 tensor on the env's device")
+            raise ValueError("actions must be a contiguous float32 tensor on the env's device (float16 / bfloat16 / float64 "
+                             "tensors there are cast once per call)")
         b.action = actions.data_ptr() if actions is not None else None
         b.action_ld = 0
         if wind is not None:
@@ -509,6 +603,8 @@ class _Partition:
                 raise ValueError("action=None is only meaningful with stick_noise=True (pure noise sticks)")
             return None
         st = self.parent.state
+        if type(action) is torch.Tensor and action.dtype in (torch.float16, torch.bfloat16, torch.float64) and action.device == st.device:
+            action = self.parent._cast_sticks(action)      # as step() and rollout() do
         if type(action) is torch.Tensor and action.dtype is torch.float32 and action.device == st.device:
             if action.shape == self._ashape and action.is_contiguous():               # [n_p, 4] rows (a row slice of [N, 4] is one)
                 self._buf.action_ld = 0

@@ -40,7 +40,12 @@ extern "C" {
 /* 7: fpv_set_rotation / fpv_get_rotation added: the fp32 drone step kernels walk the population from a start block that moves
  *    back by a cache's worth of drones per launch - the L2s' when the state overflows them (2^20 drones: 11 % less time), the
  *    Infinity Cache's beyond that (2^23 drones: up to 25 % less) - same results; automatic by default. */
-#define FPV_ABI_VERSION 7
+/* 8: the cache model behind the rotation and the row stride is CHECKED against the device (hipGetDeviceProperties at fpv_create):
+ *    fpv_check_cache_model / fpv_device_cache_model / fpv_get_cache_model / fpv_recommended_ld_device added.  A device that is not
+ *    gfx950 with 256 compute units and a 4 MiB L2 per XCD (e.g. a CPX compute partition) gets the plain order and the
+ *    conservative stride - same results.  Every single-step kernel rotates (drone fp32 / fp16 state / AoS head / Racer), as ABI 7
+ *    already did; its comment said "fp32 drone" only.  fpv_encoding_id added (what a checkpoint's fp16 words / noise stream mean). */
+#define FPV_ABI_VERSION 8
 
 enum {
     FPV_OK = 0,
@@ -295,8 +300,9 @@ int fpv_widen_state(fpv_handle_t h, const fpv_buffers_t* b, float* out, int64_t 
 int fpv_set_step_counter(fpv_handle_t h, uint64_t step);
 int fpv_get_step_counter(fpv_handle_t h, uint64_t* step);
 
-/* Rotation of the traversal (fp32 drone state, fpv_step / fpv_rollout / fpv_rollout_graph; no reference counterpart - the
- * reference steps one drone).  Every launch of a dependent chain re-reads the state the previous launch wrote.  MI355X keeps the most
+/* Rotation of the traversal (every single-step kernel - drone fp32, fp16 state, AoS head, Racer -, launched by fpv_step /
+ * fpv_rollout / fpv_rollout_graph; the k-step kernels of fpv_step_n keep the drone in registers and have nothing to find again;
+ * no reference counterpart - the reference steps one drone).  Every launch of a dependent chain re-reads the state the previous launch wrote.  MI355X keeps the most
  * recently touched 256 MiB in its Infinity Cache; a population whose state is larger than that, walked in the same order every
  * launch, finds nothing of it there (cyclic access).  With rotation the launch starts `drones` BEFORE the drone at which the
  * previous launch started - i.e. on the rows the previous launch wrote last - and wraps around, ascending addresses all the
@@ -306,9 +312,35 @@ int fpv_get_step_counter(fpv_handle_t h, uint64_t* step);
  * a launch overflows (2^19 drones for the plain kernel's 61 B beyond the L2s, 2^22 beyond the Infinity Cache; whole rounds of the
  * eight XCDs), 0 when a launch writes less than the L2s hold; 0: plain order; > 0: that many drones (rounded down to whole
  * 128-drone workgroups).  fpv_get_rotation returns the value of the last launch (before the first: the estimate for reward
- * and done only). */
+ * and done only).
+ * Two cache tiers, one rule: which tier applies is decided per launch from what that launch writes.  A hipGraph replay
+ * (fpv_rollout_graph) carries its own rotation, counted from its first node - a replay begins where the previous replay began
+ * (one launch in k starts on cold rows) and neither reads nor moves the start that fpv_step / fpv_rollout keep in the handle:
+ * mixing the two APIs on one handle is harmless (same results, each keeps its own order).
+ * The automatic rule is a model of ONE device - gfx950 in single-partition mode: 256 compute units = eight XCDs with a 4 MiB L2
+ * each behind a 256 MiB Infinity Cache, workgroups handed to the XCDs round-robin.  fpv_create asks the device
+ * (hipGetDeviceProperties: architecture, compute units, L2 size); when the answer is anything else the automatic setting is the
+ * plain order (fpv_get_rotation then reports 0 and leaves the reason in fpv_last_error(); fpv_get_cache_model has it too).  An
+ * explicit request (drones > 0) is honoured on any device. */
 int fpv_set_rotation(fpv_handle_t h, int64_t drones);
 int fpv_get_rotation(fpv_handle_t h, int64_t* drones);
+
+/* The cache model and what a device says about itself. */
+typedef struct fpv_cache_model_t {
+    uint32_t struct_size;           /* sizeof(fpv_cache_model_t) of the library that filled it */
+    int32_t matches;                /* 1: the device is the one the model was measured on - rotation and L2-aware stride apply */
+    int32_t compute_units;          /* hipDeviceProp_t.multiProcessorCount: what this process sees (a compute partition shows fewer) */
+    int32_t xcds;                   /* 8 when matches (HIP does not report it: implied by gfx950 with all 256 CUs), else 0 */
+    int64_t l2_bytes_per_xcd;       /* hipDeviceProp_t.l2CacheSize (0: not reported by the runtime) */
+    int64_t infinity_cache_bytes;   /* 256 MiB when matches (HIP does not report it), else 0 */
+    char arch[64];                  /* hipDeviceProp_t.gcnArchName, e.g. "gfx950:sramecc+:xnack-" */
+    char reason[256];               /* matches == 0: what differs and what the library does instead; else "" */
+} fpv_cache_model_t;
+/* the rule itself, host arithmetic only (no device needed): would a device with these properties get the model? */
+int fpv_check_cache_model(const char* arch, int compute_units, int64_t l2_bytes_per_xcd, fpv_cache_model_t* out);
+/* the rule applied to device `device` (FPV_ENODEV without one) / what fpv_create found for this handle */
+int fpv_device_cache_model(int device, fpv_cache_model_t* out);
+int fpv_get_cache_model(fpv_handle_t h, fpv_cache_model_t* out);
 
 /* Same k steps as fpv_rollout, replayed from a hipGraph cached in the handle: for small, launch-bound
  * batches (a 4096-drone step is ~2 us of kernel behind ~4 us of launch).  The graph is rebuilt only when
@@ -331,8 +363,12 @@ int fpv_set_params(fpv_handle_t h, const fpv_params_t* params);
  * 2 KiB: the best class of stride at every measured population), moved by multiples of 64 floats where - up to 2^21 drones - that
  * stride would make the rows of a drone block share their sets in an XCD's L2 (2^19 drones: n + 320 instead of n + 256 floats,
  * 10.7 against 13.2 us per launch).  Host arithmetic only: no device needed.  Any ld >= n that is a multiple of 4
- * is accepted by fpv_step; results do not depend on ld. */
+ * is accepted by fpv_step; results do not depend on ld.
+ * fpv_recommended_ld is the rule FOR THE MI355X the model was measured on, whatever device is present (or none);
+ * fpv_recommended_ld_device asks `device` first and returns the first, model-free rule (64-float rounding + the 8 KiB pad) for
+ * every n when the device is not that one (fpv_device_cache_model; FPV_ENODEV without a device).  Allocate with the latter. */
 int64_t fpv_recommended_ld(int64_t n);
+int64_t fpv_recommended_ld_device(int64_t n, int device);
 
 /* Diagnostics only: dst[i] = src[i] for n_floats fp32 values with the step kernel's access shape
  * (one dword per lane); a known-byte-count launch for calibrating rocprofv3 byte counters. */
@@ -395,6 +431,10 @@ int fpv_pid_call(const fpv_pid_params_t* params, float* pid_state, int64_t ld, i
 
 const char* fpv_last_error(void);
 const char* fpv_error_name(int code);
+/* Identifier of what stored bits mean, for checkpoints: 0 = the fp16 state storage words (FPV_FLAG_FP16_STATE), 1 = the
+ * in-kernel stick-noise stream.  A checkpoint records the string; a library whose string differs cannot continue it bit for
+ * bit (fp16 words: cannot decode it at all).  NULL for any other `which`. */
+const char* fpv_encoding_id(int which);
 
 #ifdef __cplusplus
 }

@@ -42,6 +42,15 @@ def test_struct_sizes_match_the_c_side():
     assert _lib.algorithmic_bytes(0) == 133 and _lib.algorithmic_bytes(1) == 181
 
 
+def test_checkpoint_labels_are_the_librarys_own():
+    """The strings a checkpoint records for its fp16 storage words and its stick-noise stream are defined next to the code they
+    describe (csrc/fpv_math.h) and exported (fpv_encoding_id): the Python copies cannot drift from the kernels'."""
+    from fpyv_amd import env
+    L = _lib.lib()
+    assert L.fpv_encoding_id(0).decode() == env.STATE_H_ENCODING and L.fpv_encoding_id(1).decode() == env.NOISE_GENERATOR
+    assert L.fpv_encoding_id(2) is None
+
+
 def test_no_gpu_means_loud_failure_not_cpu_fallback():
     import torch
     if torch.cuda.is_available():

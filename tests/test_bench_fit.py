@@ -41,3 +41,21 @@ def test_a_flat_or_falling_line_and_a_negative_floor_are_invalid():
 
 def test_median_helper():
     assert bench.median([3.0, 1.0, 2.0]) == 2.0 and bench.median([4.0, 1.0]) == 2.5 and bench.median([7.0]) == 7.0
+
+
+def test_roofline_frac_follows_value():
+    """one line, one answer.  `roofline.frac` is `value` x algorithmic bytes / peak (the wall clock of the timed
+    region); the HIP-event figure is `frac_events`.  Held on the helper and on every recorded headline line of this round."""
+    import glob
+    import json
+    import os
+    r = bench.hbm_roofline(49.71e9, 133, 1 << 20, 1.0, 20.08e-6)          # the driver's round-5 line: 49.71 G env-steps/s, 20.08 us per launch by events
+    assert abs(r["frac"] - 49.71e9 * 133 / 8e12) < 1e-12 and abs(r["frac"] - 0.8264) < 1e-3
+    assert abs(r["frac_events"] - 133 * (1 << 20) / 20.08e-6 / 8e12) < 1e-12 and abs(r["frac_events"] - 0.868) < 1e-3
+    assert abs(r["achieved"] - r["frac"] * 8000.0) < 1e-9 and abs(r["achieved_events"] - r["frac_events"] * 8000.0) < 1e-9
+    lines = sorted(glob.glob(os.path.join(bench.REPO, "profiles", "r06_bench_n1_step*.json")) + glob.glob(os.path.join(bench.REPO, "profiles", "r06_bench_n1_fp16.json")))
+    for p in lines:
+        d = json.loads(open(p).read().strip().splitlines()[-1])
+        ro = d["roofline"]
+        assert abs(ro["frac"] - d["value"] / d["n_gpus"] * ro["algorithmic_bytes_per_env_step"] / 8e12) < 1e-9, p
+        assert abs(ro["frac_events"] - ro["algorithmic_bytes_per_env_step"] * d["config"]["drones_per_gpu"] * d["config"]["steps_per_launch"] / (ro["avg_launch_us"] * 1e-6) / 8e12) < 1e-9, p

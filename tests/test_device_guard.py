@@ -1,0 +1,82 @@
+"""The cache model behind the rotation of the traversal and the row stride is a model of ONE device (gfx950, 256 compute units
+= eight XCDs with a 4 MiB L2 each, 256 MiB Infinity Cache).  fpv_create asks the device; anything else gets the plain order and
+the model-free stride.  No GPU needed: the rule is host arithmetic (fpv_check_cache_model), and the handle's
+reaction is driven through a preloaded stand-in for the four HIP calls fpv_create makes (tests/fake_device/)."""
+import ctypes as C
+import json
+import os
+import subprocess
+
+import pytest
+
+from conftest import REPO
+from fpyv_amd import _lib, load_params
+
+FAKE = os.path.join(REPO, "tests", "fake_device")
+
+
+def check(arch, cus, l2):
+    m = _lib.FpvCacheModel()
+    assert _lib.lib().fpv_check_cache_model(arch.encode(), cus, l2, C.byref(m)) == 0
+    return m.as_dict()
+
+
+def test_the_rule_itself():
+    ok = check("gfx950:sramecc+:xnack-", 256, 4 << 20)          # what the GPU box reports (profiles/r06_device_props.json)
+    assert ok == {"matches": True, "arch": "gfx950:sramecc+:xnack-", "compute_units": 256, "xcds": 8, "l2_bytes_per_xcd": 4 << 20,
+                  "infinity_cache_bytes": 256 << 20, "reason": None}
+    assert check("gfx950", 256, 0)["matches"]                    # a runtime that does not report the L2 size: architecture + CUs pin the silicon
+    for arch, cus, l2, word in (("gfx950:sramecc+:xnack-", 32, 4 << 20, "32 compute units"),          # CPX: one XCD per partition
+                                ("gfx950:sramecc+:xnack-", 128, 4 << 20, "128 compute units"),        # DPX
+                                ("gfx942:sramecc+:xnack-", 304, 4 << 20, "gfx942"),                   # MI300X
+                                ("gfx9500", 256, 4 << 20, "gfx9500"),                                 # a prefix is not a match
+                                ("gfx950", 256, 8 << 20, "8388608 bytes"),
+                                ("", 0, 0, "not gfx950")):
+        m = check(arch, cus, l2)
+        assert not m["matches"] and m["xcds"] == 0 and m["infinity_cache_bytes"] == 0, m
+        assert word in m["reason"] and "plain traversal order" in m["reason"], m
+    assert _lib.lib().fpv_check_cache_model(None, 1, 1, C.byref(_lib.FpvCacheModel())) == -1
+    assert _lib.lib().fpv_sizeof(4) == C.sizeof(_lib.FpvCacheModel)
+
+
+@pytest.fixture(scope="module")
+def fake(tmp_path_factory):
+    d = tmp_path_factory.mktemp("fake_device")
+    so, exe, blob = str(d / "libfake_hip.so"), str(d / "driver"), str(d / "params.bin")
+    subprocess.run(["gcc", "-O1", "-shared", "-fPIC", "-I/opt/rocm/include", "-o", so, os.path.join(FAKE, "fake_hip.c")], check=True)
+    subprocess.run(["gcc", "-O1", "-o", exe, os.path.join(FAKE, "driver.c"), "-L" + os.path.join(REPO, "fpyv_amd"), "-lfpv_hip",
+                    "-Wl,-rpath," + os.path.join(REPO, "fpyv_amd"), "-Wl,-rpath,/opt/rocm/lib"], check=True)
+    cp = _lib.pack_params(load_params(fps=1000), auto_reset=True)
+    with open(blob, "wb") as f:
+        f.write(bytes(cp))
+
+    def run(n, **props):
+        env = dict(os.environ, LD_PRELOAD=so, **{k: str(v) for k, v in props.items()})
+        r = subprocess.run([exe, str(n), blob], capture_output=True, text=True, env=env, timeout=120)
+        assert r.returncode == 0, (r.returncode, r.stdout, r.stderr)
+        return json.loads(r.stdout.strip().splitlines()[-1])
+    return run
+
+
+def test_the_measured_device_gets_the_model(fake):
+    for n, rot in ((1 << 19, 0), (1 << 20, 1 << 19), (1 << 23, 1 << 22), (1_000_000, 1 << 19)):
+        d = fake(n)
+        assert d["matches"] == 1 and d["xcds"] == 8 and d["mall"] == 256 << 20 and d["reason"] == ""
+        assert d["rotation"] == rot and d["rotation_explicit_4096"] == 4096
+        assert d["ld_device"] == d["ld_model"]
+    assert fake(1 << 19)["ld_device"] == (1 << 19) + 320                 # the L2 set model's choice
+
+
+@pytest.mark.parametrize("props,word", [(dict(FAKE_HIP_CUS=32), "32 compute units"), (dict(FAKE_HIP_CUS=64), "64 compute units"),
+                                        (dict(FAKE_HIP_ARCH="gfx942:sramecc+:xnack-", FAKE_HIP_CUS=304), "gfx942"),
+                                        (dict(FAKE_HIP_L2=2 << 20), "2097152 bytes")],
+                         ids=["cpx", "qpx", "mi300x", "other_l2"])
+def test_an_unexpected_device_gets_the_plain_order_and_says_why(fake, props, word):
+    for n in (1 << 19, 1 << 20, 1 << 23):
+        d = fake(n, **props)
+        assert d["matches"] == 0 and d["rotation"] == 0, d
+        assert word in d["reason"] and d["last_error_after_get_rotation"] == d["reason"]
+        assert d["rotation_explicit_4096"] == 4096                         # an explicit request is honoured anywhere
+        ld = d["ld_device"]                                                # the model-free stride: 64-float rounding + clear of 8 KiB
+        assert ld >= n and ld % 64 == 0 and ld - n < 64 + 256 and (ld % 2048) >= 256
+    assert fake(1 << 19, **props)["ld_device"] == (1 << 19) + 256 and fake(1 << 19, **props)["ld_model"] == (1 << 19) + 320

@@ -1247,6 +1247,87 @@ def test_checkpoint_resume_is_bit_exact(params_1k, tmp_path):
         h.load_state_dict({k: v for k, v in ckh.items() if k != "state_h_encoding"})
 
 
+def test_checkpoint_does_not_depend_on_the_row_stride(params_1k):
+    """fpv_recommended_ld changed between rounds (2^19 drones: n + 256 -> n + 320 floats; 10^6 drones: n -> n + 192) and
+    differs between devices, so a checkpoint stores LOGICAL columns - and a checkpoint of rounds <= 5 (padded tensors with the
+    writer's stride, flat fp16 words) still loads: the stride is read off the tensor.  Both continue bit for bit.  fp16 state: an
+    ABI-5 file (the same encoding, written before checkpoints were labelled) loads with a warning; a labelled file of another
+    encoding is refused; float16 sticks are cast the same way by step(), rollout() and step_async()."""
+    import warnings
+    from fpyv_amd.env import DroneBatch, FpvVecEnv
+    n = 3000
+    p = params_1k.replace(ceiling=10.3, noise_gain=2.0)
+    for fp16 in (False, True):
+        # (in-kernel stick noise needs fp32 state: the fp16 batch takes its sticks from a tensor)
+        kw = dict(device=DEV, stick_noise=not fp16, noise_seed=4, auto_reset=True, with_accel=False, kahan_position=not fp16, fp16_state=fp16, rounding_seed=9)
+        a, b, c = (DroneBatch(p, n, **kw) for _ in range(3))
+        for e in (a, b, c):
+            e.reset()
+        gs = torch.Generator(device=DEV); gs.manual_seed(3)
+        sticks_t = None if not fp16 else torch.rand((100, n, 4), device=DEV, generator=gs) * 2 - 1
+        roll = (lambda e, t0, k: e.rollout(None, steps=k)) if not fp16 else (lambda e, t0, k: e.rollout(sticks_t[t0:t0 + k].contiguous()))
+        roll(a, 0, 60)
+        ck = a.state_dict()
+        assert ck["layout"] == "columns" and ck["ld"] == a.ld and ck["state"].shape == (a.state.shape[0], n) and (fp16 or ck["noise_state"].shape == (4, n))
+        if fp16:
+            assert ck["state_h"].shape == (11, n) and ck["state_h"].dtype == torch.int16
+            assert torch.equal(ck["state_h"], a.storage_words()[:, :n])
+        # the same checkpoint as a library with ANOTHER row stride wrote it in rounds <= 5: padded tensors, flat fp16 words
+        ld2 = a.ld + 448
+        old = {k: v for k, v in ck.items() if k not in ("layout", "ld")}
+        for k in ("state", "noise_state", "pos_comp"):
+            if k in ck:
+                t = torch.zeros((ck[k].shape[0], ld2), dtype=ck[k].dtype, device=DEV)
+                t[:, :n] = ck[k]
+                old[k] = t
+        if fp16:
+            w = torch.zeros(11 * ld2, dtype=torch.int16, device=DEV)
+            w[:10 * ld2].view(5, ld2, 2)[:, :n] = ck["state_h"][:10].view(5, 2, n).permute(0, 2, 1)
+            w[10 * ld2:10 * ld2 + n] = ck["state_h"][10]
+            old["state_h"] = w.view(torch.float16)
+        b.load_state_dict(ck)
+        c.load_state_dict(old)
+        for e in (a, b, c):
+            roll(e, 60, 40)
+        torch.cuda.synchronize()
+        for k in ("state", "state_h", "noise_state", "pos_comp", "reward", "done_u8"):
+            x = getattr(a, k, None)
+            if x is not None:
+                view = (lambda t: t.view(torch.int16)) if k == "state_h" else (lambda t: t)
+                assert torch.equal(view(x), view(getattr(b, k))) and torch.equal(view(x), view(getattr(c, k))), (fp16, k)
+        if fp16:
+            abi5 = {k: v for k, v in old.items() if k not in ("state_h_encoding", "abi_version")}
+            with pytest.warns(RuntimeWarning, match="ABI-5"):
+                c.load_state_dict(abi5)
+            with pytest.raises(ValueError, match="storage encoding"):
+                c.load_state_dict(dict(old, state_h_encoding="abi3: eleven half rows"))
+            with pytest.raises(ValueError, match="storage encoding"):
+                c.load_state_dict({k: v for k, v in ck.items() if k != "state_h_encoding"})        # ABI >= 6 always labels
+        with pytest.raises(ValueError, match="shape"):
+            c.load_state_dict(dict(ck, state=ck["state"][:, :n - 1]))
+    # one rule for sticks of another floating dtype: cast (warned about once), whichever call takes them
+    e1, e2 = DroneBatch(p, 512, device=DEV), DroneBatch(p, 512, device=DEV)
+    e1.reset(); e2.reset()
+    g = torch.Generator(device=DEV); g.manual_seed(1)
+    acts = (torch.rand((6, 512, 4), device=DEV, generator=g) * 2 - 1).half()
+    with warnings.catch_warnings():
+        warnings.simplefilter("ignore", RuntimeWarning)
+        for t in range(6):
+            e1.step(acts[t], return_imu=False)
+        e2.rollout(acts)
+        v = FpvVecEnv(p, num_envs=512, device=DEV, partitions=2)
+        v.reset()
+        for t in range(6):
+            for part in range(v.partitions):
+                lo, hi = v.partition_range(part)
+                v.step_async(part, acts[t, lo:hi])
+        for part in range(v.partitions):
+            v.step_wait(part)
+    torch.cuda.synchronize()
+    assert torch.equal(e1.state, e2.state) and torch.equal(e1.state, v.batch.state)
+    v.close()
+
+
 def test_vec_env_options_pass_through(params_1k):
     from fpyv_amd.env import FpvVecEnv
     from fpyv_amd.objects import Ground
@@ -2286,6 +2367,10 @@ def test_bench_line_schema_small(extra):
     assert d["value"] > 1e8 and abs(d["value"] - (1 << 16) * 40 / (d["ms_per_step"] * 40e-3)) < 1e-3 * d["value"]
     ro = d["roofline"]
     assert ro["peak"] == 8000.0 and 0 < ro["frac"] < 1 and abs(ro["frac"] - ro["achieved"] / ro["peak"]) < 1e-9 and ro["traffic"] is None   # traffic is quoted for the headline size only
+    # one line, one answer: frac follows `value` by the stated formula; the HIP-event figure stands beside it under its own name
+    hv = ro["hbm_view"] if extra[:1] == ["--api"] else ro
+    assert abs(hv["frac"] - d["value"] / d["n_gpus"] * ro["algorithmic_bytes_per_env_step"] / 1e9 / 8000.0) < 1e-9 * max(1.0, hv["frac"])
+    assert hv["frac_events"] >= hv["frac"] * 0.999 and "value" in ro["frac_formula"]       # the event clock starts later and stops earlier than the wall clock
     if extra[:1] == ["--api"]:
         assert ro["bound"] == "hbm" and ro["valu"] is None and ("configuration" in ro["valu_unavailable"] or "stale" in ro["valu_unavailable"])   # (stale: sources edited since the counter pass)
         assert d["config"]["steps_per_launch"] > 1

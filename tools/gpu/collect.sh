@@ -1,14 +1,23 @@
 # copies what tools/gpu/measure.sh <round> left under gpurun_out/<round>/ into profiles/ (the tracked, judged copies)
 set -e
-R=${1:-r05}
+R=${1:-r06}
 STAGE=${2:-all}
 cd "$(dirname "$0")/../.."
 O=gpurun_out/$R; P=profiles
 last() { tail -n 1 "$1" > "$2"; }
+if [ "$STAGE" = loop ]; then
+python3 tools/closed_loop_summary.py $R > $P/${R}_closed_loop.md
+cp $O/closed_loop_ab.json $P/${R}_closed_loop_ab.json
+for t in 1048576_rot-1 1048576_rot0 8388608_rot-1 8388608_rot0 mlp; do cp $O/cl_kt_${t}_kernel_stats.csv $P/${R}_closed_loop_kernel_stats_${t}.csv; done
+exit 0
+fi
 if [ "$STAGE" != bench ]; then
 cp $O/pmc_traffic.json $O/pmc_valu.json $O/${R}_pmc_summary.md $O/${R}_kernel_stats.csv $O/${R}_beyond_mall_counters.md $P/
 cp $O/valu_counts.log      $P/${R}_pmc_valu_counts.log
 cp $O/gpu_tests.log        $P/${R}_gpu_tests.log
+cp $O/gpu_timing.log       $P/${R}_gpu_timing.log
+cp $O/timing_guards.json   $P/${R}_timing_guards.json
+cp $O/device_props.json    $P/${R}_device_props.json
 f=$(ls -t $O/prof_kt_variants/*/*_kernel_stats.csv | head -1); cp "$f" $P/${R}_kernel_stats_variants.csv
 fi
 if [ "$STAGE" = counters ]; then exit 0; fi
@@ -22,7 +31,8 @@ last $O/bench_racerW.json            $P/${R}_bench_n1_racerW.json
 last $O/bench_racerD.json            $P/${R}_bench_n1_racerD.json
 last $O/bench_forcedist.json         $P/${R}_bench_n1_forcedist.json
 last $O/bench_forcedist_20.json      $P/${R}_bench_n1_forcedist_20steps.json
-last $O/bench_rehearsal_2ranks.json  $P/${R}_bench_rehearsal_2ranks_on_one_gpu.json
+last $O/bench_rehearsal_2ranks.json     $P/${R}_bench_rehearsal_2ranks_on_one_gpu_2000steps.json
+last $O/bench_rehearsal_2ranks_20.json  $P/${R}_bench_rehearsal_2ranks_on_one_gpu.json
 python3 - $O $P/${R}_ab_partitions_20steps.json <<'PY'
 import json, sys
 out = {}
