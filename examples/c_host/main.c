@@ -52,7 +52,8 @@ int main(int argc, char** argv)
     fpv_handle_t h = NULL;
     FPV_CHECK(fpv_create(P, n, 0, &h));
     const int rows = fpv_state_rows((int)P->mode);
-    const int64_t ld = fpv_recommended_ld(n);
+    const int64_t ld = fpv_recommended_ld_device(n, 0);          /* the row stride for THIS device (negative: an error code) */
+    if (ld < n) { fprintf(stderr, "fpv_recommended_ld_device: %s\n", fpv_last_error()); return 1; }
 
     fpv_buffers_t b;
     memset(&b, 0, sizeof(b));
