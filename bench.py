@@ -1115,7 +1115,7 @@ def main(argv=None):
                                        "only the action stream and reward/done cross HBM - `beyond_mall` is the same kernel at 2^23 drones, where the traversal rotates so that "
                                        "each launch starts on what the cache still holds. With another kernel's pass over the state between two steps (a policy: action -> step -> "
                                        "action) the caches hold what THAT kernel touched last and the rotation is neutral - measured: profiles/r06_closed_loop.md (step kernel "
-                                       "21.7 us inside the loop with or without it at 2^20 drones)",
+                                       "21.6-21.7 us inside the loop with or without it at 2^20 drones)",
                          "frac_beyond_mall": beyond["frac"] if beyond else None, "beyond_mall": beyond,
                          "sustained": sustained,
                          "launch_time_fit": None,

@@ -1,6 +1,6 @@
 """The kernel-quality claims of DESIGN.md against a FRESH gfx950 disassembly (hipcc cross-compiles here, no GPU needed):
 no scratch, no MFMA, no spilled register anywhere in the library, and the instruction counts / register numbers DESIGN
-quotes for the hot kernels.  tools/hot_kernel_isa.py is the same code the committed profiles/r05_hot_kernel_isa.txt was
+quotes for the hot kernels.  tools/hot_kernel_isa.py is the same code the committed profiles/r06_hot_kernel_isa.txt was
 written with."""
 import os
 import re
@@ -71,9 +71,9 @@ def test_fp16_and_kstep_kernels_as_design_quotes(isa):
 
 
 def test_committed_isa_profile_matches_the_sources(isa):
-    """profiles/r05_hot_kernel_isa.txt was written by the same tool: its count lines must still be what the sources give."""
+    """profiles/r06_hot_kernel_isa.txt was written by the same tool: its count lines must still be what the sources give."""
     h, bodies, res = isa
-    text = open(os.path.join(REPO, "profiles", "r05_hot_kernel_isa.txt")).read()
+    text = open(os.path.join(REPO, "profiles", "r06_hot_kernel_isa.txt")).read()
     for title, pat in h.HOT.items():
         name = next(n for n in bodies if pat in n)
-        assert str(dict(sorted(h.counts(bodies[name]).items()))) in text, f"{title}: profiles/r05_hot_kernel_isa.txt is stale (python tools/hot_kernel_isa.py --write r05)"
+        assert str(dict(sorted(h.counts(bodies[name]).items()))) in text, f"{title}: profiles/r06_hot_kernel_isa.txt is stale (python tools/hot_kernel_isa.py --write r06)"
