@@ -112,6 +112,30 @@ def hbm_roofline(value_per_gpu, bytes_per_env_step, drones, steps_per_launch, av
     return {"achieved": achieved, "frac": achieved / HBM_PEAK_GBS, "achieved_events": achieved_events, "frac_events": achieved_events / HBM_PEAK_GBS}
 
 
+def _lib_step_grid(n):
+    """workgroups of one single-step launch: n drones in blocks of 128, whole rounds of the eight XCDs (csrc/fpv_hip.hip step_grid)"""
+    return (n + 8 * 128 - 1) // (8 * 128) * 8
+
+
+def xcd_map_probe(dev, blocks, launches=16):
+    """Which XCD runs which workgroup (fpv_diag_xcd_map: the XCC_ID register), over `launches` launches of the step kernel's grid:
+    the rotation's L2 tier assumes xcd(b) = (b + s) mod 8 with the same s for every launch of a chain.  HIP promises neither; this
+    is the run-time look at it (a different answer costs cache reuse, never a result)."""
+    import torch
+    from fpyv_amd import _lib
+    L = _lib.lib()
+    out = torch.full((launches, blocks), 99, dtype=torch.int32, device=dev)
+    for t in range(launches):
+        _lib.check(L.fpv_diag_xcd_map(out[t].data_ptr(), blocks, torch.cuda.current_stream(dev).cuda_stream))
+    torch.cuda.synchronize()
+    m = out.cpu()
+    b = torch.arange(blocks, dtype=torch.int32)
+    shifts = [int(r[0]) % 8 for r in m]
+    return {"blocks": blocks, "launches": launches, "round_robin_exact": all(bool(torch.equal(r, (b + s) % 8)) for r, s in zip(m, shifts)),
+            "shift_stable": len(set(shifts)) == 1, "shift": shifts[0], "xcds_seen": len(set(m.flatten().tolist())),
+            "note": "workgroup b of every launch ran on XCD (b + shift) mod 8: a drone block of the rotated traversal meets its own L2 again"}
+
+
 def median(xs):
     xs = sorted(xs)
     m = len(xs) // 2
@@ -1122,6 +1146,8 @@ def main(argv=None):
                          "note": "avg_launch_us = HIP-event time over the timed region / launches (includes inter-launch gaps); achieved / frac follow `value` "
                                  "(wall clock), achieved_events / frac_events follow avg_launch_us - see frac_formula"},
         }
+        if world == 1 and args.api == "step":
+            out["roofline"]["xcd_map"] = xcd_map_probe(dev, int(_lib_step_grid(n)))
         if venv is not None:
             out["roofline"]["note"] = (f"split phase: one step = {venv.partitions} launches on {venv.partitions} streams that overlap; avg_launch_us is the "
                                        "time per full-population step, achieved = 133 B x n / that; " + out["roofline"]["note"])

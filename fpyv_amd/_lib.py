@@ -33,7 +33,7 @@ R_OMEGA, R_IERR, R_LERR, R_FIRST, R_OMEGA_LO, R_IERR_LO, R_DFILT = 10, 13, 16, 1
 EXPORTS = ("fpv_abi_version", "fpv_sizeof", "fpv_state_rows", "fpv_algorithmic_bytes", "fpv_handle_algorithmic_bytes", "fpv_create", "fpv_destroy",
            "fpv_reset", "fpv_step", "fpv_rollout", "fpv_step_n", "fpv_rollout_graph", "fpv_return_triple", "fpv_widen_state", "fpv_set_params", "fpv_set_step_counter", "fpv_get_step_counter", "fpv_set_rotation", "fpv_get_rotation", "fpv_recommended_ld",
            "fpv_recommended_ld_device", "fpv_check_cache_model", "fpv_device_cache_model", "fpv_get_cache_model",
-           "fpv_diag_stream_copy", "fpv_diag_stream_copy_wide", "fpv_diag_busy", "fpv_pid_reset", "fpv_pid_call", "fpv_comm_unique_id", "fpv_comm_create", "fpv_comm_destroy", "fpv_comm_info",
+           "fpv_diag_stream_copy", "fpv_diag_stream_copy_wide", "fpv_diag_busy", "fpv_diag_xcd_map", "fpv_pid_reset", "fpv_pid_call", "fpv_comm_unique_id", "fpv_comm_create", "fpv_comm_destroy", "fpv_comm_info",
            "fpv_allgather_done", "fpv_allgather_f32", "fpv_last_error",
            "fpv_error_name", "fpv_encoding_id")
 
@@ -210,6 +210,7 @@ def lib() -> C.CDLL:
     L.fpv_diag_stream_copy.argtypes = [vp, vp, i64, vp]
     L.fpv_diag_stream_copy_wide.argtypes = [vp, vp, i64, vp]
     L.fpv_diag_busy.argtypes = [C.c_double, vp]
+    L.fpv_diag_xcd_map.argtypes = [vp, i64, vp]
     L.fpv_comm_unique_id.argtypes = [vp]
     L.fpv_comm_create.argtypes = [vp, C.c_int, C.c_int, C.c_int, C.POINTER(vp)]
     L.fpv_comm_destroy.argtypes = [vp]

@@ -106,6 +106,11 @@ __device__ __forceinline__ void st_drone(float* __restrict__ st, int64_t ld, uin
 }
 
 typedef float fpv_v4f __attribute__((ext_vector_type(4)));
+// Rows that a step only WRITES (the body acceleration, the AoS observation head) leave with the streaming hint, like reward and
+// done: nobody on this path reads them again before the next launch overwrites them, and stored plainly they take L2 lines away
+// from the state rows that the next launch of a rotated chain comes back for (round 6, one box, 2^20 drones: accel rows 22.85 ->
+// 22.35 us per launch, AoS head 32.8 -> 31.4; profiles/r06_exp_nt_output_rows.log).  rotation_blocks() does not count them either.
+#define ST_OUT(ref, v) __builtin_nontemporal_store((v), &(ref))
 
 // The action batch is read once and reward/done are written once per step: non-temporal, so they
 // do not displace the state rows, which are re-read next step, from L2 / Infinity Cache.
@@ -366,7 +371,7 @@ __global__ __launch_bounds__(kStepBlock) FPV_EXP_STEP_ATTR void fpv_drone_step_k
         for (int k = 0; k < 6; ++k) row_at(ROW(Be.pos_comp, k, Be.ld), j) = rst ? 0.0f : kc[k];
     }
     if (Be.accel) {
-        row_at(ROW(Be.accel, 0, Be.ld), j) = o.ax; row_at(ROW(Be.accel, 1, Be.ld), j) = o.ay; row_at(ROW(Be.accel, 2, Be.ld), j) = o.az;
+        ST_OUT(row_at(ROW(Be.accel, 0, Be.ld), j), o.ax); ST_OUT(row_at(ROW(Be.accel, 1, Be.ld), j), o.ay); ST_OUT(row_at(ROW(Be.accel, 2, Be.ld), j), o.az);
     }
     if ((Ke.flags & FPV_FLAG_AUTO_RESET) && o.done) fpv_drone_reset_lane(Ke, s);
     st_drone(Be.state, Be.ld, j, s);
@@ -513,7 +518,7 @@ __global__ __launch_bounds__(kStepBlock) void fpv_drone_rollout_kernel(const Fpv
     uint32_t j = i;
     asm volatile("" : "+v"(j));
     if (E.B.accel) {
-        row_at(ROW(E.B.accel, 0, E.B.ld), j) = o.ax; row_at(ROW(E.B.accel, 1, E.B.ld), j) = o.ay; row_at(ROW(E.B.accel, 2, E.B.ld), j) = o.az;
+        ST_OUT(row_at(ROW(E.B.accel, 0, E.B.ld), j), o.ax); ST_OUT(row_at(ROW(E.B.accel, 1, E.B.ld), j), o.ay); ST_OUT(row_at(ROW(E.B.accel, 2, E.B.ld), j), o.az);
     }
     st_drone(E.B.state, E.B.ld, j, s);
     if (NOISE) {
@@ -550,7 +555,7 @@ __global__ __launch_bounds__(kStepBlock) void fpv_drone_step_aos_kernel(FPV_STEP
         ld_drone(B.state, B.ld, i, s);
         o = fpv_drone_step_lane<false>(K, s, a.x, a.y, a.z, a.w, B.wx, B.wy, B.wz);
         if (B.accel) {
-            row_at(ROW(B.accel, 0, B.ld), i) = o.ax; row_at(ROW(B.accel, 1, B.ld), i) = o.ay; row_at(ROW(B.accel, 2, B.ld), i) = o.az;
+            ST_OUT(row_at(ROW(B.accel, 0, B.ld), i), o.ax); ST_OUT(row_at(ROW(B.accel, 1, B.ld), i), o.ay); ST_OUT(row_at(ROW(B.accel, 2, B.ld), i), o.az);
         }
         if ((K.flags & FPV_FLAG_AUTO_RESET) && o.done) fpv_drone_reset_lane(K, s);
         st_drone(B.state, B.ld, i, s);
@@ -569,7 +574,9 @@ __global__ __launch_bounds__(kStepBlock) void fpv_drone_step_aos_kernel(FPV_STEP
         const int d = f4 >> 2, c = (f4 & 3) * 4;
         if (wave_first + d < n) {
             const float* src = &tile[wave][d * kPitch + c];
-            out[f4] = make_float4(src[0], src[1], src[2], src[3]);
+            fpv_v4f v4;
+            v4.x = src[0]; v4.y = src[1]; v4.z = src[2]; v4.w = src[3];
+            __builtin_nontemporal_store(v4, reinterpret_cast<fpv_v4f*>(out) + f4);      // written once, read by the learner: streaming hint (ST_OUT)
         }
     }
 }
@@ -644,7 +651,7 @@ __global__ __launch_bounds__(kStepBlock) void fpv_drone_step_h_kernel(FPV_STEP_P
         __builtin_amdgcn_sched_barrier(0);       // loads first, constants after (see fpv_drone_step_kernel)
         o = fpv_drone_step_lane<false, true, false, false>(K, s, a.x, a.y, a.z, a.w, B.wx, B.wy, B.wz);
         if (B.accel) {
-            row_at(ROW(B.accel, 0, B.ld), i) = o.ax; row_at(ROW(B.accel, 1, B.ld), i) = o.ay; row_at(ROW(B.accel, 2, B.ld), i) = o.az;
+            ST_OUT(row_at(ROW(B.accel, 0, B.ld), i), o.ax); ST_OUT(row_at(ROW(B.accel, 1, B.ld), i), o.ay); ST_OUT(row_at(ROW(B.accel, 2, B.ld), i), o.az);
         }
         if ((K.flags & FPV_FLAG_AUTO_RESET) && o.done) fpv_drone_reset_lane(K, s);
         th = st_drone_h(B, i, K.noise.id_lo, fpv_round_seed(B.seed, B.step), s);
@@ -732,7 +739,7 @@ __global__ __launch_bounds__(kStepBlock) void fpv_drone_rollout_h_kernel(const F
     const bool live_e = (int64_t)j < E.n;
     if (live_e) {
         if (E.B.accel) {
-            row_at(ROW(E.B.accel, 0, E.B.ld), j) = o.ax; row_at(ROW(E.B.accel, 1, E.B.ld), j) = o.ay; row_at(ROW(E.B.accel, 2, E.B.ld), j) = o.az;
+            ST_OUT(row_at(ROW(E.B.accel, 0, E.B.ld), j), o.ax); ST_OUT(row_at(ROW(E.B.accel, 1, E.B.ld), j), o.ay); ST_OUT(row_at(ROW(E.B.accel, 2, E.B.ld), j), o.az);
         }
         st_packed_h(E.B, j, s, h);
     }
@@ -1005,6 +1012,15 @@ __global__ __launch_bounds__(64) void fpv_diag_busy_kernel(const unsigned long l
         if (wall_clock64() - t0 >= ticks) break;
         __builtin_amdgcn_s_sleep(32);
     }
+}
+
+// Which XCD runs which workgroup: every workgroup writes the XCC_ID hardware register of the XCD it landed on (fpv_diag_xcd_map).
+// The launch geometry is the step kernels' (kStepBlock threads), so what the probe sees is what a step launch of the same grid gets.
+__global__ __launch_bounds__(kStepBlock) void fpv_diag_xcd_kernel(uint32_t* __restrict__ out)
+{
+    uint32_t x;
+    asm volatile("s_getreg_b32 %0, hwreg(HW_REG_XCC_ID)" : "=s"(x));
+    if (threadIdx.x == 0) out[blockIdx.x] = x & 0xfu;
 }
 
 thread_local std::string g_err;
@@ -1322,8 +1338,8 @@ int device_cache_model(int device, fpv_cache_model_t* out)
     return FPV_OK;
 }
 
-// Bytes per drone that one launch WRITES: what fills a cache between two visits of a drone (reads of rows that are written back
-// are the same lines; the stick rows are streamed with a non-temporal hint).  The plain kernel: 14 rows + reward + done = 61 B,
+// Bytes per drone that one launch WRITES with ordinary stores: what fills a cache between two visits of a drone (reads of rows that
+// are written back are the same lines; the stick rows, reward / done, the accel rows and the AoS head go by with a streaming hint).  The plain kernel: 14 rows + reward + done = 61 B,
 // and 4096 blocks of 128 drones x 61 B are the 32 MB of the eight L2s - where the sweep has its optimum.  `d` = the buffers of
 // the launch, or null for an estimate from the handle alone (fpv_get_rotation before the first launch).
 int64_t written_bytes_per_drone(const fpv_env* h, const FpvBufD* d)
@@ -1336,8 +1352,7 @@ int64_t written_bytes_per_drone(const fpv_env* h, const FpvBufD* d)
     if (!d) return b + 5;
     if (d->reward) b += 4;
     if (d->done) b += 1;
-    if (d->accel) b += 12;
-    if (d->obs_aos) b += 64;
+    // (accel rows and the AoS observation head are written with the streaming hint - ST_OUT - and do not compete for the cache)
     if (d->pos_comp) b += 24;
     if (d->action_out) b += 16;
     if (d->ep_return) b += 8;                                   // running return and length (the last_* rows only when an episode ends)
@@ -1677,6 +1692,15 @@ int fpv_diag_stream_copy_wide(float* dst, const float* src, int64_t n_floats, vo
                        reinterpret_cast<const fpv_v4f*>(src), n4);
     const hipError_t e = hipGetLastError();
     if (e != hipSuccess) return hip_fail(e, "diag wide copy launch");
+    return FPV_OK;
+}
+
+int fpv_diag_xcd_map(uint32_t* xcd_of_block, int64_t blocks, void* stream)
+{
+    if (!xcd_of_block || blocks <= 0 || blocks > ((int64_t)1 << 24)) return fail(FPV_EINVAL, "fpv_diag_xcd_map: need a device buffer and 0 < blocks <= 2^24");
+    hipLaunchKernelGGL(fpv_diag_xcd_kernel, dim3((unsigned)blocks), dim3(kStepBlock), 0, (hipStream_t)stream, xcd_of_block);
+    const hipError_t e = hipGetLastError();
+    if (e != hipSuccess) return hip_fail(e, "diag xcd-map launch");
     return FPV_OK;
 }
 

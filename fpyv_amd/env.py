@@ -911,10 +911,13 @@ class FpvVecEnv:
     Calls on the whole population (reset, load_state_dict, state_dict, set_done_bits_target, close) are ordered after
     every partition's enqueued steps on the device - a reset right after a step_async does not race it.
 
-    While the policy looks at partition A, partition B steps, and the two kernel chains overlap on the GPU - each hides a
-    part of the other's per-launch floor (17 % of a 2^20-drone launch).  Drones keep their GLOBAL ids, so
-    every buffer is bit-identical to the unpartitioned env's after the same number of steps, whatever P is.  `step()`
-    still advances all drones (step_async + step_wait over all partitions).
+    While the policy looks at partition A, partition B steps: the policy of one half is hidden behind the step of the other
+    (measured: + 16 % steps per second with a linear policy, + 17 % with a 13-64-4 MLP, profiles/r06_exp_closed_loop_split_phase.log).
+    **Partitions are for loops with a policy between steps.**  A step-only loop (pre-generated or in-kernel sticks) is FASTER
+    unpartitioned - 20.0 against 22.0 us per step at 2^20 drones (profiles/r06_bench_n1_step_partitions2.json): two chains side by
+    side share the L2s that the single chain's rotated traversal has to itself - and faster still through `rollout()`.
+    Drones keep their GLOBAL ids, so every buffer is bit-identical to the unpartitioned env's after the same number of steps,
+    whatever P is.  `step()` still advances all drones (step_async + step_wait over all partitions).
     """
 
     def __init__(self, params: Optional[DroneParams] = None, num_envs: int = 1, device: Any = "cuda:0",

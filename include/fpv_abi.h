@@ -308,7 +308,8 @@ int fpv_get_step_counter(fpv_handle_t h, uint64_t* step);
  * previous launch started - i.e. on the rows the previous launch wrote last - and wraps around, ascending addresses all the
  * way; the results do not depend on the order (bit-identical).  The same holds one level up: the eight 4 MiB L2s keep the last
  * 32 MiB across a kernel boundary.  drones = -1 (default): automatic - the drones whose WRITTEN bytes (state rows, reward,
- * done and whatever else the call's buffers ask for: accel, AoS observations, Kahan rows ...) fill 61/64 of the cache level that
+ * done and whatever else the call's buffers ask for and re-reads: Kahan rows, noise rows, episode sums ...; the accel rows and the AoS
+ * observation head leave with a streaming hint and are not counted) fill 61/64 of the cache level that
  * a launch overflows (2^19 drones for the plain kernel's 61 B beyond the L2s, 2^22 beyond the Infinity Cache; whole rounds of the
  * eight XCDs), 0 when a launch writes less than the L2s hold; 0: plain order; > 0: that many drones (rounded down to whole
  * 128-drone workgroups).  fpv_get_rotation returns the value of the last launch (before the first: the estimate for reward
@@ -376,6 +377,12 @@ int fpv_diag_stream_copy(float* dst, const float* src, int64_t n_floats, void* s
 /* the same copy with 16 bytes per lane (n_floats a multiple of 4, 16-byte aligned pointers): the streaming ceiling of
  * the chip on this box - bench.py times it beside the step kernel at 2^23 drones (roofline.beyond_mall.copy_ceiling_GBs) */
 int fpv_diag_stream_copy_wide(float* dst, const float* src, int64_t n_floats, void* stream);
+/* which XCD runs which workgroup: a launch of `blocks` workgroups of the step kernels' size (128 threads) on `stream` of the
+ * current device; workgroup b writes the id (0-7, hardware register XCC_ID) of the XCD it was dispatched to into
+ * xcd_of_block[b] (device memory, `blocks` words).  The rotation of the traversal keeps a drone block on "its" XCD from launch
+ * to launch only if the dispatcher deals workgroups round-robin over the eight XCDs AND starts every launch of a chain on the
+ * same XCD - HIP promises neither; this is the probe that watches both (tools/xcd_map_probe.py, bench.py `roofline.xcd_map`). */
+int fpv_diag_xcd_map(uint32_t* xcd_of_block, int64_t blocks, void* stream);
 /* one wave that does nothing for about `microseconds` (0 < microseconds <= 1000; bounded by the constant-rate clock AND by
  * an iteration count, so every lane leaves) on `stream` of the current device: a kernel of known duration that occupies one
  * CU.  Two streams whose chains of such kernels take as long together as one chain alone run on different hardware

@@ -2501,7 +2501,11 @@ def test_rotation_is_automatic_beyond_the_l2s_and_beyond_the_infinity_cache(para
     acc = DroneBatch(params_1k, 1 << 20, device=DEV, with_accel=True, kahan_position=True)               # what a launch writes decides: + accel rows + Kahan rows
     assert acc.rotation == 1 << 19                                                                       # (the estimate before the first launch knows reward and done only)
     acc.reset(); acc.step(torch.zeros((1 << 20, 4), device=DEV), return_imu=False)
-    assert acc.rotation == share(L2, 61 + 12 + 24)
+    assert acc.rotation == share(L2, 61 + 24)                                                            # (the accel rows leave with a streaming hint and are not counted; the Kahan rows are re-read)
+    aos = DroneBatch(params_1k, 1 << 20, device=DEV, with_accel=False, with_obs_aos=True)                # the AoS head likewise: written once, streamed
+    aos.reset(); aos.step(torch.zeros((1 << 20, 4), device=DEV), return_imu=False)
+    assert aos.rotation == 1 << 19
+    del aos
     del acc
     del noisy
     torch.cuda.empty_cache()

@@ -106,6 +106,30 @@ def test_recommended_row_stride_does_not_cost_time(params_1k):
     assert t_rec < GUARD * t_old, (t_rec, t_old)
 
 
+def test_workgroups_are_dealt_round_robin_over_the_eight_xcds():
+    """The dispatcher behaviour the rotation's L2 tier rests on, watched through the XCC_ID register (fpv_diag_xcd_map): within a
+    launch workgroup b runs on XCD (b + s) mod 8, and s does not move from launch to launch of a chain - so a drone block meets the
+    same L2 again.  HIP promises neither; a firmware that deals differently costs cache reuse, never a result - which is why this
+    sits with the performance assumptions and not in the parity gate.  Observed on every box so far: s = 0, always."""
+    L = _lib.lib()
+    rows = {}
+    for blocks in (8192, 7816, 65536):
+        out = torch.full((16, blocks), 99, dtype=torch.int32, device=DEV)
+        for t in range(16):
+            _lib.check(L.fpv_diag_xcd_map(out[t].data_ptr(), blocks, None))
+        torch.cuda.synchronize()
+        m = out.cpu()
+        b = torch.arange(blocks, dtype=torch.int32)
+        shifts = [int(r[0]) % 8 for r in m]
+        exact = [bool(torch.equal(r, (b + s) % 8)) for r, s in zip(m, shifts)]
+        rows[str(blocks)] = dict(shifts=shifts, exactly_round_robin=all(exact), xcds_seen=sorted(set(m.flatten().tolist())))
+    record("xcd_round_robin", **rows)
+    for blocks, r in rows.items():
+        assert r["exactly_round_robin"] and r["xcds_seen"] == list(range(8)), (blocks, r)
+        assert len(set(r["shifts"])) == 1, (blocks, r["shifts"])
+    assert L.fpv_diag_xcd_map(None, 8, None) == -1 and L.fpv_diag_xcd_map(1, 0, None) == -1
+
+
 def test_busy_kernel_duration_and_stream_overlap():
     """fpv_diag_busy(200 us) x 20 on one stream takes about 4 ms; two chains on ONE stream take twice one chain (ratio ~2), on
     streams the probe accepted about as long as one (ratio ~1).  Guards: a factor of 5 on the duration, 1.5 between "serial" and

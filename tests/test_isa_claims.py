@@ -29,7 +29,7 @@ def _design():
 
 def test_no_scratch_no_mfma_no_spill_in_any_kernel(isa):
     h, bodies, res = isa
-    assert len(bodies) == 41 and len(res) >= 41
+    assert len(bodies) == 42 and len(res) >= 42
     for name, body in bodies.items():
         c = h.counts(body)
         assert c["scratch_flat_buffer"] == 0, name
@@ -37,7 +37,7 @@ def test_no_scratch_no_mfma_no_spill_in_any_kernel(isa):
         assert c["sgpr_spill_lane_ops"] == 0, name
     for name, r in res.items():
         assert r.get("scratch", 0) == 0 and r.get("sspill", 0) == 0 and r.get("vspill", 0) == 0, (name, r)
-    assert "41 kernels" in _design()
+    assert "42 kernels" in _design()
 
 
 def test_plain_step_kernel_counts_as_design_quotes(isa):

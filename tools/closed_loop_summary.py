@@ -48,7 +48,7 @@ for s in ab["sizes"]:
     m = s["us_per_step"]
     print(f"| {s['drones']} | {s['rotation_auto_drones']} | {m['closed_auto']['median']:.1f} us | {m['closed_plain']['median']:.1f} us | "
           f"{100 * (s['closed_loop_rotation_gain'] - 1):+.1f} % | {m['step_auto']['median']:.2f} us | {m['step_plain']['median']:.2f} us | {100 * (s['step_only_rotation_gain'] - 1):+.1f} % |")
-print("\n(`DroneBatch` defaults of the A/B: accel rows on, so a launch writes 73 B per drone and the automatic step is 61/64 of the cache / 73 B.)\n")
+print("\n(`DroneBatch` defaults of the A/B: accel rows on; they are written with a streaming hint and do not change the automatic rotation.)\n")
 print("The step kernel alone, inside the loop (kernel trace, average over the timed + warm-up launches):\n")
 print("| drones | step kernel, rotation auto | step kernel, plain order | GEMM, auto | GEMM, plain |")
 print("|---|---|---|---|---|")

@@ -18,6 +18,13 @@ cp $O/gpu_tests.log        $P/${R}_gpu_tests.log
 cp $O/gpu_timing.log       $P/${R}_gpu_timing.log
 cp $O/timing_guards.json   $P/${R}_timing_guards.json
 cp $O/device_props.json    $P/${R}_device_props.json
+python3 - $O/xcd_map.json $P/${R}_xcd_map.json <<'PY'
+import json, sys
+d = json.load(open(sys.argv[1]))
+for v in d.values():                      # 64 equal numbers per scenario say no more than their set
+    v["distinct_shifts"] = sorted(set(v.pop("shifts")))
+json.dump(d, open(sys.argv[2], "w"), indent=1)
+PY
 f=$(ls -t $O/prof_kt_variants/*/*_kernel_stats.csv | head -1); cp "$f" $P/${R}_kernel_stats_variants.csv
 fi
 if [ "$STAGE" = counters ]; then exit 0; fi

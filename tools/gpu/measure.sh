@@ -18,6 +18,7 @@ timeout -k 10 900 python -m pytest tests -m gpu -q > $O/gpu_tests.log 2>&1; echo
 # wall-clock ratios: NOT part of the gate (marker gpu_timing); the measured ratios land in $O/timing_guards.json
 FPV_TIMING_JSON=$O/timing_guards.json timeout -k 10 400 python -m pytest tests/test_gpu_timing.py -m gpu_timing -q > $O/gpu_timing.log 2>&1; echo "timing rc=$?" >> $O/gpu_timing.log; tail -2 $O/gpu_timing.log
 python3 tools/gpu/device_props.py > $O/device_props.json 2> /dev/null; echo "props rc=$?"
+timeout -k 10 200 python3 tools/xcd_map_probe.py --out $O/xcd_map.json > $O/xcd_map.log 2>&1; echo "xcd map rc=$?"
 # counters first (they define traffic / VALU counts that the bench lines quote)
 timeout -k 10 300 rocprofv3 --kernel-trace --pmc SQ_INSTS_VALU SQ_INSTS_SALU SQ_WAVES --output-format csv -d $O/pmc_valu -- python3 tools/kernel_sweep.py --fp16 --racer --noise --extras --fused --rounds 1 --launches 64 --ring 32 > $O/pmc_valu.log 2>&1; echo "pmc valu rc=$?"
 python3 tools/pmc_valu.py $O/pmc_valu --steps-per-launch 32 --round $R > $O/valu_counts.log 2>&1; tail -2 $O/valu_counts.log
