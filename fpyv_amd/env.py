@@ -912,9 +912,9 @@ class FpvVecEnv:
     every partition's enqueued steps on the device - a reset right after a step_async does not race it.
 
     While the policy looks at partition A, partition B steps: the policy of one half is hidden behind the step of the other
-    (measured: + 16 % steps per second with a linear policy, + 17 % with a 13-64-4 MLP, profiles/r06_exp_closed_loop_split_phase.log).
+    (measured: + 16...26 % steps per second with a linear policy, + 16 % with a 13-64-4 MLP, profiles/r06_exp_closed_loop_split_phase.log).
     **Partitions are for loops with a policy between steps.**  A step-only loop (pre-generated or in-kernel sticks) is FASTER
-    unpartitioned - 20.0 against 22.0 us per step at 2^20 drones (profiles/r06_bench_n1_step_partitions2.json): two chains side by
+    unpartitioned - 20.1 against 22.0 us per step at 2^20 drones (profiles/r06_bench_n1_step_partitions2.json): two chains side by
     side share the L2s that the single chain's rotated traversal has to itself - and faster still through `rollout()`.
     Drones keep their GLOBAL ids, so every buffer is bit-identical to the unpartitioned env's after the same number of steps,
     whatever P is.  `step()` still advances all drones (step_async + step_wait over all partitions).
