@@ -1338,10 +1338,12 @@ int device_cache_model(int device, fpv_cache_model_t* out)
     return FPV_OK;
 }
 
-// Bytes per drone that one launch WRITES with ordinary stores: what fills a cache between two visits of a drone (reads of rows that
-// are written back are the same lines; the stick rows, reward / done, the accel rows and the AoS head go by with a streaming hint).  The plain kernel: 14 rows + reward + done = 61 B,
-// and 4096 blocks of 128 drones x 61 B are the 32 MB of the eight L2s - where the sweep has its optimum.  `d` = the buffers of
-// the launch, or null for an estimate from the handle alone (fpv_get_rotation before the first launch).
+// Bytes per drone that one launch WRITES and that compete for a cache between two visits of a drone (reads of rows that are
+// written back are the same lines).  The plain kernel: 14 rows + reward + done = 61 B, and 4096 blocks of 128 drones x 61 B are the
+// 32 MB of the eight L2s - where the sweep has its optimum (reward and done carry a streaming hint but stay in the count: the 61/64
+// factor was fitted with them in).  The stick rows are only read; the accel rows and the AoS head are write-only rows stored with
+// the streaming hint (ST_OUT) and measured not to compete (profiles/r06_exp_nt_output_rows.log).  `d` = the buffers of the launch,
+// or null for an estimate from the handle alone (fpv_get_rotation before the first launch).
 int64_t written_bytes_per_drone(const fpv_env* h, const FpvBufD* d)
 {
     int64_t b;
