@@ -281,7 +281,7 @@ def cpu_baseline(params, seconds_budget=12.0):
     return {"value": best["value"], "unit": "env-steps/s", "cores": threads, "kind": "port",
             "leg": "simd_across_drones" if best_is_simd else "scalar_per_drone",
             "sample": best["sample"] + f"; {usable} usable of {os.cpu_count()} logical CPUs (nproc / cgroup quota); reference's own Python Drone.step, timed in the "
-                      f"build container only (it cannot travel): 2.7e3-4.0e3 env-steps/s on one core (profiles/r01_reference_python_timing.json)",
+                      f"build container only (it cannot travel): 2.7e3-4.0e3 env-steps/s on one core (profiles/archive/r01_reference_python_timing.json)",
             "one_thread_value": best["one_thread_value"], "host_cpus": os.cpu_count(), "usable_cpus": usable, "threads_used": threads,
             "scalar_per_drone": scalar,
             "simd_across_drones": simd,
@@ -530,7 +530,7 @@ def parse_args(argv=None):
     ap.add_argument("--no-gather", action="store_true", help="skip the done-mask all-gather (N > 1)")
     ap.add_argument("--gather-block", type=int, default=0,
                     help="steps of done masks bucketed into one all-gather (N > 1); 0 = sized to the run: every collective "
-                         "costs the launch stream ~25 us whatever its size (measured, profiles/r02_exp_gather_block.log), so long "
+                         "costs the launch stream ~25 us whatever its size (measured, profiles/archive/r02_exp_gather_block.log), so long "
                          "runs use 64-step buckets (8 MiB per rank, 1.5 %% of the time) and runs under 256 steps 16-step buckets, "
                          "whose unfilled tail - gathered inside the timed region - stays small")
     ap.add_argument("--gather-returns", action="store_true",

@@ -1,7 +1,7 @@
 // fpv_hip.hip - gfx950 kernels + the C ABI of include/fpv_abi.h.
 //
 // One lane = one drone: every wave instruction touches 256 contiguous bytes of one SoA row.  Measured on MI355X
-// (profiles/r01_exp_*.log, r03_exp_wide_rows_beyond_mall.log): 128-thread workgroups beat 64/256/512/1024,
+// (profiles/archive/r01_exp_*.log, r03_exp_wide_rows_beyond_mall.log): 128-thread workgroups beat 64/256/512/1024,
 // one drone per lane beats 2/4 with float2/float4 rows at 2^20 AND at 2^23 drones, persistent/grid-stride/prefetch
 // loops lose to plain oversubscription, non-temporal hints on the once-touched operands (action in, reward/done out)
 // are worth ~0.5 %, and a row stride that is NOT a multiple of 8 KiB is worth 6-9 % (fpv_recommended_ld).  A step is:
@@ -39,7 +39,7 @@ namespace {
 
 constexpr int kBlock = 256;   // reset / pid / diag kernels: 4 wave64 per workgroup
 // step and k-step kernels: 128-thread workgroups (2 wave64), the fastest of 64/128/256/512/1024 in every measurement
-// (profiles/r01_exp10_shapes_clean.log, r02_sweep_geometry.log); fpv_exp.h: -DFPV_EXP_BLOCK=N rebuilds them all for an A/B
+// (profiles/archive/r01_exp10_shapes_clean.log, r02_sweep_geometry.log); fpv_exp.h: -DFPV_EXP_BLOCK=N rebuilds them all for an A/B
 constexpr int kStepBlock = FPV_EXP_BLOCK;
 static_assert(kStepBlock % 64 == 0 && kStepBlock >= 64 && kStepBlock <= 1024, "whole wave64s");
 
@@ -261,7 +261,7 @@ __device__ __forceinline__ float4 apply_stick_noise(const FpvK& K, const FpvBufD
 // simulator.py:110): nine more floats and the thrust force per drone, read with a 36-byte lane stride - the
 // matrices arrive in the caller's [n][3][3] layout; this is the closed-loop guidance path, not the headline one.
 // One drone per lane, kStepBlock threads per workgroup: 2 / 4 drones per lane and 256-thread workgroups lost every
-// measurement of rounds 1-2 (profiles/r01_exp10_shapes_clean.log, r02_sweep_geometry.log) and were removed in round 3.
+// measurement of rounds 1-2 (profiles/archive/r01_exp10_shapes_clean.log, r02_sweep_geometry.log) and were removed in round 3.
 // The single-step kernels take what their FIRST instructions need - the state and action bases, the row stride, n - as
 // plain leading scalars, ahead of the two argument structs.  The library is built with
 // -mllvm -amdgpu-kernarg-preload-count=6 (six leading 8-byte arguments = 12 dwords): on gfx950 the command processor then
@@ -269,7 +269,7 @@ __device__ __forceinline__ float4 apply_stick_noise(const FpvK& K, const FpvBufD
 // kernel-argument segment in SGPRs at wave launch, so a wave issues its 15 vector loads at once instead of first
 // waiting for a scalar load of those pointers - a cold one at every kernel start, because the scalar cache and L2
 // are invalidated at the kernel boundary.  It is the head of the per-launch floor of a chain of dependent step
-// kernels (profiles/r03_exp_launch_floor.log).  (Firmware without the feature runs the compiler's compatibility
+// kernels (profiles/archive/r03_exp_launch_floor.log).  (Firmware without the feature runs the compiler's compatibility
 // prologue, which loads the same prefix with s_load: same results either way.)  The structs that follow still carry
 // the same fields; fpv_step_view() overrides them, so their kernarg copies are never loaded.
 #define FPV_STEP_PARAMS float* __restrict__ a_state, const int64_t a_ld, const float4* __restrict__ a_action, \
@@ -356,7 +356,7 @@ __global__ __launch_bounds__(kStepBlock) FPV_EXP_STEP_ATTR void fpv_drone_step_k
     // ---- 3. the stores
     // OBJ: the store addresses are formed only now - the 14 row-address pairs the compiler would otherwise carry from
     // the loads to the stores (28 VGPRs) come on top of the object pass's own registers (102 VGPRs, 4 waves per SIMD);
-    // the plain kernel is faster WITH the carried addresses (profiles/r02_exp_state_cache_policy.log) and keeps them
+    // the plain kernel is faster WITH the carried addresses (profiles/archive/r02_exp_state_cache_policy.log) and keeps them
     uint32_t j = i;
     if (OBJ || SECTIONED) FPV_KEEP_HERE(j);
     const FpvStepArgs* E = nullptr;

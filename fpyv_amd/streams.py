@@ -3,7 +3,7 @@
 Two chains of dependent kernels overlap on the GPU only when their streams sit on different hardware queues.  The HIP
 runtime owns a handful of hardware queues per device and shares them among streams once all are handed out; chains on a
 shared queue do not overlap - they interleave, slower than one chain alone (measured on MI355X, 2^20 drones as two
-partitions: 21.6 us per step on separate queues, 26-35 us on a shared one; `profiles/r04_exp_split_streams.log`).  Which
+partitions: 21.6 us per step on separate queues, 26-35 us on a shared one; `profiles/archive/r04_exp_split_streams.log`).  Which
 stream lands on which queue is the runtime's business and differs from stream to stream, so this module does not guess:
 it MEASURES - a chain of time-bounded one-wave kernels (`fpv_diag_busy`) on each of two streams takes as long as one
 chain alone when the queues differ and twice as long when they are shared - and keeps drawing streams until it holds a

@@ -15,7 +15,7 @@ def pts(us):
 
 
 def test_points_on_a_line_give_a_valid_fit():
-    # the builder's round-4 measurement (profiles/r04_bench_n1_step.json)
+    # the builder's round-4 measurement (profiles/archive/r04_bench_n1_step.json)
     f = bench.fit_launch_time(pts([13.124, 22.291, 40.751]))
     assert f["valid"] and f["invalid_reason"] is None
     assert 3.5 < f["floor_us"] < 4.5 and f["max_residual_us"] < 0.1
