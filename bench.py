@@ -539,7 +539,7 @@ def parse_args(argv=None):
     ap.add_argument("--force-dist", action="store_true",
                     help="rehearsal: run the RCCL process group + all-gather path even with one rank")
     ap.add_argument("--rehearse-on-one-gpu", action="store_true",
-                    help="TEST ONLY (tests/test_gpu_parity.py): run the real N-rank path - shards, per-rank stick streams, kernels, "
+                    help="TEST ONLY (tests/test_gpu_boundary.py): run the real N-rank path - shards, per-rank stick streams, kernels, "
                          "bucketed done-mask all-gather, flush, MAX over ranks - with every rank on GPU 0 and the gloo backend (RCCL "
                          "refuses two ranks on one device); the line is marked data=rehearsal and its value means nothing")
     ap.add_argument("--dump-gathered", default=None,

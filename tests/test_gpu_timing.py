@@ -8,7 +8,7 @@ Every test measures a ratio, writes it to $FPV_TIMING_JSON (default gpurun_out/t
 profiles/<round>_timing_guards.json) and asserts only a REGRESSION GUARD whose margin lies outside anything a healthy box has
 shown: "the optimisation does not cost time" (ratio < 1.05), never "the optimisation pays this much" - how much it pays is what
 the JSON and bench.py's `beyond_mall.plain_order_avg_launch_us` say.  The bit-identity halves of the same experiments are in
-tests/test_gpu_parity.py (test_rotation_is_automatic_..., test_ragged_population_..., test_results_do_not_depend_on_the_row_stride).
+tests/test_gpu_traversal.py (test_rotation_is_automatic_..., test_ragged_population_..., test_results_do_not_depend_on_the_row_stride).
 
 Path under test: /root/reference/src/utils/components.py:220-248 (Drone.step), chained as simulator.py:83-156 chains it.
 """

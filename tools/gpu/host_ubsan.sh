@@ -14,7 +14,7 @@ cp fpyv_amd/libfpv_hip.so gpurun_out/ubsan/libfpv_hip.plain.so
 RT=$(/opt/rocm/lib/llvm/bin/clang -print-file-name=libclang_rt.ubsan_standalone-x86_64.so)
 echo "ubsan runtime: $RT"
 LD_PRELOAD=$RT UBSAN_OPTIONS=print_stacktrace=1:halt_on_error=1:log_path=gpurun_out/ubsan/ubsan \
-    timeout -k 10 900 python3 -m pytest tests/test_gpu_parity.py -m gpu -q -x -k "not bench and not plain_c_host and not two_host_threads" > gpurun_out/ubsan/tests.log 2>&1
+    timeout -k 10 900 python3 -m pytest tests/test_gpu_parity.py tests/test_gpu_fp16.py tests/test_gpu_kstep.py tests/test_gpu_boundary.py tests/test_gpu_traversal.py -m gpu -q -x -k "not bench and not plain_c_host and not two_host_threads" > gpurun_out/ubsan/tests.log 2>&1
 rc=$?
 cp gpurun_out/ubsan/libfpv_hip.plain.so fpyv_amd/libfpv_hip.so
 tail -5 gpurun_out/ubsan/tests.log
