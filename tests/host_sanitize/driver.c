@@ -41,6 +41,22 @@ int main(void)
     int64_t rot = -2;
     if (fpv_get_rotation(0, &rot) >= 0) return 12;                                  /* null handle */
     if (fpv_set_rotation(0, 128) >= 0) return 13;
+    /* the cache-model rule (ABI 8) is host arithmetic: every text field is bounded, whatever the device calls itself */
+    fpv_cache_model_t m;
+    char longname[600];
+    memset(longname, 'x', sizeof longname - 1);
+    longname[sizeof longname - 1] = 0;
+    memcpy(longname, "gfx950:", 7);
+    if (fpv_check_cache_model(longname, 256, 4 << 20, &m) != FPV_OK || !m.matches || strlen(m.arch) != sizeof m.arch - 1) return 14;
+    memcpy(longname, "gfx9999", 7);
+    if (fpv_check_cache_model(longname, 256, 4 << 20, &m) != FPV_OK || m.matches || strlen(m.reason) >= sizeof m.reason || !strstr(m.reason, "is not gfx950")) return 15;
+    if (fpv_check_cache_model("gfx950:sramecc+:xnack-", 32, 4 << 20, &m) != FPV_OK || m.matches || !strstr(m.reason, "32 compute units")) return 16;
+    if (fpv_check_cache_model("gfx950", 256, 0, &m) != FPV_OK || !m.matches || m.xcds != 8 || m.reason[0]) return 17;
+    if (fpv_check_cache_model(0, 256, 0, &m) >= 0 || fpv_check_cache_model("gfx950", 256, 0, 0) >= 0) return 18;
+    if (fpv_sizeof(4) != (int)sizeof(fpv_cache_model_t) || m.struct_size != sizeof m) return 19;
+    if (fpv_get_cache_model(0, &m) >= 0) return 20;
+    if (!fpv_encoding_id(0) || !fpv_encoding_id(1) || fpv_encoding_id(2) || fpv_encoding_id(-1)) return 21;
+    if (fpv_diag_xcd_map(0, 8, 0) >= 0) return 22;                                  /* refused before any device is touched */
     fpv_destroy(0);                                                                 /* destroying nothing is a no-op, never a crash */
     printf("host sanitizers: clean (%lld strides checked; last error text: %s)\n", (long long)checked, fpv_last_error());
     return 0;
