@@ -261,6 +261,16 @@ def test_rotation_is_automatic_beyond_the_l2s_and_beyond_the_infinity_cache(para
     from fpyv_amd.env import DroneBatch
     share = lambda cache, written: cache // 64 * 61 // written // 128 // 8 * 8 * 128      # noqa: E731  (61/64 of the cache, whole rounds of the eight XCDs)
     L2, MALL = 32 << 20, 256 << 20
+    # the rule applies because the device is the one the cache model was measured on (fpv_create asked it: ABI 8); elsewhere the
+    # automatic setting is the plain order (tests/test_device_guard.py drives that through a stand-in runtime)
+    probe = DroneBatch(params_1k, 4096, device=DEV, with_accel=False)
+    cm = probe.cache_model
+    assert cm["matches"] and cm["arch"].startswith("gfx950") and cm["compute_units"] == 256 and cm["xcds"] == 8 and cm["reason"] is None, cm
+    assert cm["l2_bytes_per_xcd"] in (0, 4 << 20) and cm["infinity_cache_bytes"] == MALL
+    L = _lib.lib()
+    for n in (4096, 1 << 19, 1_000_000, 1 << 20, 3 << 20):
+        assert L.fpv_recommended_ld_device(n, 0) == L.fpv_recommended_ld(n)
+    assert L.fpv_recommended_ld_device(1 << 20, 99) < 0 and b"device index" in L.fpv_last_error()
     assert DroneBatch(params_1k, 1 << 19, device=DEV, with_accel=False).rotation == 0                      # a launch writes 32 MB: the L2s hold it
     assert DroneBatch(params_1k, 1 << 20, device=DEV, with_accel=False).rotation == share(L2, 61) == 1 << 19
     assert DroneBatch(params_1k, 1 << 22, device=DEV, with_accel=False).rotation == 1 << 19
