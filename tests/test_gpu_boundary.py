@@ -850,3 +850,21 @@ def test_sharded_example_under_the_launcher_two_ranks_on_one_gpu():
     assert r.returncode == 0, (r.stdout + r.stderr)[-3000:]
     assert "2 ranks x 32768 drones over gloo, 150 steps" in r.stdout and "(must agree)" in r.stdout
     assert "equals its slice of the unsharded run bit for bit" in r.stdout
+
+
+@pytest.mark.parametrize("script,args,expect", [
+    ("simulator_headless.py", ["--drones", "2048", "--steps", "300"], ["2048 drones x 300 steps", "crashed into ground/obstacles/target"]),
+    ("guidance_headless.py", ["--drones", "2048", "--steps", "300"], ["2048 drones x 300 guided steps", "closest approach to the moving target"]),
+    ("closed_loop_policy.py", ["--drones", "16384", "--steps", "60", "--partitions", "1", "2"], ["16384 drones, 60 closed-loop steps", "split phase with 2 partitions"]),
+], ids=["simulator", "guidance", "closed_loop"])
+def test_examples_run_end_to_end(script, args, expect):
+    """The headless replays of the reference's own loops (examples/: simulator.py:83-156 with its object list, the guidance branch of
+    :110, the closed policy loop on the zero-copy observation) run to the end against the library as it is built now."""
+    import os
+    import subprocess
+    import sys
+    from conftest import REPO
+    r = subprocess.run([sys.executable, os.path.join(REPO, "examples", script)] + args, capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0, (r.stdout + r.stderr)[-3000:]
+    for s in expect:
+        assert s in r.stdout, (s, r.stdout[-2000:])
