@@ -10,9 +10,22 @@
 
 static int env_int(const char* k, int dflt) { const char* v = getenv(k); return v && *v ? atoi(v) : dflt; }
 
+/* the thread's current device and every hipSetDevice call, so that a driver can watch the library's scoped device binding
+ * (DeviceGuard in csrc/fpv_hip.hip) switch to a handle's device and put the caller's back */
+static int g_current = 0, g_calls[64], g_ncalls = 0;
+int fake_hip_current_device(void) { return g_current; }
+int fake_hip_set_device_calls(int* out, int max) { for (int i = 0; i < g_ncalls && i < max; ++i) out[i] = g_calls[i]; return g_ncalls; }
+void fake_hip_make_current(int device) { g_current = device; }
+
 hipError_t hipGetDeviceCount(int* count) { *count = env_int("FAKE_HIP_DEVICES", 1); return hipSuccess; }
-hipError_t hipGetDevice(int* device) { *device = 0; return hipSuccess; }
-hipError_t hipSetDevice(int device) { (void)device; return hipSuccess; }
+hipError_t hipGetDevice(int* device) { *device = g_current; return hipSuccess; }
+hipError_t hipSetDevice(int device)
+{
+    if (device < 0 || device >= env_int("FAKE_HIP_DEVICES", 1)) return hipErrorInvalidDevice;
+    if (g_ncalls < 64) g_calls[g_ncalls++] = device;
+    g_current = device;
+    return hipSuccess;
+}
 
 hipError_t hipGetDevicePropertiesR0600(hipDeviceProp_tR0600* prop, int device)
 {

@@ -80,3 +80,23 @@ def test_an_unexpected_device_gets_the_plain_order_and_says_why(fake, props, wor
         ld = d["ld_device"]                                                # the model-free stride: 64-float rounding + clear of 8 KiB
         assert ld >= n and ld % 64 == 0 and ld - n < 64 + 256 and (ld % 2048) >= 256
     assert fake(1 << 19, **props)["ld_device"] == (1 << 19) + 256 and fake(1 << 19, **props)["ld_model"] == (1 << 19) + 320
+
+
+def test_launching_calls_bind_the_handles_device_and_put_the_callers_back(tmp_path):
+    """DeviceGuard (csrc/fpv_hip.hip) on a host with TWO devices - its switch branch never ran on the builder's one-GPU boxes
+    (Missing #4).  The stand-in runtime reports two devices and records hipSetDevice; a handle created on device 1 is
+    stepped while the caller's device is 0: the library switches to 1 and back to 0 - also though the launch itself then fails
+    (there is no GPU under it here: FPV_ENODEV), i.e. on the error path; a handle on the caller's own device causes no switch."""
+    so, exe, blob = str(tmp_path / "libfake_hip.so"), str(tmp_path / "driver_guard"), str(tmp_path / "params.bin")
+    subprocess.run(["gcc", "-O1", "-shared", "-fPIC", "-I/opt/rocm/include", "-o", so, os.path.join(FAKE, "fake_hip.c")], check=True)
+    subprocess.run(["gcc", "-O1", "-o", exe, os.path.join(FAKE, "driver_guard.c"), "-L" + os.path.join(REPO, "fpyv_amd"), "-lfpv_hip", "-ldl",
+                    "-Wl,-rpath," + os.path.join(REPO, "fpyv_amd"), "-Wl,-rpath,/opt/rocm/lib"], check=True)
+    with open(blob, "wb") as f:
+        f.write(bytes(_lib.pack_params(load_params(fps=1000), auto_reset=True)))
+    r = subprocess.run([exe, blob], capture_output=True, text=True, env=dict(os.environ, LD_PRELOAD=so, FAKE_HIP_DEVICES="2"), timeout=120)
+    assert r.returncode == 0, (r.returncode, r.stdout, r.stderr)
+    d = json.loads(r.stdout.strip().splitlines()[-1])
+    assert (d["set_device_calls"], d["first"], d["second"], d["current_after"]) == (2, 1, 0, 0), d           # to the handle's device and back
+    assert (d["set_device_calls_same_device"], d["current_after_same"]) == (0, 0), d                         # already current: no HIP call
+    assert (d["set_device_calls_reset"], d["reset_first"], d["reset_second"], d["current_after_reset"]) == (2, 0, 1, 1), d
+    assert d["rc_step_other_device"] < 0 and d["rc_step_same_device"] < 0 and d["rc_reset_from_device_1"] < 0     # no GPU under the stand-in: loud, not silent
